@@ -1,0 +1,175 @@
+"""Deterministic synthetic weights for parity tests and benchmarks.
+
+No checkpoint exists offline, so every parity/bench run uses seeded synthetic
+weights at the real architecture dimensions.  Weights are never committed: both sides of a
+comparison (this container, the GPU box, the golden-fixture generator) regenerate them from
+this counter-based generator, which uses only exact integer arithmetic and a single IEEE fp32
+multiply, so the bits do not depend on the numpy/torch version or the CPU.
+
+Stream definition (all arithmetic mod 2**64):
+    key    = splitmix64(seed ^ fnv1a64(tensor_name))
+    u64(i) = splitmix64(key + (i + 1) * 0x9E3779B97F4A7C15)
+    uniform: top 24 bits k -> (k - 2**23 + 0.5) / 2**23           in (-1, 1), exact in fp32
+    normal : four 16-bit fields a,b,c,d -> (a+b+c+d - 2*65535) * (sqrt(3)/65536)   (Irwin-Hall)
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+_GAMMA = np.uint64(0x9E3779B97F4A7C15)
+_M1 = np.uint64(0xBF58476D1CE4E5B9)
+_M2 = np.uint64(0x94D049BB133111EB)
+
+
+def _splitmix64(z: np.ndarray) -> np.ndarray:
+    z = (z ^ (z >> np.uint64(30))) * _M1
+    z = (z ^ (z >> np.uint64(27))) * _M2
+    return z ^ (z >> np.uint64(31))
+
+
+def fnv1a64(name: str) -> int:
+    h = 0xCBF29CE484222325
+    for b in name.encode("utf-8"):
+        h = ((h ^ b) * 0x100000001B3) & 0xFFFFFFFFFFFFFFFF
+    return h
+
+
+def _raw(seed: int, name: str, n: int, start: int = 0) -> np.ndarray:
+    with np.errstate(over="ignore"):
+        key = _splitmix64(np.array([(seed ^ fnv1a64(name)) & 0xFFFFFFFFFFFFFFFF], dtype=np.uint64))[0]
+        idx = np.arange(start + 1, start + n + 1, dtype=np.uint64)
+        return _splitmix64(key + idx * _GAMMA)
+
+
+_CHUNK = 1 << 24
+
+
+def uniform(seed: int, name: str, shape, scale: float) -> np.ndarray:
+    """fp32 array, U(-scale, scale)."""
+    n = int(np.prod(shape))
+    out = np.empty(n, dtype=np.float32)
+    for s in range(0, n, _CHUNK):
+        m = min(_CHUNK, n - s)
+        k = (_raw(seed, name, m, s) >> np.uint64(40)).astype(np.int64)
+        v = (k - (1 << 23)).astype(np.float32) + np.float32(0.5)
+        out[s:s + m] = v * np.float32(scale / float(1 << 23))
+    return out.reshape(shape)
+
+
+_IH = np.float32(np.sqrt(3.0) / 65536.0)
+
+
+def normal(seed: int, name: str, shape, std: float = 1.0) -> np.ndarray:
+    """fp32 array, approximately N(0, std^2) (sum of four 16-bit uniforms)."""
+    n = int(np.prod(shape))
+    out = np.empty(n, dtype=np.float32)
+    for s in range(0, n, _CHUNK):
+        m = min(_CHUNK, n - s)
+        r = _raw(seed, name, m, s)
+        t = ((r & np.uint64(0xFFFF)) + ((r >> np.uint64(16)) & np.uint64(0xFFFF))
+             + ((r >> np.uint64(32)) & np.uint64(0xFFFF)) + (r >> np.uint64(48))).astype(np.int64)
+        out[s:s + m] = (t - 2 * 65535).astype(np.float32) * np.float32(_IH * np.float32(std))
+    return out.reshape(shape)
+
+
+def randint(seed: int, name: str, shape, high: int) -> np.ndarray:
+    """int64 array uniform in [0, high)."""
+    n = int(np.prod(shape))
+    r = _raw(seed, name, n)
+    return ((r >> np.uint64(33)) % np.uint64(high)).astype(np.int64).reshape(shape)
+
+
+def _t(a: np.ndarray, dtype) -> torch.Tensor:
+    return torch.from_numpy(a).to(dtype)
+
+
+def zonos_state_dict(cfg: dict, seed: int = 1234, dtype=torch.bfloat16) -> dict:
+    """Synthetic transformer-backbone weights under the reference's safetensors key contract
+    (module names at zonos/backbone/_torch.py:154-155,278-281,373-374,453-454,
+    zonos/model.py:81-82).  Scales follow PyTorch defaults: Linear U(+-1/sqrt(in)), Embedding
+    N(0,1), LayerNorm weight 1+-0.1 / bias +-0.1 (perturbed so that affine bugs show up).
+
+    cfg keys: d_model, n_layer, num_heads, num_heads_kv, d_ff, n_codebooks, vocab_embed, vocab_head
+    """
+    d, L, H, Hkv, F = cfg["d_model"], cfg["n_layer"], cfg["num_heads"], cfg["num_heads_kv"], cfg["d_ff"]
+    hd = d // H
+    nq = cfg.get("n_codebooks", 9)
+    ve, vh = cfg.get("vocab_embed", 1032), cfg.get("vocab_head", 1025)
+    sd = {}
+    for i in range(nq):
+        sd[f"embeddings.{i}.weight"] = _t(normal(seed, f"embeddings.{i}.weight", (ve, d)), dtype)
+    sd["fused_heads.weight"] = torch.cat(
+        [_t(uniform(seed, f"heads.{i}.weight", (vh, d), 1.0 / np.sqrt(d)), dtype) for i in range(nq)], 0)
+    for l in range(L):
+        p = f"backbone.layers.{l}."
+        for nm in ("norm", "norm2"):
+            sd[p + nm + ".weight"] = _t(1.0 + uniform(seed, p + nm + ".weight", (d,), 0.1), dtype)
+            sd[p + nm + ".bias"] = _t(uniform(seed, p + nm + ".bias", (d,), 0.1), dtype)
+        sd[p + "mixer.in_proj.weight"] = _t(uniform(seed, p + "mixer.in_proj.weight", ((H + 2 * Hkv) * hd, d), 1.0 / np.sqrt(d)), dtype)
+        sd[p + "mixer.out_proj.weight"] = _t(uniform(seed, p + "mixer.out_proj.weight", (d, H * hd), 1.0 / np.sqrt(H * hd)), dtype)
+        sd[p + "mlp.fc1.weight"] = _t(uniform(seed, p + "mlp.fc1.weight", (2 * F, d), 1.0 / np.sqrt(d)), dtype)
+        sd[p + "mlp.fc2.weight"] = _t(uniform(seed, p + "mlp.fc2.weight", (d, F), 1.0 / np.sqrt(F)), dtype)
+    sd["backbone.norm_f.weight"] = _t(1.0 + uniform(seed, "backbone.norm_f.weight", (d,), 0.1), dtype)
+    sd["backbone.norm_f.bias"] = _t(uniform(seed, "backbone.norm_f.bias", (d,), 0.1), dtype)
+    return sd
+
+
+TINY_CFG = dict(d_model=128, n_layer=2, num_heads=4, num_heads_kv=2, d_ff=256)
+FULL_CFG = dict(d_model=2048, n_layer=26, num_heads=16, num_heads_kv=4, d_ff=8192)
+
+
+def conditioning(seed: int, name: str, rows: int, l_c: int, d: int, dtype=torch.bfloat16) -> torch.Tensor:
+    """Synthetic prefix conditioning [rows, L_c, d]."""
+    return _t(normal(seed, name, (rows, l_c, d)), dtype)
+
+
+# ------------------------------------------------------------------ DAC decoder weights
+
+def dac_decoder_spec(hidden=1024, dec_hidden=1536, ratios=(8, 8, 4, 2), n_codebooks=9,
+                     codebook_size=1024, codebook_dim=8):
+    """(name, shape, kind) for every tensor autoencoder.decode() touches, in the state-dict naming of
+    transformers DacModel (modeling_dac.py:347-371 from_codes, :407-441 DacDecoder, :236-264 block,
+    :175-209 residual unit)."""
+    spec = []
+    for i in range(n_codebooks):
+        q = f"quantizer.quantizers.{i}."
+        spec += [(q + "codebook.weight", (codebook_size, codebook_dim), "emb"),
+                 (q + "out_proj.weight", (hidden, codebook_dim, 1), "conv"),
+                 (q + "out_proj.bias", (hidden,), "bias")]
+    spec += [("decoder.conv1.weight", (dec_hidden, hidden, 7), "conv"), ("decoder.conv1.bias", (dec_hidden,), "bias")]
+    c = dec_hidden
+    for bi, s in enumerate(ratios):
+        b = f"decoder.block.{bi}."
+        co = c // 2
+        spec += [(b + "snake1.alpha", (1, c, 1), "alpha"),
+                 (b + "conv_t1.weight", (c, co, 2 * s), "convt"), (b + "conv_t1.bias", (co,), "bias")]
+        for u in (1, 2, 3):
+            r = b + f"res_unit{u}."
+            spec += [(r + "snake1.alpha", (1, co, 1), "alpha"),
+                     (r + "conv1.weight", (co, co, 7), "conv"), (r + "conv1.bias", (co,), "bias"),
+                     (r + "snake2.alpha", (1, co, 1), "alpha"),
+                     (r + "conv2.weight", (co, co, 1), "conv"), (r + "conv2.bias", (co,), "bias")]
+        c = co
+    spec += [("decoder.snake1.alpha", (1, c, 1), "alpha"),
+             ("decoder.conv2.weight", (1, c, 7), "conv"), ("decoder.conv2.bias", (1,), "bias")]
+    return spec
+
+
+def dac_state_dict(seed: int = 4321, **kw) -> dict:
+    """Synthetic fp32 DAC decoder weights.  Conv weights use the PyTorch-default fan-in scale (so
+    activations stay O(1) through ~30 layers), Snake alpha in [0.5, 1.5], codebooks N(0,1)."""
+    sd = {}
+    for name, shape, kind in dac_decoder_spec(**kw):
+        if kind == "emb":
+            a = normal(seed, name, shape, 1.0)
+        elif kind == "conv":
+            a = uniform(seed, name, shape, 1.0 / np.sqrt(shape[1] * shape[2]))
+        elif kind == "convt":  # [Cin, Cout, k]; each output sees 2 taps * Cin inputs
+            a = uniform(seed, name, shape, 1.0 / np.sqrt(shape[0] * 2))
+        elif kind == "bias":
+            a = uniform(seed, name, shape, 0.05)
+        else:
+            a = 1.0 + uniform(seed, name, shape, 0.5)
+        sd[name] = torch.from_numpy(a)
+    return sd
