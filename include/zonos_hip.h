@@ -1,0 +1,174 @@
+/* zonos_hip.h — C ABI of libzonos_hip.so: the MI355X (gfx950) implementation of the Zonos TTS hot path.
+ *
+ * The reference (langfod/Zonos) is 100 % Python and has no FFI; its seam for this path is the Python surface
+ * zonos/model.py (Zonos.generate :354-548, _compute_logits :225-234, setup_cache :305-338), the backbone plugin
+ * contract zonos/backbone/__init__.py:24-36 + _torch.py:157,213, zonos/sampling.py:166-231 and
+ * zonos/autoencoder.py:119-170 (DACAutoencoder.decode / decode_to_int16).  Each entry point below names the
+ * reference interface it replaces.  INTEGRATION.md shows the ctypes binding a maintainer of the reference adds.
+ *
+ * Conventions: extern "C", plain pointers and sizes, no torch types.  Every call returns an int status
+ * (ZN_OK = 0, < 0 = error) and never throws or aborts; zn_last_error(h) gives the message.  All `*_dev`
+ * pointers are device (HBM) pointers owned by the caller (torch tensors' data_ptr()); the library owns only the
+ * handle-scoped workspace.  `stream` is a hipStream_t (torch.cuda.current_stream().cuda_stream), 0 = default.
+ * One handle = one device; calls on one handle must not overlap in time; distinct handles are independent.
+ * bf16 = raw uint16 bit pattern, row-major tensors, nn.Linear weights are [out_features][in_features].
+ */
+#ifndef ZONOS_HIP_H
+#define ZONOS_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ZN_ABI_VERSION 1
+
+enum zn_status {
+  ZN_OK = 0,
+  ZN_ERR_ARG = -1,          /* bad argument / shape the kernels do not support */
+  ZN_ERR_HIP = -2,          /* a HIP runtime call failed */
+  ZN_ERR_STATE = -3,        /* call order violated (e.g. decode before zn_gen_begin) */
+  ZN_ERR_UNSUPPORTED = -4,  /* valid in the reference, not built yet */
+  ZN_ERR_NOMEM = -5
+};
+
+typedef struct zn_handle_s* zn_handle;
+typedef struct zn_dac_s* zn_dac;
+typedef void* zn_stream;
+
+/* Model hyper-parameters: zonos/config.py:55-84 BackboneConfig + :105-126 ZonosConfig (read from config.json
+ * by the host; never hard-coded). */
+typedef struct zn_config {
+  int32_t d_model, n_layer, n_heads, n_heads_kv, d_ff; /* attn_mlp_d_intermediate */
+  int32_t n_codebooks;     /* 9 */
+  int32_t vocab_head;      /* 1025 logits per codebook (zonos/model.py:82) */
+  int32_t vocab_embed;     /* 1032 embedding rows (zonos/model.py:80) */
+  int32_t eos_id, mask_id; /* 1024, 1025 */
+  int32_t rope_positions;  /* rows of the RoPE table, 16384 (_torch.py:206) */
+  int32_t double_out_proj; /* 1 = reproduce _torch.py:419-420 (out_proj applied twice), 0 = upstream behaviour */
+  float norm_eps;          /* 1e-5 */
+} zn_config;
+
+typedef struct zn_layer_weights { /* bf16; names = _torch.py:278-281,373-374,453-454 */
+  const void *norm_w, *norm_b;     /* [d] */
+  const void *in_proj;             /* [(H+2Hkv)*hd, d] */
+  const void *out_proj;            /* [d, H*hd] */
+  const void *norm2_w, *norm2_b;   /* [d] */
+  const void *fc1;                 /* [2*d_ff, d]  rows [0,d_ff) = value, [d_ff,2d_ff) = gate */
+  const void *fc2;                 /* [d, d_ff] */
+} zn_layer_weights;
+
+typedef struct zn_weights {
+  const void* const* embeddings;   /* host array of n_codebooks device pointers, each bf16 [vocab_embed, d] */
+  const void* heads;               /* bf16 [n_codebooks*vocab_head, d]  (fused_heads, zonos/model.py:82,208-223) */
+  const void *norm_f_w, *norm_f_b; /* bf16 [d] */
+  const zn_layer_weights* layers;  /* host array [n_layer] */
+  const float* rope_table;         /* fp32 [rope_positions, hd/2, 2] (cos,sin), built by the host exactly as
+                                      _torch.py:29-34 does (torch.polar on CPU) */
+} zn_weights;
+
+/* sampling_params of Zonos.generate (zonos/sampling.py:166-178 defaults). */
+typedef struct zn_sampling {
+  float temperature;   /* <= 0: greedy argmax */
+  float top_p; int32_t top_k; float min_p;
+  float linear, conf, quad;
+  float repetition_penalty; int32_t repetition_penalty_window;
+  uint64_t seed;       /* device RNG stream for the Gumbel-max draw */
+} zn_sampling;
+
+/* ---------------------------------------------------------------- lifecycle */
+int zn_abi_version(void);
+/* Replaces Zonos.__init__/from_local weight binding (zonos/model.py:68-86,128-176).  Weights stay owned by the
+ * caller and must outlive the handle.  max_rows = 2 * max batch (CFG doubles rows, generation_utils.py:192). */
+int zn_create(const zn_config* cfg, const zn_weights* w, int32_t max_rows, zn_handle* out);
+int zn_destroy(zn_handle h);
+const char* zn_last_error(zn_handle h); /* h may be NULL: last creation error */
+/* Bytes of one layer's KV cache [rows, max_len, 2, Hkv, hd] bf16 (_torch.py:305). */
+size_t zn_kv_bytes_per_layer(const zn_config* cfg, int32_t rows, int32_t max_len);
+
+/* ---------------------------------------------------------------- generation (Zonos.generate, model.py:354-548) */
+/* Binds the per-call state that zonos/model.py:410-463 builds: KV caches (one device pointer per layer, layout
+ * [2B, max_len, 2, Hkv, hd] bf16 = TorchZonosBackbone.allocate_inference_cache), lengths_per_sample int32[2B]
+ * (device, zeroed by the caller), the delay-patterned code buffer int32 [B, n_codebooks, t_total] with -1 for
+ * unknown (model.py:414-420), the first column to write `offset0` = prefix_len + 1, cfg_scale and sampling. */
+int zn_gen_begin(zn_handle h, int32_t batch, const void* const* kv_layers_dev, int32_t max_len,
+                 int32_t* lengths_dev, int32_t* delayed_codes_dev, int32_t t_total, int32_t offset0,
+                 int32_t max_new_tokens, float cfg_scale, const zn_sampling* sp, zn_stream stream);
+/* prefill_static (generation_utils.py:206-244) + _compute_logits: hidden bf16 [2B, S, d] = [cond ‖ uncond]
+ * conditioning concatenated with embed(delayed[..., :prefix+1]); fills KV positions [0,S), lengths += S and
+ * leaves the CFG-mixed fp32 logits [B, n_codebooks, vocab_head] in the handle. */
+int zn_prefill(zn_handle h, const void* hidden_dev, int32_t S, zn_stream stream);
+/* model.py:423-431: sample the first frame from the prefill logits (no repetition penalty, no logit bias) and
+ * write it into column offset0 where that column is -1. */
+int zn_sample_first(zn_handle h, zn_stream stream);
+/* n iterations of the hot loop (model.py:467-502): embed column offset-1, 26 blocks, heads, CFG, logit bias,
+ * repetition penalty, sample, EOS bookkeeping (tensor_ops.py:155-211), frame write (tensor_ops.py:12-53),
+ * offsets += 1.  Asynchronous; replays one hipGraph per step. */
+int zn_decode_steps(zn_handle h, int32_t n, zn_stream stream);
+/* 1 if the decode step is currently replayed as an instantiated hipGraph, 0 if launched kernel by kernel. */
+int zn_graph_active(zn_handle h);
+/* (remaining_steps <= 0).all() of tensor_ops.py:95,102 — synchronises the stream. */
+int zn_all_stopped(zn_handle h, int32_t* out, zn_stream stream);
+/* Copies the fp32 logits the sampler last consumed ([B, n_codebooks, vocab_head], after CFG and logit bias) and
+ * the raw sampled tokens int32 [B, n_codebooks] to device buffers (either may be NULL).  For parity tests. */
+int zn_get_step_outputs(zn_handle h, float* logits_dev, int32_t* tokens_dev, zn_stream stream);
+/* Test hook: at loop step `step` (0-based) force codebook-0 EOS by setting its logit to 1e4 (-1 = off). */
+int zn_debug_force_eos(zn_handle h, int32_t step);
+/* Test hook: replace the sampled raw tokens of call k (0 = first frame, k = loop step k-1) by
+ * tokens_dev[k] (int32 [calls, B, n_codebooks], device) so that the EOS bookkeeping, frame writes and stop
+ * cadence can be checked bit-exactly against the reference's recorded token stream.  NULL = off. */
+int zn_debug_token_override(zn_handle h, const int32_t* tokens_dev, int32_t calls);
+/* Test/benchmark hook: add `bias` to the codebook-0 EOS logit on every step (-inf suppresses EOS so that all
+ * max_new_tokens+7 steps run). */
+int zn_debug_eos_bias(zn_handle h, float bias);
+
+/* ---------------------------------------------------------------- measurement */
+/* Average duration (HIP events on `stream`) of one of the decode step's weight-streaming kernels over `iters`
+ * launches that cycle through the layers' weights, and its algorithmic bytes per launch (the weight matrix).
+ * which: 0 = LayerNorm+fc1+SiLU-gate, 1 = fc2+residual, 2 = out_proj+residual, 3 = LayerNorm+heads. */
+int zn_bench_kernel(zn_handle h, int32_t which, int32_t rows, int32_t iters, float* ms_per_launch,
+                    double* bytes_per_launch, zn_stream stream);
+
+/* ---------------------------------------------------------------- single ops (parity tests call these) */
+/* nn.LayerNorm + nn.Linear(no bias): out[r,n] = bf16(sum_k LN(x)[r,k] W[n,k]); ln_w == NULL skips the norm. */
+int zn_op_linear(zn_handle h, const void* x_dev, const void* ln_w, const void* ln_b, const void* W_dev,
+                 void* out_dev, int32_t rows, int32_t N, int32_t K, zn_stream stream);
+/* nn.LayerNorm (_torch.py:155 norm_f): bf16 [rows, d] -> bf16 [rows, d], fp32 statistics. */
+int zn_op_layernorm(zn_handle h, const void* x_dev, const void* w_dev, const void* b_dev, void* out_dev, int32_t rows,
+                    int32_t d, zn_stream stream);
+/* One decode step of TransformerBlock `layer` (_torch.py:307-328) on x bf16 [rows, d] in place, reading and
+ * appending to kv_dev at position lengths_dev[r]; ext_dev (optional, int32[rows]) = number of keys the
+ * reference's CPU flash-attention block sees for that row (prefill emulation), NULL = lengths+1. */
+int zn_op_layer_decode(zn_handle h, int32_t layer, void* x_dev, void* kv_dev, int32_t max_len,
+                       const int32_t* lengths_dev, const int32_t* ext_dev, int32_t rows, zn_stream stream);
+/* Decode attention alone (_torch.py:413-417): q bf16 [rows, Hq*hd] (post-RoPE), kv [rows, max_len, 2, Hkv, hd] holding
+ * lengths[r]+1 keys -> out bf16 [rows, Hq*hd]; reproduces the CPU flash-attention rounding points. */
+int zn_op_attn_decode(zn_handle h, const void* q_dev, const void* kv_dev, int32_t max_len, const int32_t* lengths_dev,
+                      const int32_t* ext_dev, void* out_dev, int32_t rows, zn_stream stream);
+/* embed_codes_static (codec_utils.py:37): codes int32 [B, n_codebooks] -> bf16 [B, d], sequential bf16 adds. */
+int zn_op_embed(zn_handle h, const int32_t* codes_dev, void* out_dev, int32_t batch, zn_stream stream);
+/* sample_from_logits (sampling.py:166-231) on fp32 logits [B, n_codebooks, vocab_head]; recent int32
+ * [B, n_codebooks, window] or NULL; tokens int32 [B, n_codebooks]; probs_out (optional) receives the filtered
+ * probabilities the Gumbel-max draw uses. */
+int zn_op_sample(zn_handle h, const float* logits_dev, const int32_t* recent_dev, int32_t window,
+                 const zn_sampling* sp, uint64_t draw_index, int32_t* tokens_dev, float* probs_out_dev,
+                 int32_t batch, zn_stream stream);
+
+/* ---------------------------------------------------------------- DAC decode (autoencoder.py:119-170) */
+typedef struct zn_dac_config { /* transformers DacConfig fields used by decode */
+  int32_t n_codebooks, codebook_size, codebook_dim, hidden_size, decoder_hidden_size;
+  int32_t n_ratios; int32_t ratios[8]; /* upsampling_ratios, e.g. 8,8,4,2 */
+} zn_dac_config;
+typedef struct zn_dac_tensor { const char* name; const float* data_dev; int64_t numel; } zn_dac_tensor;
+/* Weights by their transformers state-dict names (fp32, device).  The library re-lays them out once. */
+int zn_dac_create(const zn_dac_config* cfg, const zn_dac_tensor* tensors, int32_t n_tensors, zn_dac* out);
+int zn_dac_destroy(zn_dac d);
+const char* zn_dac_last_error(zn_dac d);
+/* DACAutoencoder.decode: codes int32 [B, n_codebooks, T] -> wav fp32 [B, 1, hop*T]. */
+int zn_dac_decode(zn_dac d, const int32_t* codes_dev, int32_t batch, int32_t T, float* wav_dev, zn_stream stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -53,7 +53,7 @@ def import_reference():
     return zm
 
 
-def build_reference_model(zm, cfg, seed):
+def build_reference_model(zm, cfg, seed, peaky=False):
     from zonos.backbone._torch import TorchZonosBackbone
     from zonos.config import BackboneConfig, PrefixConditionerConfig, ZonosConfig
     from zonos.utilities.generation_utils import CUDAGraphManager
@@ -73,7 +73,7 @@ def build_reference_model(zm, cfg, seed):
         heads = nn.Linear(cfg["d_model"], 9 * 1025, bias=False)
     m.backbone, m.embeddings, m.fused_heads = bb, emb, heads
     m._cuda_graph_manager = CUDAGraphManager()
-    sd = synth.zonos_state_dict(cfg, seed)
+    sd = synth.zonos_state_dict(cfg, seed, peaky=peaky)
     m.load_state_dict(sd, assign=True, strict=True)
     return m.eval(), sd
 
@@ -130,7 +130,7 @@ def bf16_bits(t):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="tiny,full,ops,sampling,eos,dac")
+    ap.add_argument("--only", default="tiny,full,ops,sampling,eos,dac,peaky")
     args = ap.parse_args()
     only = set(args.only.split(","))
     torch.manual_seed(0)
@@ -153,11 +153,13 @@ def main():
             c = gen_case(zm, model, cond, 48, keep=(), force=s)
             cases[f"out_{s}"] = c["out"]
             cases[f"calls_{s}"] = c["n_calls"]
+            cases[f"tokens_{s}"] = c["tokens"]
         pre = torch.from_numpy(synth.randint(seed, "prefix", (1, 9, 5), 1024))
         for s in (2, 9):
             c = gen_case(zm, model, cond, 32, prefix=pre, keep=(), force=s)
             cases[f"pout_{s}"] = c["out"]
             cases[f"pcalls_{s}"] = c["n_calls"]
+            cases[f"ptokens_{s}"] = c["tokens"]
         np.savez_compressed(f"{HERE}/tiny_eos.npz", seed=seed, l_c=6, max_new=48, p_max_new=32, prefix_len=5, **cases)
         print("eos done")
 
@@ -186,6 +188,20 @@ def main():
             out[f"knew_{L}"] = bf16_bits(kv[:, L - 1, 0])
         np.savez_compressed(f"{HERE}/full_layer0.npz", seed=seed, **out)
         print("ops done")
+
+    if "peaky" in only:
+        # decisive-margin ("peaky" head) variants for free-running greedy parity
+        cfg, seed = synth.TINY_CFG, 77
+        model, _ = build_reference_model(zm, cfg, seed, peaky=True)
+        cond = synth.conditioning(seed, "cond", 2, 6, cfg["d_model"])
+        c = gen_case(zm, model, cond, 96, keep=(0, 1, 50))
+        np.savez_compressed(f"{HERE}/tiny_gen_peaky.npz", seed=seed, l_c=6, max_new=96, **c)
+        cfg, seed = synth.FULL_CFG, 1234
+        model, _ = build_reference_model(zm, cfg, seed, peaky=True)
+        cond = synth.conditioning(seed, "cond", 2, 24, cfg["d_model"])
+        c = gen_case(zm, model, cond, 160, keep=(0, 1, 100))
+        np.savez_compressed(f"{HERE}/full_gen_peaky.npz", seed=seed, l_c=24, max_new=160, **c)
+        print("peaky done")
 
     if "sampling" in only:
         import zonos.sampling as zs

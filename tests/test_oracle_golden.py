@@ -135,6 +135,22 @@ def test_full_dims_layer0_decode(golden_dir, full_weights):
         assert np.array_equal(kv[:, L - 1, 0].contiguous().view(torch.int16).numpy(), g[f"knew_{L}"]), L
 
 
+def test_peaky_head_generate_matches_reference(golden_dir, full_weights):
+    """Decisive-margin synthetic heads (synth.peaky_heads): the free-running parity cases of the GPU suite."""
+    g = _load(golden_dir, "tiny_gen_peaky")
+    w = synth.zonos_state_dict(synth.TINY_CFG, int(g["seed"]), peaky=True)
+    cond = synth.conditioning(int(g["seed"]), "cond", 2, int(g["l_c"]), synth.TINY_CFG["d_model"])
+    out = zo.generate(w, synth.TINY_CFG, cond, max_new_tokens=int(g["max_new"]), sampling_params={"temperature": 0.0})
+    assert np.array_equal(out.numpy(), g["out"].astype(np.int64))
+    g = _load(golden_dir, "full_gen_peaky")
+    w = dict(full_weights)
+    w["fused_heads.weight"] = torch.cat([torch.from_numpy(synth.peaky_heads(int(g["seed"]), f"heads.{i}.weight", 1025, 2048)).to(torch.bfloat16)
+                                         for i in range(9)], 0)
+    cond = synth.conditioning(int(g["seed"]), "cond", 2, int(g["l_c"]), 2048)
+    out = zo.generate(w, synth.FULL_CFG, cond, max_new_tokens=int(g["max_new"]), sampling_params={"temperature": 0.0})
+    assert np.array_equal(out.numpy(), g["out"].astype(np.int64))
+
+
 def test_dac_decode_matches_transformers(golden_dir):
     g = _load(golden_dir, "dac")
     seed = int(g["seed"])

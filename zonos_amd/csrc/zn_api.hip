@@ -1,0 +1,589 @@
+// libzonos_hip.so — C ABI (include/zonos_hip.h) over the gfx950 kernels.  Host logic only: argument checks,
+// workspace, launch geometry, hipGraph capture of one decode step.
+#include "../../include/zonos_hip.h"
+#include "zn_decode_kernels.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+static thread_local std::string g_create_err;
+
+struct zn_handle_s {
+  zn_config cfg;
+  int max_rows = 0, hd = 0, G = 0;
+  std::vector<zn_layer_weights> layers;
+  const void* heads = nullptr;
+  const void *norm_f_w = nullptr, *norm_f_b = nullptr;
+  const float* rope = nullptr;
+  const bf16_t** emb_tables_dev = nullptr;
+  bool has_io = false;  // embeddings + heads bound (false: backbone-only handle)
+  // workspace (device)
+  bf16_t *x = nullptr, *q = nullptr, *o1 = nullptr, *mbuf = nullptr;
+  float *logits_raw = nullptr, *last_logits = nullptr;
+  int* tok_raw = nullptr;
+  float *scores = nullptr, *cmax = nullptr, *pacc = nullptr, *pl = nullptr, *pm = nullptr;
+  int lcap = 0, nb_cap = 0;
+  GenState* st = nullptr;
+  int *remaining = nullptr, *stopping = nullptr;
+  int* done_host = nullptr;  // pinned
+  // per-generation state (host mirror)
+  bool gen_active = false;
+  int batch = 0, rows = 0, max_len = 0, t_total = 0, offset0 = 0, max_new = 0;
+  float cfg_scale = 2.f;
+  zn_sampling sp{};
+  std::vector<const void*> kv_layers;
+  int *lengths = nullptr, *codes = nullptr;
+  int force_eos_step = -1;
+  float eos_bias = 0.f;
+  const int* tok_override = nullptr;
+  int tok_override_calls = 0;
+  hipStream_t cap_stream = nullptr;
+  hipGraphExec_t graph_exec = nullptr;
+  hipGraph_t graph = nullptr;
+  bool graph_tried = false;
+  std::string err;
+};
+
+#define ZN_FAIL(h, code, ...)                                   \
+  do {                                                          \
+    char _b[512]; snprintf(_b, sizeof _b, __VA_ARGS__);         \
+    if (h) (h)->err = _b; else g_create_err = _b;               \
+    return (code);                                              \
+  } while (0)
+#define HIPCHK(h, call)                                                                       \
+  do {                                                                                        \
+    hipError_t _e = (call);                                                                   \
+    if (_e != hipSuccess) ZN_FAIL(h, ZN_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(_e)); \
+  } while (0)
+
+extern "C" int zn_abi_version(void) { return ZN_ABI_VERSION; }
+
+extern "C" const char* zn_last_error(zn_handle h) { return h ? h->err.c_str() : g_create_err.c_str(); }
+
+extern "C" size_t zn_kv_bytes_per_layer(const zn_config* c, int32_t rows, int32_t max_len) {
+  if (!c || c->n_heads <= 0) return 0;
+  const size_t hd = (size_t)c->d_model / c->n_heads;
+  return (size_t)rows * max_len * 2 * c->n_heads_kv * hd * 2;
+}
+
+static void free_graph(zn_handle h) {
+  if (h->graph_exec) { (void)hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; }
+  if (h->graph) { (void)hipGraphDestroy(h->graph); h->graph = nullptr; }
+  h->graph_tried = false;
+}
+
+extern "C" int zn_destroy(zn_handle h) {
+  if (!h) return ZN_OK;
+  free_graph(h);
+  void* ptrs[] = {h->emb_tables_dev, h->x, h->q, h->o1, h->mbuf, h->logits_raw, h->last_logits, h->tok_raw, h->scores,
+                  h->cmax, h->pacc, h->pl, h->pm, h->st, h->remaining, h->stopping};
+  for (void* p : ptrs) if (p) (void)hipFree(p);
+  if (h->done_host) (void)hipHostFree(h->done_host);
+  if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
+  delete h;
+  return ZN_OK;
+}
+
+static int ensure_attn_ws(zn_handle h, int max_len) {
+  const int lcap = ((max_len + 511) / 512) * 512;
+  if (lcap <= h->lcap) return ZN_OK;
+  free_graph(h);
+  for (float** p : {&h->scores, &h->cmax, &h->pacc, &h->pl, &h->pm}) if (*p) { (void)hipFree(*p); *p = nullptr; }
+  const size_t RH = (size_t)h->max_rows * h->cfg.n_heads;
+  const int nb = lcap / 512;
+  HIPCHK(h, hipMalloc(&h->scores, RH * lcap * sizeof(float)));
+  HIPCHK(h, hipMalloc(&h->cmax, RH * (lcap / 128) * sizeof(float)));
+  HIPCHK(h, hipMalloc(&h->pacc, RH * nb * h->hd * sizeof(float)));
+  HIPCHK(h, hipMalloc(&h->pl, RH * nb * sizeof(float)));
+  HIPCHK(h, hipMalloc(&h->pm, RH * nb * sizeof(float)));
+  h->lcap = lcap; h->nb_cap = nb;
+  return ZN_OK;
+}
+
+extern "C" int zn_create(const zn_config* cfg, const zn_weights* w, int32_t max_rows, zn_handle* out) {
+  if (!cfg || !w || !out) ZN_FAIL((zn_handle) nullptr, ZN_ERR_ARG, "zn_create: null argument");
+  *out = nullptr;
+  const zn_config& c = *cfg;
+  if (c.d_model <= 0 || c.n_layer <= 0 || c.n_heads <= 0 || c.n_heads_kv <= 0 || c.d_ff <= 0 || c.n_codebooks <= 0)
+    ZN_FAIL((zn_handle) nullptr, ZN_ERR_ARG, "zn_create: non-positive dimension");
+  if (c.d_model % c.n_heads || c.n_heads % c.n_heads_kv) ZN_FAIL((zn_handle) nullptr, ZN_ERR_ARG, "zn_create: heads do not divide");
+  const int hd = c.d_model / c.n_heads, G = c.n_heads / c.n_heads_kv;
+  if (hd != 32 && hd != 64 && hd != 128) ZN_FAIL((zn_handle) nullptr, ZN_ERR_UNSUPPORTED, "head_dim %d not in {32,64,128}", hd);
+  if (G != 1 && G != 2 && G != 4 && G != 8) ZN_FAIL((zn_handle) nullptr, ZN_ERR_UNSUPPORTED, "GQA group %d not in {1,2,4,8}", G);
+  if (c.d_model % 8 || c.d_ff % 8 || c.d_model > 4096) ZN_FAIL((zn_handle) nullptr, ZN_ERR_UNSUPPORTED, "d_model/d_ff must be multiples of 8, d_model <= 4096");
+  if (c.vocab_head > ZN_SAMPLE_MAXV) ZN_FAIL((zn_handle) nullptr, ZN_ERR_UNSUPPORTED, "vocab_head > %d", ZN_SAMPLE_MAXV);
+  if (max_rows < 2 || max_rows % 2) ZN_FAIL((zn_handle) nullptr, ZN_ERR_ARG, "max_rows must be even and >= 2");
+  zn_handle h = new zn_handle_s();
+  h->cfg = c; h->max_rows = max_rows; h->hd = hd; h->G = G;
+  h->layers.assign(w->layers, w->layers + c.n_layer);
+  h->heads = w->heads; h->norm_f_w = w->norm_f_w; h->norm_f_b = w->norm_f_b; h->rope = w->rope_table;
+#define ZC(call) do { hipError_t _e = (call); if (_e != hipSuccess) { g_create_err = std::string(#call) + ": " + hipGetErrorString(_e); zn_destroy(h); return ZN_ERR_HIP; } } while (0)
+  ZC(hipMalloc(&h->emb_tables_dev, sizeof(void*) * c.n_codebooks));
+  if (w->embeddings) ZC(hipMemcpy(h->emb_tables_dev, w->embeddings, sizeof(void*) * c.n_codebooks, hipMemcpyHostToDevice));
+  h->has_io = (w->embeddings != nullptr && w->heads != nullptr);
+  const size_t R = max_rows;
+  ZC(hipMalloc(&h->x, R * c.d_model * 2));
+  ZC(hipMalloc(&h->q, R * c.d_model * 2));
+  ZC(hipMalloc(&h->o1, R * c.d_model * 2));
+  ZC(hipMalloc(&h->mbuf, R * c.d_ff * 2));
+  ZC(hipMalloc(&h->logits_raw, R * c.n_codebooks * c.vocab_head * sizeof(float)));
+  ZC(hipMalloc(&h->last_logits, (R / 2) * c.n_codebooks * c.vocab_head * sizeof(float)));
+  ZC(hipMalloc(&h->tok_raw, (R / 2) * c.n_codebooks * sizeof(int)));
+  ZC(hipMalloc(&h->st, sizeof(GenState)));
+  ZC(hipMemset(h->st, 0, sizeof(GenState)));
+  ZC(hipMalloc(&h->remaining, (R / 2) * sizeof(int)));
+  ZC(hipMalloc(&h->stopping, (R / 2) * sizeof(int)));
+  ZC(hipHostMalloc(&h->done_host, sizeof(int) * 4));
+#undef ZC
+  *out = h;
+  return ZN_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ launches
+template <int R, int NCH, int KS, int PRO, int EPI>
+static void launch_gemv_t(const GemvArgs& a, int blocks, hipStream_t s) {
+  hipLaunchKernelGGL((gemv_kernel<R, NCH, KS, PRO, EPI>), dim3(blocks), dim3(256), 0, s, a);
+}
+template <int R, int KS, int PRO, int EPI>
+static int launch_gemv_nch(const GemvArgs& a, int nch, int blocks, hipStream_t s) {
+  switch (nch) {
+    case 1: launch_gemv_t<R, 1, KS, PRO, EPI>(a, blocks, s); return 0;
+    case 2: launch_gemv_t<R, 2, KS, PRO, EPI>(a, blocks, s); return 0;
+    case 4: launch_gemv_t<R, 4, KS, PRO, EPI>(a, blocks, s); return 0;
+    case 8: launch_gemv_t<R, 8, KS, PRO, EPI>(a, blocks, s); return 0;
+  }
+  return -1;
+}
+template <int PRO, int EPI>
+static int launch_gemv_rows(const GemvArgs& a, int rgroup, int ks, int nch, int blocks, hipStream_t s) {
+  if (ks == 1) {
+    if (rgroup <= 2) return launch_gemv_nch<2, 1, PRO, EPI>(a, nch, blocks, s);
+    return launch_gemv_nch<4, 1, PRO, EPI>(a, nch, blocks, s);
+  }
+  if constexpr (PRO == PRO_NONE) {
+    if (rgroup <= 2) return launch_gemv_nch<2, 4, PRO, EPI>(a, nch, blocks, s);
+    return launch_gemv_nch<4, 4, PRO, EPI>(a, nch, blocks, s);
+  }
+  return -1;
+}
+
+// Runs one fused GEMV over `rows` activation rows (groups of <= 4 rows per launch; weights are re-streamed per
+// group, so batches beyond 2 utterances pay extra HBM traffic until the MFMA small-M path lands).
+template <int PRO, int EPI>
+static int run_gemv(zn_handle h, GemvArgs a, int rows, int target_blocks, hipStream_t s) {
+  const int K = a.K;
+  int ks = 1;
+  if (PRO == PRO_NONE && K >= 4096 && K % 2048 == 0) ks = 4;
+  const int kw = K / ks;
+  int nch = (kw + 511) / 512;
+  nch = nch <= 1 ? 1 : nch <= 2 ? 2 : nch <= 4 ? 4 : nch <= 8 ? 8 : 99;
+  if (nch > 8) ZN_FAIL(h, ZN_ERR_UNSUPPORTED, "gemv: K=%d too large for the register-resident activation path", K);
+  a.units = (EPI == EPI_SILU) ? a.N / 2 : (a.N + 1) / 2;
+  const int lanes_units = (ks == 1) ? 4 : 1;  // units in flight per block
+  int upw = (a.units + target_blocks * lanes_units - 1) / (target_blocks * lanes_units);
+  if (upw < 1) upw = 1;
+  a.upw = upw;
+  const int blocks = (a.units + upw * lanes_units - 1) / (upw * lanes_units);
+  for (int r0 = 0; r0 < rows; r0 += 4) {
+    GemvArgs g = a;
+    const int nr = rows - r0 < 4 ? rows - r0 : 4;
+    g.nrows = nr;
+    if (g.x) g.x += (size_t)r0 * K;
+    if (g.out) g.out += (size_t)r0 * (EPI == EPI_SILU ? a.N / 2 : a.N);
+    if (g.resid) g.resid += (size_t)r0 * a.N;
+    if (g.out_f32) g.out_f32 += (size_t)r0 * a.N;
+    if (g.lengths) g.lengths += r0;
+    if (g.q_out) g.q_out += (size_t)r0 * a.n_heads * a.hd;
+    if (g.kv) g.kv += (size_t)r0 * a.max_len * 2 * a.n_heads_kv * a.hd;
+    if (g.pacc) { g.pacc += (size_t)r0 * a.n_heads * a.nb_cap * a.hd; g.pl += (size_t)r0 * a.n_heads * a.nb_cap; g.pm += (size_t)r0 * a.n_heads * a.nb_cap; }
+    if (launch_gemv_rows<PRO, EPI>(g, nr, ks, nch, blocks, s) != 0) ZN_FAIL(h, ZN_ERR_UNSUPPORTED, "gemv: no kernel for ks=%d nch=%d", ks, nch);
+  }
+  return ZN_OK;
+}
+
+template <int HD>
+static int launch_attn_g(const AttnArgs& a, int G, dim3 gs, dim3 gp, hipStream_t s) {
+  switch (G) {
+    case 1: hipLaunchKernelGGL((attn_scores_kernel<HD, 1>), gs, dim3(256), 0, s, a); hipLaunchKernelGGL((attn_pv_kernel<HD, 1>), gp, dim3(1024), 0, s, a); return 0;
+    case 2: hipLaunchKernelGGL((attn_scores_kernel<HD, 2>), gs, dim3(256), 0, s, a); hipLaunchKernelGGL((attn_pv_kernel<HD, 2>), gp, dim3(1024), 0, s, a); return 0;
+    case 4: hipLaunchKernelGGL((attn_scores_kernel<HD, 4>), gs, dim3(256), 0, s, a); hipLaunchKernelGGL((attn_pv_kernel<HD, 4>), gp, dim3(1024), 0, s, a); return 0;
+    case 8: hipLaunchKernelGGL((attn_scores_kernel<HD, 8>), gs, dim3(256), 0, s, a); hipLaunchKernelGGL((attn_pv_kernel<HD, 8>), gp, dim3(1024), 0, s, a); return 0;
+  }
+  return -1;
+}
+
+// One decode step of block `li` on x [rows][d] in place (_torch.py:307-328).
+static int layer_decode(zn_handle h, int li, bf16_t* x, bf16_t* kv, int max_len, const int* lengths, const int* ext,
+                        int ext_scalar, int rows, hipStream_t s) {
+  const zn_config& c = h->cfg;
+  const zn_layer_weights& lw = h->layers[li];
+  const int d = c.d_model, hd = h->hd, nq = c.n_heads * hd, nkv = c.n_heads_kv * hd;
+  int rc;
+  {  // LayerNorm -> in_proj -> split -> RoPE(q,k) -> KV append
+    GemvArgs a{};
+    a.W = (const bf16_t*)lw.in_proj; a.N = nq + 2 * nkv; a.K = d; a.x = x;
+    a.ln_w = (const bf16_t*)lw.norm_w; a.ln_b = (const bf16_t*)lw.norm_b; a.eps = c.norm_eps;
+    a.lengths = lengths; a.hd = hd; a.n_heads = c.n_heads; a.n_heads_kv = c.n_heads_kv;
+    a.q_out = h->q; a.kv = kv; a.rope = h->rope; a.max_len = max_len; a.rope_positions = c.rope_positions;
+    if ((rc = run_gemv<PRO_LN, EPI_ROPE_KV>(h, a, rows, 512, s))) return rc;
+  }
+  {  // scores + per-512-block P.V partials
+    AttnArgs a{};
+    a.q = h->q; a.kv = kv; a.lengths = lengths; a.ext = ext; a.ext_scalar = ext_scalar; a.max_len = max_len;
+    a.n_heads = c.n_heads; a.n_heads_kv = c.n_heads_kv; a.lcap = h->lcap; a.nb_cap = h->nb_cap;
+    a.scale = (float)(1.0 / std::sqrt((double)hd));
+    a.scores = h->scores; a.cmax = h->cmax; a.pacc = h->pacc; a.pl = h->pl; a.pm = h->pm;
+    const int lim = max_len < h->lcap ? max_len : h->lcap;
+    dim3 gs((lim + 127) / 128, c.n_heads_kv, rows), gp((lim + 511) / 512, c.n_heads_kv, rows);
+    int r2 = hd == 128 ? launch_attn_g<128>(a, h->G, gs, gp, s) : hd == 64 ? launch_attn_g<64>(a, h->G, gs, gp, s) : launch_attn_g<32>(a, h->G, gs, gp, s);
+    if (r2) ZN_FAIL(h, ZN_ERR_UNSUPPORTED, "attention: unsupported group %d", h->G);
+  }
+  {  // combine partials -> out_proj (-> out_proj again, _torch.py:419-420) -> residual
+    GemvArgs a{};
+    a.W = (const bf16_t*)lw.out_proj; a.N = d; a.K = nq; a.lengths = lengths;
+    a.pacc = h->pacc; a.pl = h->pl; a.pm = h->pm; a.nb_cap = h->nb_cap; a.hd = hd; a.n_heads = c.n_heads;
+    if (c.double_out_proj) {
+      a.out = h->o1;
+      if ((rc = run_gemv<PRO_ATTN, EPI_STORE>(h, a, rows, 512, s))) return rc;
+      GemvArgs b{};
+      b.W = (const bf16_t*)lw.out_proj; b.N = d; b.K = nq; b.x = h->o1; b.resid = x; b.out = x;
+      if ((rc = run_gemv<PRO_NONE, EPI_RESID>(h, b, rows, 512, s))) return rc;
+    } else {
+      a.resid = x; a.out = x;
+      if ((rc = run_gemv<PRO_ATTN, EPI_RESID>(h, a, rows, 512, s))) return rc;
+    }
+  }
+  {  // LayerNorm -> fc1 -> y * silu(gate)
+    GemvArgs a{};
+    a.W = (const bf16_t*)lw.fc1; a.N = 2 * c.d_ff; a.K = d; a.x = x;
+    a.ln_w = (const bf16_t*)lw.norm2_w; a.ln_b = (const bf16_t*)lw.norm2_b; a.eps = c.norm_eps; a.out = h->mbuf;
+    if ((rc = run_gemv<PRO_LN, EPI_SILU>(h, a, rows, 1024, s))) return rc;
+  }
+  {  // fc2 -> residual
+    GemvArgs a{};
+    a.W = (const bf16_t*)lw.fc2; a.N = d; a.K = c.d_ff; a.x = h->mbuf; a.resid = x; a.out = x;
+    if ((rc = run_gemv<PRO_NONE, EPI_RESID>(h, a, rows, 1024, s))) return rc;
+  }
+  return ZN_OK;
+}
+
+static int heads_logits(zn_handle h, const bf16_t* x, int rows, hipStream_t s) {
+  const zn_config& c = h->cfg;
+  GemvArgs a{};
+  a.W = (const bf16_t*)h->heads; a.N = c.n_codebooks * c.vocab_head; a.K = c.d_model; a.x = x;
+  a.ln_w = (const bf16_t*)h->norm_f_w; a.ln_b = (const bf16_t*)h->norm_f_b; a.eps = c.norm_eps; a.out_f32 = h->logits_raw;
+  return run_gemv<PRO_LN, EPI_F32>(h, a, rows, 1024, s);
+}
+
+static SampleArgs make_sample_args(zn_handle h, const zn_sampling& sp) {
+  SampleArgs a{};
+  const zn_config& c = h->cfg;
+  a.n_q = c.n_codebooks; a.V = c.vocab_head; a.eos_id = c.eos_id;
+  a.temperature = sp.temperature; a.top_p = sp.top_p; a.top_k = sp.top_k; a.min_p = sp.min_p;
+  a.linear = sp.linear; a.conf = sp.conf; a.quad = sp.quad;
+  a.penalty = sp.repetition_penalty; a.pen_window = sp.repetition_penalty_window;
+  a.seed = sp.seed;
+  return a;
+}
+
+// embed -> 26 blocks -> heads -> CFG/bias/penalty/sample -> bookkeeping: one iteration of model.py:467-502
+static int enqueue_step(zn_handle h, hipStream_t s) {
+  const zn_config& c = h->cfg;
+  int rc;
+  EmbedArgs e{};
+  e.tables = h->emb_tables_dev; e.codes = h->codes; e.col_dev = &h->st->offset; e.sb = c.n_codebooks * h->t_total; e.si = h->t_total;
+  e.col = 0; e.n_q = c.n_codebooks; e.d = c.d_model; e.batch = h->batch; e.vocab_embed = c.vocab_embed; e.out = h->x; e.dup = 1;
+  hipLaunchKernelGGL(embed_kernel, dim3(h->batch), dim3(256), 0, s, e);
+  for (int li = 0; li < c.n_layer; ++li)
+    if ((rc = layer_decode(h, li, h->x, (bf16_t*)h->kv_layers[li], h->max_len, h->lengths, nullptr, 0, h->rows, s))) return rc;
+  if ((rc = heads_logits(h, h->x, h->rows, s))) return rc;
+  SampleArgs a = make_sample_args(h, h->sp);
+  a.raw = h->logits_raw; a.mix = 1; a.cfg_scale = h->cfg_scale; a.apply_bias = 1; a.batch = h->batch;
+  a.codes = h->codes; a.t_total = h->t_total; a.ctx = h->max_new < 100 ? h->max_new : 100;
+  a.use_penalty = (h->sp.repetition_penalty != 1.0f); a.st = h->st; a.logits_out = h->last_logits; a.tokens = h->tok_raw;
+  a.draw = 1;
+  hipLaunchKernelGGL(sample_kernel, dim3(c.n_codebooks, h->batch), dim3(256), 0, s, a);
+  FrameArgs f{};
+  f.st = h->st; f.codes = h->codes; f.t_total = h->t_total; f.batch = h->batch; f.n_q = c.n_codebooks; f.eos_id = c.eos_id;
+  f.mask_id = c.mask_id; f.tokens = h->tok_raw; f.remaining = h->remaining; f.stopping = h->stopping; f.lengths = h->lengths;
+  f.rows = h->rows; f.first = 0; f.override = h->tok_override; f.override_calls = h->tok_override_calls;
+  hipLaunchKernelGGL(frame_update_kernel, dim3(1), dim3(256), 0, s, f);
+  return ZN_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ generation
+extern "C" int zn_gen_begin(zn_handle h, int32_t batch, const void* const* kv_layers_dev, int32_t max_len, int32_t* lengths_dev,
+                            int32_t* delayed_codes_dev, int32_t t_total, int32_t offset0, int32_t max_new_tokens, float cfg_scale,
+                            const zn_sampling* sp, zn_stream stream) {
+  if (!h) return ZN_ERR_ARG;
+  if (!kv_layers_dev || !lengths_dev || !delayed_codes_dev || !sp) ZN_FAIL(h, ZN_ERR_ARG, "zn_gen_begin: null argument");
+  if (!h->has_io) ZN_FAIL(h, ZN_ERR_STATE, "zn_gen_begin: handle was created without embeddings/heads");
+  if (batch < 1 || 2 * batch > h->max_rows) ZN_FAIL(h, ZN_ERR_ARG, "zn_gen_begin: batch %d exceeds max_rows %d / 2", batch, h->max_rows);
+  if (max_len < 1 || t_total < 1 || offset0 < 1 || offset0 >= t_total) ZN_FAIL(h, ZN_ERR_ARG, "zn_gen_begin: bad lengths");
+  if (cfg_scale == 1.0f) ZN_FAIL(h, ZN_ERR_ARG, "cfg_scale == 1 is not supported (zonos/model.py:399)");
+  if (sp->repetition_penalty_window < 0 || sp->repetition_penalty_window > 64) ZN_FAIL(h, ZN_ERR_ARG, "repetition_penalty_window out of range");
+  hipStream_t s = (hipStream_t)stream;
+  int rc = ensure_attn_ws(h, max_len);
+  if (rc) return rc;
+  free_graph(h);
+  h->batch = batch; h->rows = 2 * batch; h->max_len = max_len; h->t_total = t_total; h->offset0 = offset0; h->max_new = max_new_tokens;
+  h->cfg_scale = cfg_scale; h->sp = *sp;
+  h->kv_layers.assign(kv_layers_dev, kv_layers_dev + h->cfg.n_layer);
+  h->lengths = lengths_dev; h->codes = delayed_codes_dev;
+  GenState st{};
+  st.offset = offset0; st.step = 0; st.all_done = 0; st.force_eos_step = h->force_eos_step; st.eos_bias = h->eos_bias;
+  HIPCHK(h, hipMemcpyAsync(h->st, &st, sizeof st, hipMemcpyHostToDevice, s));
+  std::vector<int> rem(batch, t_total - offset0), stop(batch, 0);   // model.py:439-441
+  HIPCHK(h, hipMemcpyAsync(h->remaining, rem.data(), batch * sizeof(int), hipMemcpyHostToDevice, s));
+  HIPCHK(h, hipMemcpyAsync(h->stopping, stop.data(), batch * sizeof(int), hipMemcpyHostToDevice, s));
+  HIPCHK(h, hipStreamSynchronize(s));  // host vectors go out of scope
+  h->gen_active = true;
+  return ZN_OK;
+}
+
+static int qsplit(int S) { return S >= 768 ? 256 : S >= 192 ? 64 : 32; }
+
+extern "C" int zn_prefill(zn_handle h, const void* hidden_dev, int32_t S, zn_stream stream) {
+  if (!h) return ZN_ERR_ARG;
+  if (!h->gen_active) ZN_FAIL(h, ZN_ERR_STATE, "zn_prefill before zn_gen_begin");
+  if (!hidden_dev || S < 1 || S > h->max_len) ZN_FAIL(h, ZN_ERR_ARG, "zn_prefill: bad S=%d (max_len %d)", S, h->max_len);
+  hipStream_t s = (hipStream_t)stream;
+  const zn_config& c = h->cfg;
+  // Position by position through the decode kernels.  Row-wise ops are independent of S; attention reproduces the
+  // reference's causal flash-attention blocking through `ext` = keys spanned by the query block of this position.
+  const int qb = qsplit(S);
+  int rc;
+  for (int p = 0; p < S; ++p) {
+    hipLaunchKernelGGL(gather_pos_kernel, dim3(h->rows), dim3(256), 0, s, (const bf16_t*)hidden_dev, h->x, S, p, c.d_model);
+    int ext = (p / qb) * qb + qb; if (ext > S) ext = S;
+    for (int li = 0; li < c.n_layer; ++li)
+      if ((rc = layer_decode(h, li, h->x, (bf16_t*)h->kv_layers[li], h->max_len, h->lengths, nullptr, ext, h->rows, s))) return rc;
+    hipLaunchKernelGGL(add_lengths_kernel, dim3(1), dim3(64 > h->rows ? 64 : h->rows), 0, s, h->lengths, h->rows, 1);
+  }
+  if ((rc = heads_logits(h, h->x, h->rows, s))) return rc;
+  HIPCHK(h, hipGetLastError());
+  return ZN_OK;
+}
+
+extern "C" int zn_sample_first(zn_handle h, zn_stream stream) {
+  if (!h) return ZN_ERR_ARG;
+  if (!h->gen_active) ZN_FAIL(h, ZN_ERR_STATE, "zn_sample_first before zn_gen_begin");
+  hipStream_t s = (hipStream_t)stream;
+  const zn_config& c = h->cfg;
+  SampleArgs a = make_sample_args(h, h->sp);
+  a.raw = h->logits_raw; a.mix = 1; a.cfg_scale = h->cfg_scale; a.apply_bias = 0; a.batch = h->batch;
+  a.use_penalty = 0; a.st = h->st; a.logits_out = h->last_logits; a.tokens = h->tok_raw; a.draw = 0;
+  hipLaunchKernelGGL(sample_kernel, dim3(c.n_codebooks, h->batch), dim3(256), 0, s, a);
+  FrameArgs f{};
+  f.st = h->st; f.codes = h->codes; f.t_total = h->t_total; f.batch = h->batch; f.n_q = c.n_codebooks; f.eos_id = c.eos_id;
+  f.mask_id = c.mask_id; f.tokens = h->tok_raw; f.remaining = h->remaining; f.stopping = h->stopping; f.lengths = h->lengths;
+  f.rows = h->rows; f.first = 1; f.override = h->tok_override; f.override_calls = h->tok_override_calls;
+  hipLaunchKernelGGL(frame_update_kernel, dim3(1), dim3(256), 0, s, f);
+  HIPCHK(h, hipGetLastError());
+  return ZN_OK;
+}
+
+extern "C" int zn_decode_steps(zn_handle h, int32_t n, zn_stream stream) {
+  if (!h) return ZN_ERR_ARG;
+  if (!h->gen_active) ZN_FAIL(h, ZN_ERR_STATE, "zn_decode_steps before zn_gen_begin");
+  if (n < 0) ZN_FAIL(h, ZN_ERR_ARG, "n < 0");
+  hipStream_t s = (hipStream_t)stream;
+  if (!h->graph_exec && !h->graph_tried && n > 1) {
+    // capture one step; every step-varying quantity (column, positions) is read from device memory
+    h->graph_tried = true;
+    // capture on an internal stream: the caller's stream may be the legacy null stream, which cannot be captured
+    if (!h->cap_stream) (void)hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking);
+    hipStream_t cs = h->cap_stream;
+    if (cs && hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+      int rc = enqueue_step(h, cs);
+      hipGraph_t g = nullptr;
+      hipError_t e = hipStreamEndCapture(cs, &g);
+      if (rc == ZN_OK && e == hipSuccess && g && hipGraphInstantiate(&h->graph_exec, g, nullptr, nullptr, 0) == hipSuccess) h->graph = g;
+      else { if (g) (void)hipGraphDestroy(g); h->graph_exec = nullptr; (void)hipGetLastError(); }
+    } else (void)hipGetLastError();
+  }
+  for (int i = 0; i < n; ++i) {
+    if (h->graph_exec) HIPCHK(h, hipGraphLaunch(h->graph_exec, s));
+    else { int rc = enqueue_step(h, s); if (rc) return rc; }
+  }
+  HIPCHK(h, hipGetLastError());
+  return ZN_OK;
+}
+
+extern "C" int zn_graph_active(zn_handle h) { return (h && h->graph_exec) ? 1 : 0; }
+
+extern "C" int zn_all_stopped(zn_handle h, int32_t* out, zn_stream stream) {
+  if (!h || !out) return ZN_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  HIPCHK(h, hipMemcpyAsync(h->done_host, &h->st->all_done, sizeof(int), hipMemcpyDeviceToHost, s));
+  HIPCHK(h, hipStreamSynchronize(s));
+  *out = h->done_host[0];
+  return ZN_OK;
+}
+
+extern "C" int zn_get_step_outputs(zn_handle h, float* logits_dev, int32_t* tokens_dev, zn_stream stream) {
+  if (!h) return ZN_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  const zn_config& c = h->cfg;
+  if (logits_dev) HIPCHK(h, hipMemcpyAsync(logits_dev, h->last_logits, (size_t)h->batch * c.n_codebooks * c.vocab_head * sizeof(float), hipMemcpyDeviceToDevice, s));
+  if (tokens_dev) HIPCHK(h, hipMemcpyAsync(tokens_dev, h->tok_raw, (size_t)h->batch * c.n_codebooks * sizeof(int), hipMemcpyDeviceToDevice, s));
+  return ZN_OK;
+}
+
+extern "C" int zn_debug_force_eos(zn_handle h, int32_t step) { if (!h) return ZN_ERR_ARG; h->force_eos_step = step; return ZN_OK; }
+extern "C" int zn_debug_token_override(zn_handle h, const int32_t* tokens_dev, int32_t calls) {
+  if (!h) return ZN_ERR_ARG;
+  h->tok_override = tokens_dev; h->tok_override_calls = tokens_dev ? calls : 0;
+  free_graph(h);
+  return ZN_OK;
+}
+extern "C" int zn_debug_eos_bias(zn_handle h, float bias) { if (!h) return ZN_ERR_ARG; h->eos_bias = bias; return ZN_OK; }
+
+// ------------------------------------------------------------------------------------------------ measurement
+// Launches one of the step's weight-streaming kernels `iters` times on `stream`, cycling over the layers so that
+// every launch streams its weights from HBM (26 x 67 MB >> the 256 MiB Infinity Cache), bracketed by HIP events on
+// that stream.  which: 0 = LayerNorm+fc1+SiLU-gate, 1 = fc2+residual, 2 = out_proj+residual, 3 = LayerNorm+heads.
+extern "C" int zn_bench_kernel(zn_handle h, int32_t which, int32_t rows, int32_t iters, float* ms_per_launch, double* bytes_per_launch,
+                               zn_stream stream) {
+  if (!h) return ZN_ERR_ARG;
+  if (!ms_per_launch || !bytes_per_launch || iters < 1 || rows < 1 || rows > h->max_rows || which < 0 || which > 3)
+    ZN_FAIL(h, ZN_ERR_ARG, "zn_bench_kernel: bad argument");
+  hipStream_t s = (hipStream_t)stream;
+  const zn_config& c = h->cfg;
+  const int d = c.d_model;
+  HIPCHK(h, hipMemsetAsync(h->x, 0, (size_t)rows * d * 2, s));
+  HIPCHK(h, hipMemsetAsync(h->mbuf, 0, (size_t)rows * c.d_ff * 2, s));
+  HIPCHK(h, hipMemsetAsync(h->o1, 0, (size_t)rows * d * 2, s));
+  hipEvent_t e0, e1;
+  HIPCHK(h, hipEventCreate(&e0));
+  HIPCHK(h, hipEventCreate(&e1));
+  int rc = ZN_OK;
+  for (int pass = 0; pass < 2 && rc == ZN_OK; ++pass) {   // pass 0 = warm-up
+    if (pass == 1) HIPCHK(h, hipEventRecord(e0, s));
+    for (int i = 0; i < (pass ? iters : (iters < 8 ? iters : 8)) && rc == ZN_OK; ++i) {
+      const zn_layer_weights& lw = h->layers[i % c.n_layer];
+      GemvArgs a{};
+      a.eps = c.norm_eps;
+      if (which == 0) {
+        a.W = (const bf16_t*)lw.fc1; a.N = 2 * c.d_ff; a.K = d; a.x = h->x; a.ln_w = (const bf16_t*)lw.norm2_w; a.ln_b = (const bf16_t*)lw.norm2_b; a.out = h->mbuf;
+        rc = run_gemv<PRO_LN, EPI_SILU>(h, a, rows, 1024, s);
+      } else if (which == 1) {
+        a.W = (const bf16_t*)lw.fc2; a.N = d; a.K = c.d_ff; a.x = h->mbuf; a.resid = h->x; a.out = h->x;
+        rc = run_gemv<PRO_NONE, EPI_RESID>(h, a, rows, 1024, s);
+      } else if (which == 2) {
+        a.W = (const bf16_t*)lw.out_proj; a.N = d; a.K = c.n_heads * h->hd; a.x = h->o1; a.resid = h->x; a.out = h->x;
+        rc = run_gemv<PRO_NONE, EPI_RESID>(h, a, rows, 512, s);
+      } else {
+        rc = heads_logits(h, h->x, rows, s);
+      }
+    }
+  }
+  if (rc) return rc;
+  HIPCHK(h, hipEventRecord(e1, s));
+  HIPCHK(h, hipEventSynchronize(e1));
+  float ms = 0.f;
+  HIPCHK(h, hipEventElapsedTime(&ms, e0, e1));
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  *ms_per_launch = ms / iters;
+  const double wbytes = which == 0 ? 2.0 * c.d_ff * d * 2 : which == 1 ? (double)d * c.d_ff * 2 : which == 2 ? (double)d * c.n_heads * h->hd * 2
+                                   : (double)c.n_codebooks * c.vocab_head * d * 2;
+  *bytes_per_launch = wbytes;   // algorithmic bytes = the weight matrix, read once (activations are KBs)
+  return ZN_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ single ops
+extern "C" int zn_op_linear(zn_handle h, const void* x, const void* ln_w, const void* ln_b, const void* W, void* out, int32_t rows,
+                            int32_t N, int32_t K, zn_stream stream) {
+  if (!h) return ZN_ERR_ARG;
+  if (!x || !W || !out || rows < 1 || N < 1 || K < 8 || K % 8) ZN_FAIL(h, ZN_ERR_ARG, "zn_op_linear: bad argument");
+  GemvArgs a{};
+  a.W = (const bf16_t*)W; a.N = N; a.K = K; a.x = (const bf16_t*)x; a.out = (bf16_t*)out; a.eps = h->cfg.norm_eps;
+  int rc;
+  if (ln_w) {
+    if (K > 4096) ZN_FAIL(h, ZN_ERR_UNSUPPORTED, "zn_op_linear: fused LayerNorm needs K <= 4096");
+    a.ln_w = (const bf16_t*)ln_w; a.ln_b = (const bf16_t*)ln_b;
+    rc = run_gemv<PRO_LN, EPI_STORE>(h, a, rows, 1024, (hipStream_t)stream);
+  } else rc = run_gemv<PRO_NONE, EPI_STORE>(h, a, rows, 1024, (hipStream_t)stream);
+  if (rc) return rc;
+  HIPCHK(h, hipGetLastError());
+  return ZN_OK;
+}
+
+extern "C" int zn_op_layernorm(zn_handle h, const void* x, const void* w, const void* b, void* out, int32_t rows, int32_t d, zn_stream stream) {
+  if (!h) return ZN_ERR_ARG;
+  if (!x || !w || !b || !out || rows < 1 || d < 8 || d % 8) ZN_FAIL(h, ZN_ERR_ARG, "zn_op_layernorm: bad argument");
+  hipLaunchKernelGGL(layernorm_kernel, dim3(rows), dim3(64), 0, (hipStream_t)stream, (const bf16_t*)x, (const bf16_t*)w, (const bf16_t*)b,
+                     (bf16_t*)out, d, h->cfg.norm_eps);
+  HIPCHK(h, hipGetLastError());
+  return ZN_OK;
+}
+
+extern "C" int zn_op_layer_decode(zn_handle h, int32_t layer, void* x, void* kv, int32_t max_len, const int32_t* lengths,
+                                  const int32_t* ext, int32_t rows, zn_stream stream) {
+  if (!h) return ZN_ERR_ARG;
+  if (!x || !kv || !lengths || layer < 0 || layer >= h->cfg.n_layer || rows < 1 || rows > h->max_rows || max_len < 1)
+    ZN_FAIL(h, ZN_ERR_ARG, "zn_op_layer_decode: bad argument");
+  int rc = ensure_attn_ws(h, max_len);
+  if (rc) return rc;
+  rc = layer_decode(h, layer, (bf16_t*)x, (bf16_t*)kv, max_len, lengths, ext, 0, rows, (hipStream_t)stream);
+  if (rc) return rc;
+  HIPCHK(h, hipGetLastError());
+  return ZN_OK;
+}
+
+static AttnArgs make_attn_args(zn_handle h, const bf16_t* q, const bf16_t* kv, int max_len, const int* lengths, const int* ext, int ext_scalar) {
+  const zn_config& c = h->cfg;
+  AttnArgs a{};
+  a.q = q; a.kv = kv; a.lengths = lengths; a.ext = ext; a.ext_scalar = ext_scalar; a.max_len = max_len;
+  a.n_heads = c.n_heads; a.n_heads_kv = c.n_heads_kv; a.lcap = h->lcap; a.nb_cap = h->nb_cap;
+  a.scale = (float)(1.0 / std::sqrt((double)h->hd));
+  a.scores = h->scores; a.cmax = h->cmax; a.pacc = h->pacc; a.pl = h->pl; a.pm = h->pm;
+  return a;
+}
+
+extern "C" int zn_op_attn_decode(zn_handle h, const void* q, const void* kv, int32_t max_len, const int32_t* lengths, const int32_t* ext,
+                                 void* out, int32_t rows, zn_stream stream) {
+  if (!h) return ZN_ERR_ARG;
+  if (!q || !kv || !lengths || !out || rows < 1 || rows > h->max_rows || max_len < 1) ZN_FAIL(h, ZN_ERR_ARG, "zn_op_attn_decode: bad argument");
+  int rc = ensure_attn_ws(h, max_len);
+  if (rc) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  const zn_config& c = h->cfg;
+  AttnArgs a = make_attn_args(h, (const bf16_t*)q, (const bf16_t*)kv, max_len, lengths, ext, 0);
+  const int lim = max_len < h->lcap ? max_len : h->lcap;
+  dim3 gs((lim + 127) / 128, c.n_heads_kv, rows), gp((lim + 511) / 512, c.n_heads_kv, rows);
+  const int hd = h->hd;
+  int r2 = hd == 128 ? launch_attn_g<128>(a, h->G, gs, gp, s) : hd == 64 ? launch_attn_g<64>(a, h->G, gs, gp, s) : launch_attn_g<32>(a, h->G, gs, gp, s);
+  if (r2) ZN_FAIL(h, ZN_ERR_UNSUPPORTED, "attention: unsupported group %d", h->G);
+  hipLaunchKernelGGL(attn_combine_kernel, dim3(rows), dim3(256), 0, s, a, (bf16_t*)out, hd);
+  HIPCHK(h, hipGetLastError());
+  return ZN_OK;
+}
+
+extern "C" int zn_op_embed(zn_handle h, const int32_t* codes, void* out, int32_t batch, zn_stream stream) {
+  if (!h) return ZN_ERR_ARG;
+  if (!codes || !out || batch < 1) ZN_FAIL(h, ZN_ERR_ARG, "zn_op_embed: bad argument");
+  if (!h->has_io) ZN_FAIL(h, ZN_ERR_STATE, "zn_op_embed: handle was created without embeddings");
+  const zn_config& c = h->cfg;
+  EmbedArgs e{};
+  e.tables = h->emb_tables_dev; e.codes = codes; e.sb = c.n_codebooks; e.si = 1; e.col = 0; e.n_q = c.n_codebooks; e.d = c.d_model;
+  e.batch = batch; e.vocab_embed = c.vocab_embed; e.out = (bf16_t*)out; e.dup = 0;
+  hipLaunchKernelGGL(embed_kernel, dim3(batch), dim3(256), 0, (hipStream_t)stream, e);
+  HIPCHK(h, hipGetLastError());
+  return ZN_OK;
+}
+
+extern "C" int zn_op_sample(zn_handle h, const float* logits, const int32_t* recent, int32_t window, const zn_sampling* sp,
+                            uint64_t draw_index, int32_t* tokens, float* probs_out, int32_t batch, zn_stream stream) {
+  if (!h) return ZN_ERR_ARG;
+  if (!logits || !sp || !tokens || batch < 1 || (recent && window < 1)) ZN_FAIL(h, ZN_ERR_ARG, "zn_op_sample: bad argument");
+  SampleArgs a = make_sample_args(h, *sp);
+  a.raw = logits; a.mix = 0; a.apply_bias = 0; a.batch = batch; a.recent = recent; a.window = window;
+  a.use_penalty = (recent != nullptr && sp->repetition_penalty != 1.0f); a.tokens = tokens; a.probs_out = probs_out; a.draw = draw_index;
+  hipLaunchKernelGGL(sample_kernel, dim3(h->cfg.n_codebooks, batch), dim3(256), 0, (hipStream_t)stream, a);
+  HIPCHK(h, hipGetLastError());
+  return ZN_OK;
+}

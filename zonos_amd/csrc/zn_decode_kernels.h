@@ -1,0 +1,760 @@
+// Decode-step kernels (S = 1, R = 2B rows): weight-streaming bf16 GEMV with fused prologues/epilogues,
+// KV-cached GQA attention that reproduces the reference CPU flash-attention rounding points, embedding sum,
+// sampler and frame bookkeeping.  All HBM-bound: weights are read once per step with 16-B non-temporal loads,
+// activations (a few KB) live in registers, reductions are wavefront shuffles.
+#pragma once
+#include "zn_common.h"
+
+// ------------------------------------------------------------------------------------------------ GEMV
+enum { PRO_NONE = 0, PRO_LN = 1, PRO_ATTN = 2 };
+enum { EPI_STORE = 0, EPI_RESID = 1, EPI_SILU = 2, EPI_ROPE_KV = 3, EPI_F32 = 4 };
+
+struct GemvArgs {
+  const bf16_t* W;  // [N][K]
+  int N, K, nrows;
+  int units;        // work units (a unit = two weight rows)
+  int upw;          // units per wave (KSPLIT=1) / per block (KSPLIT=4)
+  // prologue
+  const bf16_t* x;  // bf16 [rows][K]
+  const bf16_t *ln_w, *ln_b;
+  float eps;
+  // PRO_ATTN: partial attention results per 512-key block (see attn_pv_kernel)
+  const float *pacc, *pl, *pm;
+  const int* lengths;  // int32 [rows]: keys already in the cache (position of the new token)
+  int nb_cap, hd, n_heads;
+  // epilogue
+  bf16_t* out;           // bf16 [rows][N] (EPI_SILU: [rows][N/2])
+  const bf16_t* resid;   // EPI_RESID
+  float* out_f32;        // EPI_F32 [rows][N]
+  // EPI_ROPE_KV
+  bf16_t* q_out;         // [rows][Hq*hd]
+  bf16_t* kv;            // [rows][max_len][2][Hkv][hd]
+  const float* rope;     // [positions][hd/2][2]
+  int max_len, n_heads_kv, rope_positions;
+};
+
+template <int R, int NCH, int KSPLIT, int PRO, int EPI>
+__global__ __launch_bounds__(256) void gemv_kernel(GemvArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int K = a.K;
+  const int kw = K / KSPLIT;                      // k-range of this wave
+  const int kbase = (KSPLIT == 1) ? 0 : wave * kw;
+  __shared__ float red[4][2][R];
+
+  // ---------------- prologue: this lane's slices of the activation rows, packed bf16 in registers
+  u32x4 xr[NCH][R];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int k = (c * 64 + lane) * 8;
+    const bool kv_ok = k < kw;
+#pragma unroll
+    for (int r = 0; r < R; ++r) xr[c][r] = u32x4{0, 0, 0, 0};
+    if constexpr (PRO == PRO_NONE || PRO == PRO_LN) {
+#pragma unroll
+      for (int r = 0; r < R; ++r)
+        if (kv_ok && r < a.nrows) xr[c][r] = ld16(a.x + (size_t)r * K + kbase + k);
+    }
+  }
+  if constexpr (PRO == PRO_LN) {
+    // nn.LayerNorm (_torch.py:278,280,155): fp32 statistics, biased variance, affine, bf16 out.  KSPLIT == 1.
+    const float invK = 1.0f / (float)K;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      float s = 0.f;
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        const u32x4 v = xr[c][r];
+        s += lo_f(v.x) + hi_f(v.x) + lo_f(v.y) + hi_f(v.y) + lo_f(v.z) + hi_f(v.z) + lo_f(v.w) + hi_f(v.w);
+      }
+      const float mean = wave_sum(s) * invK;
+      float ss = 0.f;
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        if ((c * 64 + lane) * 8 < kw) {
+          const u32x4 v = xr[c][r];
+          float d;
+          d = lo_f(v.x) - mean; ss += d * d; d = hi_f(v.x) - mean; ss += d * d;
+          d = lo_f(v.y) - mean; ss += d * d; d = hi_f(v.y) - mean; ss += d * d;
+          d = lo_f(v.z) - mean; ss += d * d; d = hi_f(v.z) - mean; ss += d * d;
+          d = lo_f(v.w) - mean; ss += d * d; d = hi_f(v.w) - mean; ss += d * d;
+        }
+      }
+      const float rstd = 1.0f / sqrtf(wave_sum(ss) * invK + a.eps);
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        const int k = (c * 64 + lane) * 8;
+        if (k < kw) {
+          const u32x4 g = ld16(a.ln_w + k), b = ld16(a.ln_b + k), v = xr[c][r];
+          u32x4 o;
+          o.x = pack2((lo_f(v.x) - mean) * rstd * lo_f(g.x) + lo_f(b.x), (hi_f(v.x) - mean) * rstd * hi_f(g.x) + hi_f(b.x));
+          o.y = pack2((lo_f(v.y) - mean) * rstd * lo_f(g.y) + lo_f(b.y), (hi_f(v.y) - mean) * rstd * hi_f(g.y) + hi_f(b.y));
+          o.z = pack2((lo_f(v.z) - mean) * rstd * lo_f(g.z) + lo_f(b.z), (hi_f(v.z) - mean) * rstd * hi_f(g.z) + hi_f(b.z));
+          o.w = pack2((lo_f(v.w) - mean) * rstd * lo_f(g.w) + lo_f(b.w), (hi_f(v.w) - mean) * rstd * hi_f(g.w) + hi_f(b.w));
+          xr[c][r] = o;
+        }
+      }
+    }
+  }
+  if constexpr (PRO == PRO_ATTN) {
+    // Combine the per-512-key-block partials exactly as the reference's CPU flash attention walks its KV blocks:
+    // acc = acc*exp(m_prev - m_new) + P.V ; sum likewise ; out = bf16(acc * (1/sum)).
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int k = kbase + (c * 64 + lane) * 8;
+      if ((c * 64 + lane) * 8 < kw) {
+        const int h = k / a.hd, d0 = k % a.hd;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          if (r < a.nrows) {
+            const int L = a.lengths[r] + 1;
+            const int nb = (L + 511) >> 9;
+            const size_t hb = ((size_t)r * a.n_heads + h) * a.nb_cap;
+            float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            float l = 0.f, mprev = 0.f;
+            for (int j = 0; j < nb; ++j) {
+              const float mj = a.pm[hb + j];
+              const float f = (j == 0) ? 0.f : expf(mprev - mj);
+              mprev = mj;
+              l = __fadd_rn(a.pl[hb + j], __fmul_rn(f, l));
+              const float* pa = a.pacc + (hb + j) * a.hd + d0;
+              const f32x4 p0 = *(const f32x4*)pa, p1 = *(const f32x4*)(pa + 4);
+              acc[0] = __fadd_rn(__fmul_rn(acc[0], f), p0.x); acc[1] = __fadd_rn(__fmul_rn(acc[1], f), p0.y);
+              acc[2] = __fadd_rn(__fmul_rn(acc[2], f), p0.z); acc[3] = __fadd_rn(__fmul_rn(acc[3], f), p0.w);
+              acc[4] = __fadd_rn(__fmul_rn(acc[4], f), p1.x); acc[5] = __fadd_rn(__fmul_rn(acc[5], f), p1.y);
+              acc[6] = __fadd_rn(__fmul_rn(acc[6], f), p1.z); acc[7] = __fadd_rn(__fmul_rn(acc[7], f), p1.w);
+            }
+            const float rl = 1.0f / l;
+            u32x4 o;
+            o.x = pack2(__fmul_rn(acc[0], rl), __fmul_rn(acc[1], rl)); o.y = pack2(__fmul_rn(acc[2], rl), __fmul_rn(acc[3], rl));
+            o.z = pack2(__fmul_rn(acc[4], rl), __fmul_rn(acc[5], rl)); o.w = pack2(__fmul_rn(acc[6], rl), __fmul_rn(acc[7], rl));
+            xr[c][r] = o;
+          }
+        }
+      }
+    }
+  }
+
+  // ---------------- main loop over work units
+  const int F = a.N >> 1;  // EPI_SILU: gate rows start at N/2
+  for (int it = 0; it < a.upw; ++it) {
+    int u;
+    if constexpr (KSPLIT == 1) u = (blockIdx.x * 4 + wave) * a.upw + it;
+    else u = blockIdx.x * a.upw + it;
+    const bool u_ok = u < a.units;  // wave-uniform (block-uniform for KSPLIT=4)
+    int rowA, rowB;
+    if constexpr (EPI == EPI_SILU) { rowA = u; rowB = u + F; }
+    else { rowA = 2 * u; rowB = 2 * u + 1; }
+    const bool b_ok = u_ok && rowB < a.N;
+    float accA[R], accB[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) { accA[r] = 0.f; accB[r] = 0.f; }
+    if (u_ok) {
+      u32x4 wa[NCH], wb[NCH];
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        const int k = (c * 64 + lane) * 8;
+        wa[c] = u32x4{0, 0, 0, 0}; wb[c] = u32x4{0, 0, 0, 0};
+        if (k < kw) {
+          wa[c] = ld_nt16(a.W + (size_t)rowA * K + kbase + k);
+          if (b_ok) wb[c] = ld_nt16(a.W + (size_t)rowB * K + kbase + k);
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          accA[r] = dot8(wa[c], xr[c][r], accA[r]);
+          accB[r] = dot8(wb[c], xr[c][r], accB[r]);
+        }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) { accA[r] = wave_sum(accA[r]); accB[r] = wave_sum(accB[r]); }
+    if constexpr (KSPLIT > 1) {
+      __syncthreads();
+      if (lane == 0) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) { red[wave][0][r] = accA[r]; red[wave][1][r] = accB[r]; }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        accA[r] = ((red[0][0][r] + red[1][0][r]) + red[2][0][r]) + red[3][0][r];
+        accB[r] = ((red[0][1][r] + red[1][1][r]) + red[2][1][r]) + red[3][1][r];
+      }
+      if (wave != 0) continue;
+    }
+    if (!u_ok) continue;
+    // ---------------- epilogue: lane r finishes row r
+    float vA = 0.f, vB = 0.f;
+#pragma unroll
+    for (int r = 0; r < R; ++r) if (lane == r) { vA = accA[r]; vB = accB[r]; }
+    if (lane >= a.nrows) continue;
+    const int r = lane;
+    if constexpr (EPI == EPI_STORE) {
+      if (b_ok) *(unsigned*)(a.out + (size_t)r * a.N + rowA) = pack2(vA, vB);
+      else a.out[(size_t)r * a.N + rowA] = f2bf(vA);
+    } else if constexpr (EPI == EPI_F32) {
+      a.out_f32[(size_t)r * a.N + rowA] = bfround(vA);
+      if (b_ok) a.out_f32[(size_t)r * a.N + rowB] = bfround(vB);
+    } else if constexpr (EPI == EPI_RESID) {
+      // x + linear(...) with both operands bf16 (_torch.py:326-327)
+      const size_t o = (size_t)r * a.N + rowA;
+      if (b_ok) {
+        const unsigned rs = *(const unsigned*)(a.resid + o);
+        *(unsigned*)(a.out + o) = pack2(lo_f(rs) + bfround(vA), hi_f(rs) + bfround(vB));
+      } else a.out[o] = f2bf(bf2f(a.resid[o]) + bfround(vA));
+    } else if constexpr (EPI == EPI_SILU) {
+      // y * silu(gate), fc1(x).chunk(2) (_torch.py:473-474): bf16 roundings after fc1, silu and mul
+      const float y = bfround(vA), g = bfround(vB);
+      const float s = bfround(g / (1.0f + expf(-g)));
+      a.out[(size_t)r * F + u] = f2bf(y * s);
+    } else if constexpr (EPI == EPI_ROPE_KV) {
+      // split q|k|v (_torch.py:399-405), interleaved-pair RoPE in fp32 (_torch.py:57-68), KV append (:105-106)
+      const int hd = a.hd, nq = a.n_heads * hd, nk = a.n_heads_kv * hd;
+      const float x0 = bfround(vA), x1 = bfround(vB);
+      const int pos = a.lengths[r];
+      if (rowA < nq + nk) {
+        const int i = (rowA % hd) >> 1;
+        const int p = pos < a.rope_positions ? pos : a.rope_positions - 1;
+        const float cs = a.rope[((size_t)p * (hd >> 1) + i) * 2], sn = a.rope[((size_t)p * (hd >> 1) + i) * 2 + 1];
+        const float re = __fsub_rn(__fmul_rn(x0, cs), __fmul_rn(x1, sn));
+        const float im = __fadd_rn(__fmul_rn(x1, cs), __fmul_rn(x0, sn));
+        if (rowA < nq) *(unsigned*)(a.q_out + (size_t)r * nq + rowA) = pack2(re, im);
+        else if (pos < a.max_len)
+          *(unsigned*)(a.kv + (((size_t)r * a.max_len + pos) * 2 + 0) * nk + (rowA - nq)) = pack2(re, im);
+      } else if (pos < a.max_len) {
+        *(unsigned*)(a.kv + (((size_t)r * a.max_len + pos) * 2 + 1) * nk + (rowA - nq - nk)) = pack2(x0, x1);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ attention
+// Reference semantics (torch CPU flash attention as called at _torch.py:415, verified numerically):
+//   s_t = fl32(q.k_t) * fl32(1/sqrt(hd)); keys are walked in blocks of 512; per block the running max m is
+//   updated, e_t = exp(s_t - m) uses fexp_u20 for the first 16*floor(n/16) keys of the block and libm exp for
+//   the rest, the row sum uses the unrounded e_t, P.V uses bf16(e_t), and the output is bf16(acc * (1/sum)).
+struct AttnArgs {
+  const bf16_t* q;      // [rows][Hq*hd] (post-RoPE)
+  const bf16_t* kv;     // [rows][max_len][2][Hkv][hd]
+  const int* lengths;   // position of the newest key (already appended): L = lengths[r] + 1 keys
+  const int* ext;       // optional int32 [rows]: keys the reference's block loop spans (prefill emulation)
+  int ext_scalar;       // used when ext == NULL and > 0
+  int max_len, n_heads, n_heads_kv, lcap, nb_cap;
+  float scale;
+  float* scores;        // [rows][Hq][lcap]
+  float* cmax;          // [rows][Hq][lcap/128]
+  float *pacc, *pl, *pm;  // [rows][Hq][nb_cap][hd], [rows][Hq][nb_cap] x2
+};
+
+template <int HD, int G>
+__global__ __launch_bounds__(256) void attn_scores_kernel(AttnArgs a) {
+  constexpr int LPP = HD / 8;      // lanes per key
+  constexpr int PPW = 64 / LPP;    // keys per wave-wide load
+  const int chunk = blockIdx.x, kvh = blockIdx.y, r = blockIdx.z;
+  const int L = a.lengths[r] + 1;
+  if (chunk * 128 >= L) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int sub = lane % LPP, grp = lane / LPP;
+  u32x4 qv[G];
+#pragma unroll
+  for (int g = 0; g < G; ++g) qv[g] = ld16(a.q + ((size_t)r * a.n_heads + kvh * G + g) * HD + sub * 8);
+  float mx[G];
+#pragma unroll
+  for (int g = 0; g < G; ++g) mx[g] = -INFINITY;
+  const size_t kvrow = (size_t)2 * a.n_heads_kv * HD;
+  const bf16_t* kbase = a.kv + (size_t)r * a.max_len * kvrow + (size_t)kvh * HD + sub * 8;
+#pragma unroll
+  for (int i = 0; i < 32 / PPW; ++i) {
+    const int t = chunk * 128 + wave * 32 + i * PPW + grp;
+    const bool ok = t < L;
+    u32x4 kk = u32x4{0, 0, 0, 0};
+    if (ok) kk = ld16(kbase + (size_t)t * kvrow);
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      float d = group_sum<LPP>(dot8(kk, qv[g], 0.f));
+      const float s = __fmul_rn(d, a.scale);
+      if (ok) {
+        mx[g] = fmaxf(mx[g], s);
+        if (sub == 0) a.scores[((size_t)r * a.n_heads + kvh * G + g) * a.lcap + t] = s;
+      }
+    }
+  }
+  __shared__ float sm[4][G];
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    const float m = wave_max(mx[g]);
+    if (lane == 0) sm[wave][g] = m;
+  }
+  __syncthreads();
+  if (threadIdx.x < G) {
+    const int g = threadIdx.x;
+    a.cmax[((size_t)r * a.n_heads + kvh * G + g) * (a.lcap >> 7) + chunk] = fmaxf(fmaxf(sm[0][g], sm[1][g]), fmaxf(sm[2][g], sm[3][g]));
+  }
+}
+
+template <int HD, int G>
+__global__ __launch_bounds__(1024) void attn_pv_kernel(AttnArgs a) {
+  constexpr int LPP = HD / 8, PPW = 64 / LPP;
+  const int j = blockIdx.x, kvh = blockIdx.y, r = blockIdx.z;
+  const int L = a.lengths[r] + 1;
+  if (j * 512 >= L) return;
+  int E = a.ext ? a.ext[r] : (a.ext_scalar > 0 ? a.ext_scalar : L);
+  if (E < L) E = L;
+  const int nblk = min(512, E - j * 512);
+  const int nvec = nblk & ~15;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int sub = lane % LPP, grp = lane / LPP;
+  // running max through this block = max over the 128-key chunk maxima of blocks 0..j
+  float m[G];
+  const int nch = min(4 * (j + 1), (L + 127) >> 7);
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    const float* cm = a.cmax + ((size_t)r * a.n_heads + kvh * G + g) * (a.lcap >> 7);
+    float v = -INFINITY;
+    for (int c = 0; c < nch; ++c) v = fmaxf(v, cm[c]);
+    m[g] = v;
+  }
+  float acc[G][8], lsum[G];
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    lsum[g] = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[g][e] = 0.f;
+  }
+  const size_t kvrow = (size_t)2 * a.n_heads_kv * HD;
+  const bf16_t* vbase = a.kv + (size_t)r * a.max_len * kvrow + (size_t)(a.n_heads_kv + kvh) * HD + sub * 8;
+#pragma unroll
+  for (int i = 0; i < 32 / PPW; ++i) {
+    const int idx = wave * 32 + i * PPW + grp;  // index inside the 512-key block
+    const int t = j * 512 + idx;
+    const bool ok = t < L;
+    u32x4 vv = u32x4{0, 0, 0, 0};
+    if (ok) vv = ld16(vbase + (size_t)t * kvrow);
+    const float v0 = lo_f(vv.x), v1 = hi_f(vv.x), v2 = lo_f(vv.y), v3 = hi_f(vv.y);
+    const float v4 = lo_f(vv.z), v5 = hi_f(vv.z), v6 = lo_f(vv.w), v7 = hi_f(vv.w);
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      float e = 0.f;
+      if (ok) {
+        const float x = __fsub_rn(a.scores[((size_t)r * a.n_heads + kvh * G + g) * a.lcap + t], m[g]);
+        e = (idx < nvec) ? zn_fexp_u20(x) : expf(x);
+      }
+      if (sub == 0) lsum[g] += e;
+      const float p = bfround(e);
+      acc[g][0] = fmaf(p, v0, acc[g][0]); acc[g][1] = fmaf(p, v1, acc[g][1]);
+      acc[g][2] = fmaf(p, v2, acc[g][2]); acc[g][3] = fmaf(p, v3, acc[g][3]);
+      acc[g][4] = fmaf(p, v4, acc[g][4]); acc[g][5] = fmaf(p, v5, acc[g][5]);
+      acc[g][6] = fmaf(p, v6, acc[g][6]); acc[g][7] = fmaf(p, v7, acc[g][7]);
+    }
+  }
+  // reduce over the PPW key groups of the wave, then over the 16 waves through LDS (fixed order: deterministic)
+  __shared__ float sacc[16][G][HD];
+  __shared__ float sl[16][G];
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float v = acc[g][e];
+#pragma unroll
+      for (int o = LPP; o < 64; o <<= 1) v += __shfl_xor(v, o);
+      acc[g][e] = v;
+    }
+    const float ls = wave_sum(lsum[g]);
+    if (lane == 0) sl[wave][g] = ls;
+    if (grp == 0) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) sacc[wave][g][sub * 8 + e] = acc[g][e];
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < G * HD; i += 1024) {
+    const int g = i / HD, d = i % HD;
+    float v = 0.f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) v += sacc[w][g][d];
+    a.pacc[(((size_t)r * a.n_heads + kvh * G + g) * a.nb_cap + j) * HD + d] = v;
+  }
+  if (threadIdx.x < G) {
+    const int g = threadIdx.x;
+    float v = 0.f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) v += sl[w][g];
+    const size_t o = ((size_t)r * a.n_heads + kvh * G + g) * a.nb_cap + j;
+    a.pl[o] = v;
+    a.pm[o] = m[g];
+  }
+}
+
+// standalone combine of the per-block partials (same math as the PRO_ATTN GEMV prologue) -> bf16 [rows][Hq*HD]
+__global__ __launch_bounds__(256) void attn_combine_kernel(AttnArgs a, bf16_t* out, int hd) {
+  const int r = blockIdx.x;
+  const int L = a.lengths[r] + 1, nb = (L + 511) >> 9;
+  for (int k = threadIdx.x; k < a.n_heads * hd; k += blockDim.x) {
+    const int h = k / hd, d = k % hd;
+    const size_t hb = ((size_t)r * a.n_heads + h) * a.nb_cap;
+    float acc = 0.f, l = 0.f, mprev = 0.f;
+    for (int j = 0; j < nb; ++j) {
+      const float mj = a.pm[hb + j];
+      const float f = (j == 0) ? 0.f : expf(mprev - mj);
+      mprev = mj;
+      l = __fadd_rn(a.pl[hb + j], __fmul_rn(f, l));
+      acc = __fadd_rn(__fmul_rn(acc, f), a.pacc[(hb + j) * hd + d]);
+    }
+    out[(size_t)r * a.n_heads * hd + k] = f2bf(__fmul_rn(acc, 1.0f / l));
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ embedding
+struct EmbedArgs {
+  const bf16_t* const* tables;  // device array [n_q] of [vocab_embed][d]
+  const int* codes;             // code(b,i) = codes[b*sb + i*si + col]
+  const int* col_dev;           // optional device scalar added to the index (current column), else col
+  int sb, si, col, n_q, d, batch, vocab_embed;
+  bf16_t* out;                  // [2*batch or batch][d]
+  int dup;                      // 1: also write row b + batch (CFG duplicate, generation_utils.py:192)
+};
+__global__ __launch_bounds__(256) void embed_kernel(EmbedArgs a) {
+  const int b = blockIdx.x;
+  const int col = a.col_dev ? *a.col_dev : a.col;
+  for (int k = threadIdx.x * 8; k < a.d; k += 256 * 8) {
+    float acc[8];
+    for (int i = 0; i < a.n_q; ++i) {
+      int code = a.codes[(size_t)b * a.sb + (size_t)i * a.si + col];
+      code = code < 0 ? 0 : (code >= a.vocab_embed ? a.vocab_embed - 1 : code);
+      const u32x4 v = ld16(a.tables[i] + (size_t)code * a.d + k);
+      const float f[8] = {lo_f(v.x), hi_f(v.x), lo_f(v.y), hi_f(v.y), lo_f(v.z), hi_f(v.z), lo_f(v.w), hi_f(v.w)};
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] = (i == 0) ? f[e] : bfround(acc[e] + f[e]);  // python sum(): bf16 adds
+    }
+    u32x4 o;
+    o.x = pack2(acc[0], acc[1]); o.y = pack2(acc[2], acc[3]); o.z = pack2(acc[4], acc[5]); o.w = pack2(acc[6], acc[7]);
+    *(u32x4*)(a.out + (size_t)b * a.d + k) = o;
+    if (a.dup) *(u32x4*)(a.out + (size_t)(b + a.batch) * a.d + k) = o;
+  }
+}
+
+// rows of a [rows][S][d] tensor at position s -> x [rows][d]
+__global__ void gather_pos_kernel(const bf16_t* hidden, bf16_t* x, int S, int s, int d) {
+  const int r = blockIdx.x;
+  for (int k = threadIdx.x * 8; k < d; k += blockDim.x * 8)
+    *(u32x4*)(x + (size_t)r * d + k) = *(const u32x4*)(hidden + ((size_t)r * S + s) * d + k);
+}
+// standalone nn.LayerNorm: one wave per row
+__global__ __launch_bounds__(64) void layernorm_kernel(const bf16_t* x, const bf16_t* w, const bf16_t* b, bf16_t* out, int d, float eps) {
+  const int r = blockIdx.x, lane = threadIdx.x;
+  const bf16_t* xr = x + (size_t)r * d;
+  float s = 0.f;
+  for (int k = lane * 8; k < d; k += 512) { const u32x4 v = ld16(xr + k); s += lo_f(v.x) + hi_f(v.x) + lo_f(v.y) + hi_f(v.y) + lo_f(v.z) + hi_f(v.z) + lo_f(v.w) + hi_f(v.w); }
+  const float mean = wave_sum(s) / (float)d;
+  float ss = 0.f;
+  for (int k = lane * 8; k < d; k += 512) {
+    const u32x4 v = ld16(xr + k);
+    const float f[8] = {lo_f(v.x), hi_f(v.x), lo_f(v.y), hi_f(v.y), lo_f(v.z), hi_f(v.z), lo_f(v.w), hi_f(v.w)};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { const float dd = f[e] - mean; ss += dd * dd; }
+  }
+  const float rstd = 1.0f / sqrtf(wave_sum(ss) / (float)d + eps);
+  for (int k = lane * 8; k < d; k += 512) {
+    const u32x4 v = ld16(xr + k), g = ld16(w + k), bb = ld16(b + k);
+    u32x4 o;
+    o.x = pack2((lo_f(v.x) - mean) * rstd * lo_f(g.x) + lo_f(bb.x), (hi_f(v.x) - mean) * rstd * hi_f(g.x) + hi_f(bb.x));
+    o.y = pack2((lo_f(v.y) - mean) * rstd * lo_f(g.y) + lo_f(bb.y), (hi_f(v.y) - mean) * rstd * hi_f(g.y) + hi_f(bb.y));
+    o.z = pack2((lo_f(v.z) - mean) * rstd * lo_f(g.z) + lo_f(bb.z), (hi_f(v.z) - mean) * rstd * hi_f(g.z) + hi_f(bb.z));
+    o.w = pack2((lo_f(v.w) - mean) * rstd * lo_f(g.w) + lo_f(bb.w), (hi_f(v.w) - mean) * rstd * hi_f(g.w) + hi_f(bb.w));
+    *(u32x4*)(out + (size_t)r * d + k) = o;
+  }
+}
+__global__ void add_lengths_kernel(int* lengths, int rows, int n) {
+  if (threadIdx.x < rows) lengths[threadIdx.x] += n;
+}
+
+// ------------------------------------------------------------------------------------------------ sampler
+struct GenState {      // device-resident loop state (model.py:439-465)
+  int offset;          // column of delayed_codes that feeds the next step (model.py:474: offset-1 after +=1)
+  int step;            // completed loop steps
+  int all_done;        // (remaining_steps <= 0).all()
+  int force_eos_step;  // test hook, -1 = off
+  float eos_bias;      // test/bench hook added to the codebook-0 EOS logit
+  int pad[3];
+};
+
+struct SampleArgs {
+  const float* raw;        // [2B][n_q*V] bf16-valued fp32 from the heads GEMV (mix=1) or [B][n_q][V] final logits
+  int mix; float cfg_scale;
+  int apply_bias;          // loop steps: logit_bias (model.py:433-437,476)
+  int batch, n_q, V, eos_id;
+  const int* codes; int t_total;   // delayed codes [B][n_q][t_total] (penalty history), or
+  const int* recent; int window;   // explicit recent tokens [B][n_q][window]
+  int ctx;                         // min(max_new_tokens, 100) (model.py:463)
+  int use_penalty; float penalty; int pen_window;
+  float temperature, top_p; int top_k; float min_p, linear, conf, quad;
+  unsigned long long seed, draw;
+  GenState* st;            // may be NULL (op mode)
+  float* logits_out;       // [B][n_q][V] logits as consumed by the sampler (after bias), may be NULL
+  float* probs_out;        // optional filtered probabilities
+  int* tokens;             // [B][n_q]
+};
+
+ZN_DEVINL void block_argmax(float v, int i, float* sv, int* si, float& bv, int& bi) {
+  // first-max-wins (torch CPU argmax returns the lowest index among ties)
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(v, o);
+    const int oi = __shfl_xor(i, o);
+    if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) { sv[wave] = v; si[wave] = i; }
+  __syncthreads();
+  bv = sv[0]; bi = si[0];
+  for (int w = 1; w < (int)(blockDim.x >> 6); ++w)
+    if (sv[w] > bv || (sv[w] == bv && si[w] < bi)) { bv = sv[w]; bi = si[w]; }
+}
+ZN_DEVINL float block_sum(float v, float* sv) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) sv[wave] = v;
+  __syncthreads();
+  float t = 0.f;
+  for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += sv[w];
+  return t;
+}
+ZN_DEVINL float block_max(float v, float* sv) {
+  v = wave_max(v);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) sv[wave] = v;
+  __syncthreads();
+  float t = sv[0];
+  for (int w = 1; w < (int)(blockDim.x >> 6); ++w) t = fmaxf(t, sv[w]);
+  return t;
+}
+ZN_DEVINL unsigned long long zn_mix64(unsigned long long z) {
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+
+#define ZN_SAMPLE_MAXV 2048
+__global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
+  const int cb = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const int V = a.V;
+  __shared__ float sp[ZN_SAMPLE_MAXV];
+  __shared__ int sidx[ZN_SAMPLE_MAXV];
+  __shared__ float sv[4];
+  __shared__ int si[4];
+  const int o = a.st ? a.st->offset : 0;
+  // ---- logits: CFG mix (model.py:231-232), logit bias (model.py:433-437,476)
+  for (int i = tid; i < V; i += 256) {
+    float l;
+    if (a.mix) {
+      const float c = a.raw[((size_t)b * a.n_q + cb) * V + i];
+      const float u = a.raw[((size_t)(b + a.batch) * a.n_q + cb) * V + i];
+      l = __fadd_rn(u, __fmul_rn(__fsub_rn(c, u), a.cfg_scale));
+    } else l = a.raw[((size_t)b * a.n_q + cb) * V + i];
+    if (a.apply_bias && i == a.eos_id) {
+      if (cb == 0) {
+        l = __fadd_rn(l, -0.6931471824645996f);  // -log(2) in fp32
+        if (a.st) {
+          l += a.st->eos_bias;
+          if (a.st->force_eos_step == a.st->step) l = 1.0e4f;
+        }
+      } else l = -INFINITY;
+    }
+    if (a.logits_out) a.logits_out[((size_t)b * a.n_q + cb) * V + i] = l;
+    sp[i] = l;
+  }
+  __syncthreads();
+  // ---- repetition penalty (sampling.py:159-163): factor = penalty^(#occurrences in the last `window` tokens)
+  if (a.use_penalty) {
+    int nw = 0;
+    const int* hist = nullptr;
+    if (a.recent) { nw = a.window < a.pen_window ? a.window : a.pen_window; hist = a.recent + ((size_t)b * a.n_q + cb) * a.window + (a.window - nw); }
+    else if (a.codes) {
+      int avail = o + 1 < a.ctx ? o + 1 : a.ctx;   // columns [max(0,o+1-ctx), o]
+      nw = avail < a.pen_window ? avail : a.pen_window;
+      hist = a.codes + ((size_t)b * a.n_q + cb) * a.t_total + (o + 1 - nw);
+    }
+    if (tid == 0) {
+      for (int w = 0; w < nw; ++w) {
+        int g = hist[w];
+        g = g > V - 1 ? V - 1 : g;
+        if (g < 0) continue;
+        // scatter_reduce(prod) builds the factor first; apply once per distinct token
+        bool seen = false;
+        for (int w2 = 0; w2 < w; ++w2) { int g2 = hist[w2]; g2 = g2 > V - 1 ? V - 1 : g2; if (g2 == g) seen = true; }
+        if (seen) continue;
+        float f = 1.f;
+        for (int w2 = w; w2 < nw; ++w2) { int g2 = hist[w2]; g2 = g2 > V - 1 ? V - 1 : g2; if (g2 == g) f = __fmul_rn(f, a.penalty); }
+        const float l = sp[g];
+        sp[g] = (l <= 0.f) ? __fmul_rn(l, f) : __fdiv_rn(l, f);
+      }
+    }
+    __syncthreads();
+  }
+  int tok;
+  if (!(a.temperature > 0.f)) {
+    float bv = -INFINITY; int bi = 0x7fffffff;
+    for (int i = tid; i < V; i += 256) { const float v = sp[i]; if (v > bv) { bv = v; bi = i; } }
+    float rv; int ri;
+    block_argmax(bv, bi, sv, si, rv, ri);
+    tok = ri == 0x7fffffff ? 0 : ri;
+  } else {
+    // ---- softmax(logits / T) (sampling.py:217)
+    float mx = -INFINITY;
+    for (int i = tid; i < V; i += 256) { sp[i] = sp[i] / a.temperature; mx = fmaxf(mx, sp[i]); }
+    mx = block_max(mx, sv);
+    float s = 0.f;
+    for (int i = tid; i < V; i += 256) { const float e = expf(sp[i] - mx); sp[i] = e; s += e; }
+    s = block_sum(s, sv);
+    for (int i = tid; i < V; i += 256) sp[i] = sp[i] / s;
+    __syncthreads();
+    if (a.linear > 0.f) {  // apply_unified (sampling.py:60-63)
+      float ent = 0.f;
+      for (int i = tid; i < V; i += 256) { const float lp = logf(fmaxf(sp[i], 1e-20f)); ent += sp[i] * lp; }
+      ent = -block_sum(ent, sv);
+      float m2 = -INFINITY;
+      for (int i = tid; i < V; i += 256) {
+        const float lp = logf(fmaxf(sp[i], 1e-20f));
+        const float raw = lp * (a.linear + ent * a.conf) - lp * lp * a.quad;
+        sp[i] = raw; m2 = fmaxf(m2, raw);
+      }
+      m2 = block_max(m2, sv);
+      float s2 = 0.f;
+      for (int i = tid; i < V; i += 256) { const float e = expf(sp[i] - m2); sp[i] = e; s2 += e; }
+      s2 = block_sum(s2, sv);
+      for (int i = tid; i < V; i += 256) sp[i] = sp[i] / s2;
+      __syncthreads();
+    }
+    if (a.top_p > 0.f || a.top_k > 0) {
+      // descending bitonic sort of (prob, index) padded to 2048 (sampling.py:93 torch.sort, :77 topk)
+      for (int i = tid; i < ZN_SAMPLE_MAXV; i += 256) { sidx[i] = i; if (i >= V) sp[i] = -1.f; }
+      __syncthreads();
+      for (int k = 2; k <= ZN_SAMPLE_MAXV; k <<= 1) {
+        for (int jj = k >> 1; jj > 0; jj >>= 1) {
+          for (int i = tid; i < ZN_SAMPLE_MAXV; i += 256) {
+            const int p = i ^ jj;
+            if (p > i) {
+              const bool desc = (i & k) == 0;
+              const float x = sp[i], y = sp[p];
+              const int xi = sidx[i], yi = sidx[p];
+              const bool x_first = (x > y) || (x == y && xi < yi);  // order wanted for a descending run
+              if (desc ? !x_first : x_first) { sp[i] = y; sp[p] = x; sidx[i] = yi; sidx[p] = xi; }
+            }
+          }
+          __syncthreads();
+        }
+      }
+      if (a.top_p > 0.f) {  // apply_top_p (sampling.py:93-99): sequential fp32 cumsum like torch.cumsum on CPU
+        if (tid == 0) {
+          float cum = 0.f;
+          for (int i = 0; i < V; ++i) { const float p = sp[i]; cum += p; if (cum - p > a.top_p) sp[i] = 0.f; }
+        }
+        __syncthreads();
+        float s3 = 0.f;
+        for (int i = tid; i < V; i += 256) s3 += sp[i];
+        s3 = block_sum(s3, sv);
+        for (int i = tid; i < V; i += 256) sp[i] = sp[i] / s3;
+        __syncthreads();
+      }
+      if (a.top_k > 0) {  // apply_top_k (sampling.py:77-81): still sorted descending (zeros sink consistently)
+        const int kk = a.top_k < V ? a.top_k : V;
+        // after top_p the array is no longer strictly sorted only among zeros; the k-th largest is sp[kk-1]
+        const float pivot = sp[kk - 1];
+        __syncthreads();
+        float s4 = 0.f;
+        for (int i = tid; i < V; i += 256) { if (sp[i] < pivot) sp[i] = 0.f; s4 += sp[i]; }
+        s4 = block_sum(s4, sv);
+        for (int i = tid; i < V; i += 256) sp[i] = sp[i] / s4;
+        __syncthreads();
+      }
+    } else {
+      for (int i = tid; i < V; i += 256) sidx[i] = i;
+      __syncthreads();
+    }
+    if (a.min_p > 0.f) {  // apply_min_p (sampling.py:123-127)
+      float m3 = 0.f;
+      for (int i = tid; i < V; i += 256) m3 = fmaxf(m3, sp[i]);
+      m3 = block_max(m3, sv);
+      float s5 = 0.f;
+      for (int i = tid; i < V; i += 256) { if (sp[i] < a.min_p * m3) sp[i] = 0.f; s5 += sp[i]; }
+      s5 = block_sum(s5, sv);
+      for (int i = tid; i < V; i += 256) sp[i] = sp[i] / s5;
+      __syncthreads();
+    }
+    if (a.probs_out) for (int i = tid; i < V; i += 256) a.probs_out[((size_t)b * a.n_q + cb) * V + sidx[i]] = sp[i];
+    // Gumbel-max: argmax(p / Exp(1)) (sampling.py:28-30); counter-based RNG stream
+    float bv = -1.f; int bi = 0x7fffffff;
+    for (int i = tid; i < V; i += 256) {
+      const int tokid = sidx[i];
+      unsigned long long h = zn_mix64(a.seed ^ zn_mix64(a.draw + (a.st ? (unsigned long long)a.st->step : 0ull)));
+      h = zn_mix64(h + 0x9E3779B97F4A7C15ull * (unsigned long long)(((size_t)b * a.n_q + cb) * V + tokid + 1));
+      const float uu = ((float)(h >> 40) + 0.5f) * (1.0f / 16777216.0f);
+      const float q = -logf(uu);
+      const float v = sp[i] / q;
+      if (v > bv || (v == bv && tokid < bi)) { bv = v; bi = tokid; }
+    }
+    float rv; int ri;
+    block_argmax(bv, bi, sv, si, rv, ri);
+    tok = ri == 0x7fffffff ? 0 : ri;
+  }
+  if (tid == 0) a.tokens[b * a.n_q + cb] = tok;
+}
+
+// ------------------------------------------------------------------------------------------------ bookkeeping
+struct FrameArgs {
+  GenState* st;
+  int* codes; int t_total, batch, n_q, eos_id, mask_id;
+  const int* tokens;   // raw sampled [B][n_q]
+  int* remaining;      // [B]
+  int* stopping;       // [B]
+  int* lengths; int rows;
+  int first;           // 1: model.py:423-431 (first frame after prefill: plain write-where-unknown)
+  const int* override; // test hook: raw tokens [calls][B][n_q] replacing the sampled ones (call 0 = first frame)
+  int override_calls;
+};
+__global__ __launch_bounds__(256) void frame_update_kernel(FrameArgs a) {
+  const int o = a.st->offset;
+  __shared__ int s_done;
+  if (threadIdx.x == 0) s_done = 1;
+  __syncthreads();
+  for (int b = threadIdx.x; b < a.batch; b += blockDim.x) {
+    const int* tk = a.tokens + b * a.n_q;
+    const int call = a.first ? 0 : a.st->step + 1;
+    if (a.override && call < a.override_calls) tk = a.override + ((size_t)call * a.batch + b) * a.n_q;
+    if (a.first) {
+      for (int cb = 0; cb < a.n_q; ++cb) {
+        int* cell = a.codes + ((size_t)b * a.n_q + cb) * a.t_total + o;
+        if (o < a.t_total && *cell == -1) *cell = tk[cb];
+      }
+      continue;
+    }
+    // model.py:483-497 + tensor_ops.py:155-211
+    int rem = a.remaining[b];
+    int stop = a.stopping[b];
+    if (tk[0] == a.eos_id) { rem = rem < a.n_q ? rem : a.n_q; stop = 1; }
+    int eos_idx = a.n_q - rem; if (eos_idx > a.n_q - 1) eos_idx = a.n_q - 1;
+    const int col = o + 1;
+    if (col < a.t_total) {
+      for (int cb = 0; cb < a.n_q; ++cb) {
+        int t = tk[cb];
+        if (stop && cb < eos_idx) t = a.mask_id; else if (stop && cb == eos_idx) t = a.eos_id;
+        int* cell = a.codes + ((size_t)b * a.n_q + cb) * a.t_total + col;
+        if (*cell == -1) *cell = t;                         // tensor_ops.py:42-49
+      }
+    }
+    rem -= 1;                                               // tensor_ops.py:87
+    a.remaining[b] = rem; a.stopping[b] = stop;
+    if (rem > 0) atomicAnd(&s_done, 0);
+  }
+  __syncthreads();
+  if (!a.first) {
+    for (int r = threadIdx.x; r < a.rows; r += blockDim.x) a.lengths[r] += 1;   // tensor_ops.py:85-86
+    if (threadIdx.x == 0) { a.st->offset = o + 1; a.st->step += 1; a.st->all_done = s_done; }
+  }
+}

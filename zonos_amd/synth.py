@@ -84,7 +84,20 @@ def _t(a: np.ndarray, dtype) -> torch.Tensor:
     return torch.from_numpy(a).to(dtype)
 
 
-def zonos_state_dict(cfg: dict, seed: int = 1234, dtype=torch.bfloat16) -> dict:
+def peaky_heads(seed: int, name: str, rows: int, d: int, nnz: int = 4) -> np.ndarray:
+    """Sparse heavy-tailed head rows: `nnz` non-zeros per row at hashed columns, magnitude log-uniform in [1, 20].
+    Logits then have decisive top-2 margins (like a trained model) instead of the near-ties of Gaussian logits,
+    which makes free-running greedy decode a meaningful bit-exactness test."""
+    w = np.zeros((rows, d), dtype=np.float32)
+    cols = randint(seed, name + ".cols", (rows, nnz), d)
+    mag = np.exp(np.abs(uniform(seed, name + ".mag", (rows, nnz), 1.0)).astype(np.float64) * np.log(20.0)).astype(np.float32)
+    sgn = np.where(uniform(seed, name + ".sgn", (rows, nnz), 1.0) < 0, -1.0, 1.0).astype(np.float32)
+    for j in range(nnz):
+        w[np.arange(rows), cols[:, j]] = mag[:, j] * sgn[:, j]
+    return w
+
+
+def zonos_state_dict(cfg: dict, seed: int = 1234, dtype=torch.bfloat16, peaky: bool = False) -> dict:
     """Synthetic transformer-backbone weights under the reference's safetensors key contract
     (module names at zonos/backbone/_torch.py:154-155,278-281,373-374,453-454,
     zonos/model.py:81-82).  Scales follow PyTorch defaults: Linear U(+-1/sqrt(in)), Embedding
@@ -99,8 +112,11 @@ def zonos_state_dict(cfg: dict, seed: int = 1234, dtype=torch.bfloat16) -> dict:
     sd = {}
     for i in range(nq):
         sd[f"embeddings.{i}.weight"] = _t(normal(seed, f"embeddings.{i}.weight", (ve, d)), dtype)
-    sd["fused_heads.weight"] = torch.cat(
-        [_t(uniform(seed, f"heads.{i}.weight", (vh, d), 1.0 / np.sqrt(d)), dtype) for i in range(nq)], 0)
+    if peaky:
+        sd["fused_heads.weight"] = torch.cat([_t(peaky_heads(seed, f"heads.{i}.weight", vh, d), dtype) for i in range(nq)], 0)
+    else:
+        sd["fused_heads.weight"] = torch.cat(
+            [_t(uniform(seed, f"heads.{i}.weight", (vh, d), 1.0 / np.sqrt(d)), dtype) for i in range(nq)], 0)
     for l in range(L):
         p = f"backbone.layers.{l}."
         for nm in ("norm", "norm2"):

@@ -1,0 +1,26 @@
+"""Helpers shared by tests, bench.py and smoke(): build a `Zonos` around synthetic weights (zonos_amd/synth.py)."""
+from __future__ import annotations
+
+import torch
+
+from . import synth
+from .autoencoder import DACAutoencoder
+from .config import BackboneConfig, PrefixConditionerConfig, ZonosConfig
+from .model import Zonos
+
+
+def zonos_config(cfg: dict) -> ZonosConfig:
+    return ZonosConfig(BackboneConfig(d_model=cfg["d_model"], n_layer=cfg["n_layer"], attn_mlp_d_intermediate=cfg["d_ff"],
+                                      attn_layer_idx=list(range(cfg["n_layer"])),
+                                      attn_cfg=dict(num_heads=cfg["num_heads"], num_heads_kv=cfg["num_heads_kv"])),
+                       PrefixConditionerConfig([], "none"))
+
+
+def build_model(cfg: dict, seed: int, device="cuda", dac: DACAutoencoder | None = None, peaky: bool = False):
+    """Returns (model on `device`, CPU state dict).  The state dict uses the reference's key contract."""
+    sd = synth.zonos_state_dict(cfg, seed, peaky=peaky)
+    with torch.device("meta"):
+        model = Zonos(zonos_config(cfg), autoencoder=dac or DACAutoencoder())
+    model.load_state_dict({k: v for k, v in sd.items()}, assign=True, strict=True)
+    model = model.to(device)
+    return model.eval(), sd
