@@ -24,8 +24,6 @@ struct zn_handle_s {
   bf16_t *x = nullptr, *q = nullptr, *o1 = nullptr, *mbuf = nullptr;
   float *logits_raw = nullptr, *last_logits = nullptr;
   int* tok_raw = nullptr;
-  float *scores = nullptr, *cmax = nullptr, *pacc = nullptr, *pl = nullptr, *pm = nullptr;
-  int lcap = 0, nb_cap = 0;
   GenState* st = nullptr;
   int *remaining = nullptr, *stopping = nullptr;
   int* done_host = nullptr;  // pinned
@@ -78,28 +76,11 @@ static void free_graph(zn_handle h) {
 extern "C" int zn_destroy(zn_handle h) {
   if (!h) return ZN_OK;
   free_graph(h);
-  void* ptrs[] = {h->emb_tables_dev, h->x, h->q, h->o1, h->mbuf, h->logits_raw, h->last_logits, h->tok_raw, h->scores,
-                  h->cmax, h->pacc, h->pl, h->pm, h->st, h->remaining, h->stopping};
+  void* ptrs[] = {h->emb_tables_dev, h->x, h->q, h->o1, h->mbuf, h->logits_raw, h->last_logits, h->tok_raw, h->st, h->remaining, h->stopping};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (h->done_host) (void)hipHostFree(h->done_host);
   if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
   delete h;
-  return ZN_OK;
-}
-
-static int ensure_attn_ws(zn_handle h, int max_len) {
-  const int lcap = ((max_len + 511) / 512) * 512;
-  if (lcap <= h->lcap) return ZN_OK;
-  free_graph(h);
-  for (float** p : {&h->scores, &h->cmax, &h->pacc, &h->pl, &h->pm}) if (*p) { (void)hipFree(*p); *p = nullptr; }
-  const size_t RH = (size_t)h->max_rows * h->cfg.n_heads;
-  const int nb = lcap / 512;
-  HIPCHK(h, hipMalloc(&h->scores, RH * lcap * sizeof(float)));
-  HIPCHK(h, hipMalloc(&h->cmax, RH * (lcap / 128) * sizeof(float)));
-  HIPCHK(h, hipMalloc(&h->pacc, RH * nb * h->hd * sizeof(float)));
-  HIPCHK(h, hipMalloc(&h->pl, RH * nb * sizeof(float)));
-  HIPCHK(h, hipMalloc(&h->pm, RH * nb * sizeof(float)));
-  h->lcap = lcap; h->nb_cap = nb;
   return ZN_OK;
 }
 
@@ -198,21 +179,33 @@ static int run_gemv(zn_handle h, GemvArgs a, int rows, int target_blocks, hipStr
     if (g.lengths) g.lengths += r0;
     if (g.q_out) g.q_out += (size_t)r0 * a.n_heads * a.hd;
     if (g.kv) g.kv += (size_t)r0 * a.max_len * 2 * a.n_heads_kv * a.hd;
-    if (g.pacc) { g.pacc += (size_t)r0 * a.n_heads * a.nb_cap * a.hd; g.pl += (size_t)r0 * a.n_heads * a.nb_cap; g.pm += (size_t)r0 * a.n_heads * a.nb_cap; }
     if (launch_gemv_rows<PRO, EPI>(g, nr, ks, nch, blocks, s) != 0) ZN_FAIL(h, ZN_ERR_UNSUPPORTED, "gemv: no kernel for ks=%d nch=%d", ks, nch);
   }
   return ZN_OK;
 }
 
 template <int HD>
-static int launch_attn_g(const AttnArgs& a, int G, dim3 gs, dim3 gp, hipStream_t s) {
+static int launch_attn_g(const AttnArgs& a, int G, dim3 grid, hipStream_t s) {
   switch (G) {
-    case 1: hipLaunchKernelGGL((attn_scores_kernel<HD, 1>), gs, dim3(256), 0, s, a); hipLaunchKernelGGL((attn_pv_kernel<HD, 1>), gp, dim3(1024), 0, s, a); return 0;
-    case 2: hipLaunchKernelGGL((attn_scores_kernel<HD, 2>), gs, dim3(256), 0, s, a); hipLaunchKernelGGL((attn_pv_kernel<HD, 2>), gp, dim3(1024), 0, s, a); return 0;
-    case 4: hipLaunchKernelGGL((attn_scores_kernel<HD, 4>), gs, dim3(256), 0, s, a); hipLaunchKernelGGL((attn_pv_kernel<HD, 4>), gp, dim3(1024), 0, s, a); return 0;
-    case 8: hipLaunchKernelGGL((attn_scores_kernel<HD, 8>), gs, dim3(256), 0, s, a); hipLaunchKernelGGL((attn_pv_kernel<HD, 8>), gp, dim3(1024), 0, s, a); return 0;
+    case 1: hipLaunchKernelGGL((attn_decode_kernel<HD, 1>), grid, dim3(1024), 0, s, a); return 0;
+    case 2: hipLaunchKernelGGL((attn_decode_kernel<HD, 2>), grid, dim3(1024), 0, s, a); return 0;
+    case 4: hipLaunchKernelGGL((attn_decode_kernel<HD, 4>), grid, dim3(1024), 0, s, a); return 0;
+    case 8: hipLaunchKernelGGL((attn_decode_kernel<HD, 8>), grid, dim3(1024), 0, s, a); return 0;
   }
   return -1;
+}
+
+static int run_attention(zn_handle h, const bf16_t* q, const bf16_t* kv, int max_len, const int* lengths, const int* ext, int ext_scalar,
+                         bf16_t* out, int rows, hipStream_t s) {
+  const zn_config& c = h->cfg;
+  AttnArgs a{};
+  a.q = q; a.kv = kv; a.lengths = lengths; a.ext = ext; a.ext_scalar = ext_scalar; a.max_len = max_len;
+  a.n_heads = c.n_heads; a.n_heads_kv = c.n_heads_kv; a.scale = (float)(1.0 / std::sqrt((double)h->hd)); a.out = out;
+  const int hd = h->hd;
+  dim3 grid(hd / 32, c.n_heads_kv, rows);
+  int r2 = hd == 128 ? launch_attn_g<128>(a, h->G, grid, s) : hd == 64 ? launch_attn_g<64>(a, h->G, grid, s) : launch_attn_g<32>(a, h->G, grid, s);
+  if (r2) ZN_FAIL(h, ZN_ERR_UNSUPPORTED, "attention: unsupported group %d", h->G);
+  return ZN_OK;
 }
 
 // One decode step of block `li` on x [rows][d] in place (_torch.py:307-328).
@@ -230,30 +223,20 @@ static int layer_decode(zn_handle h, int li, bf16_t* x, bf16_t* kv, int max_len,
     a.q_out = h->q; a.kv = kv; a.rope = h->rope; a.max_len = max_len; a.rope_positions = c.rope_positions;
     if ((rc = run_gemv<PRO_LN, EPI_ROPE_KV>(h, a, rows, 512, s))) return rc;
   }
-  {  // scores + per-512-block P.V partials
-    AttnArgs a{};
-    a.q = h->q; a.kv = kv; a.lengths = lengths; a.ext = ext; a.ext_scalar = ext_scalar; a.max_len = max_len;
-    a.n_heads = c.n_heads; a.n_heads_kv = c.n_heads_kv; a.lcap = h->lcap; a.nb_cap = h->nb_cap;
-    a.scale = (float)(1.0 / std::sqrt((double)hd));
-    a.scores = h->scores; a.cmax = h->cmax; a.pacc = h->pacc; a.pl = h->pl; a.pm = h->pm;
-    const int lim = max_len < h->lcap ? max_len : h->lcap;
-    dim3 gs((lim + 127) / 128, c.n_heads_kv, rows), gp((lim + 511) / 512, c.n_heads_kv, rows);
-    int r2 = hd == 128 ? launch_attn_g<128>(a, h->G, gs, gp, s) : hd == 64 ? launch_attn_g<64>(a, h->G, gs, gp, s) : launch_attn_g<32>(a, h->G, gs, gp, s);
-    if (r2) ZN_FAIL(h, ZN_ERR_UNSUPPORTED, "attention: unsupported group %d", h->G);
-  }
-  {  // combine partials -> out_proj (-> out_proj again, _torch.py:419-420) -> residual
+  // KV-cached GQA attention over keys [0, lengths+1) (_torch.py:413-417) -> attention output in h->o1
+  if ((rc = run_attention(h, h->q, kv, max_len, lengths, ext, ext_scalar, h->o1, rows, s))) return rc;
+  {  // out_proj (-> out_proj again, _torch.py:419-420) -> residual
     GemvArgs a{};
-    a.W = (const bf16_t*)lw.out_proj; a.N = d; a.K = nq; a.lengths = lengths;
-    a.pacc = h->pacc; a.pl = h->pl; a.pm = h->pm; a.nb_cap = h->nb_cap; a.hd = hd; a.n_heads = c.n_heads;
+    a.W = (const bf16_t*)lw.out_proj; a.N = d; a.K = nq; a.x = h->o1;
     if (c.double_out_proj) {
-      a.out = h->o1;
-      if ((rc = run_gemv<PRO_ATTN, EPI_STORE>(h, a, rows, 512, s))) return rc;
+      a.out = h->q;   // q is dead after attention: reuse it for the intermediate projection
+      if ((rc = run_gemv<PRO_NONE, EPI_STORE>(h, a, rows, 512, s))) return rc;
       GemvArgs b{};
-      b.W = (const bf16_t*)lw.out_proj; b.N = d; b.K = nq; b.x = h->o1; b.resid = x; b.out = x;
+      b.W = (const bf16_t*)lw.out_proj; b.N = d; b.K = nq; b.x = h->q; b.resid = x; b.out = x;
       if ((rc = run_gemv<PRO_NONE, EPI_RESID>(h, b, rows, 512, s))) return rc;
     } else {
       a.resid = x; a.out = x;
-      if ((rc = run_gemv<PRO_ATTN, EPI_RESID>(h, a, rows, 512, s))) return rc;
+      if ((rc = run_gemv<PRO_NONE, EPI_RESID>(h, a, rows, 512, s))) return rc;
     }
   }
   {  // LayerNorm -> fc1 -> y * silu(gate)
@@ -326,8 +309,6 @@ extern "C" int zn_gen_begin(zn_handle h, int32_t batch, const void* const* kv_la
   if (cfg_scale == 1.0f) ZN_FAIL(h, ZN_ERR_ARG, "cfg_scale == 1 is not supported (zonos/model.py:399)");
   if (sp->repetition_penalty_window < 0 || sp->repetition_penalty_window > 64) ZN_FAIL(h, ZN_ERR_ARG, "repetition_penalty_window out of range");
   hipStream_t s = (hipStream_t)stream;
-  int rc = ensure_attn_ws(h, max_len);
-  if (rc) return rc;
   free_graph(h);
   h->batch = batch; h->rows = 2 * batch; h->max_len = max_len; h->t_total = t_total; h->offset0 = offset0; h->max_new = max_new_tokens;
   h->cfg_scale = cfg_scale; h->sp = *sp;
@@ -526,39 +507,18 @@ extern "C" int zn_op_layer_decode(zn_handle h, int32_t layer, void* x, void* kv,
   if (!h) return ZN_ERR_ARG;
   if (!x || !kv || !lengths || layer < 0 || layer >= h->cfg.n_layer || rows < 1 || rows > h->max_rows || max_len < 1)
     ZN_FAIL(h, ZN_ERR_ARG, "zn_op_layer_decode: bad argument");
-  int rc = ensure_attn_ws(h, max_len);
-  if (rc) return rc;
-  rc = layer_decode(h, layer, (bf16_t*)x, (bf16_t*)kv, max_len, lengths, ext, 0, rows, (hipStream_t)stream);
+  int rc = layer_decode(h, layer, (bf16_t*)x, (bf16_t*)kv, max_len, lengths, ext, 0, rows, (hipStream_t)stream);
   if (rc) return rc;
   HIPCHK(h, hipGetLastError());
   return ZN_OK;
 }
 
-static AttnArgs make_attn_args(zn_handle h, const bf16_t* q, const bf16_t* kv, int max_len, const int* lengths, const int* ext, int ext_scalar) {
-  const zn_config& c = h->cfg;
-  AttnArgs a{};
-  a.q = q; a.kv = kv; a.lengths = lengths; a.ext = ext; a.ext_scalar = ext_scalar; a.max_len = max_len;
-  a.n_heads = c.n_heads; a.n_heads_kv = c.n_heads_kv; a.lcap = h->lcap; a.nb_cap = h->nb_cap;
-  a.scale = (float)(1.0 / std::sqrt((double)h->hd));
-  a.scores = h->scores; a.cmax = h->cmax; a.pacc = h->pacc; a.pl = h->pl; a.pm = h->pm;
-  return a;
-}
-
 extern "C" int zn_op_attn_decode(zn_handle h, const void* q, const void* kv, int32_t max_len, const int32_t* lengths, const int32_t* ext,
                                  void* out, int32_t rows, zn_stream stream) {
   if (!h) return ZN_ERR_ARG;
-  if (!q || !kv || !lengths || !out || rows < 1 || rows > h->max_rows || max_len < 1) ZN_FAIL(h, ZN_ERR_ARG, "zn_op_attn_decode: bad argument");
-  int rc = ensure_attn_ws(h, max_len);
+  if (!q || !kv || !lengths || !out || rows < 1 || max_len < 1) ZN_FAIL(h, ZN_ERR_ARG, "zn_op_attn_decode: bad argument");
+  int rc = run_attention(h, (const bf16_t*)q, (const bf16_t*)kv, max_len, lengths, ext, 0, (bf16_t*)out, rows, (hipStream_t)stream);
   if (rc) return rc;
-  hipStream_t s = (hipStream_t)stream;
-  const zn_config& c = h->cfg;
-  AttnArgs a = make_attn_args(h, (const bf16_t*)q, (const bf16_t*)kv, max_len, lengths, ext, 0);
-  const int lim = max_len < h->lcap ? max_len : h->lcap;
-  dim3 gs((lim + 127) / 128, c.n_heads_kv, rows), gp((lim + 511) / 512, c.n_heads_kv, rows);
-  const int hd = h->hd;
-  int r2 = hd == 128 ? launch_attn_g<128>(a, h->G, gs, gp, s) : hd == 64 ? launch_attn_g<64>(a, h->G, gs, gp, s) : launch_attn_g<32>(a, h->G, gs, gp, s);
-  if (r2) ZN_FAIL(h, ZN_ERR_UNSUPPORTED, "attention: unsupported group %d", h->G);
-  hipLaunchKernelGGL(attn_combine_kernel, dim3(rows), dim3(256), 0, s, a, (bf16_t*)out, hd);
   HIPCHK(h, hipGetLastError());
   return ZN_OK;
 }

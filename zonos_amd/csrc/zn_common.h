@@ -31,20 +31,50 @@ __device__ __forceinline__ float dot8(const u32x4& w, const u32x4& x, float c) {
 __device__ __forceinline__ u32x4 ld_nt16(const void* p) { return __builtin_nontemporal_load((const u32x4*)p); }
 __device__ __forceinline__ u32x4 ld16(const void* p) { return *(const u32x4*)p; }
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+// ---- cross-lane reductions on the VALU (DPP within a 16-lane row, v_permlane16/32_swap across rows): no LDS
+// round trips (ds_bpermute chains made the first version of these kernels latency-bound).
+template <int CTRL> __device__ __forceinline__ float dpp_mov(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+#define ZN_DPP_XOR1 0xB1          // quad_perm [1,0,3,2]
+#define ZN_DPP_XOR2 0x4E          // quad_perm [2,3,0,1]
+#define ZN_DPP_HALF_MIRROR 0x141  // lane i <-> 7-i inside each 8 lanes
+#define ZN_DPP_MIRROR 0x140       // lane i <-> 15-i inside each row of 16
+#define ZN_DPP_ROR4 0x124
+#define ZN_DPP_ROR8 0x128
+__device__ __forceinline__ float readlane_f(float v, int lane) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
+}
+// reduce over groups of WIDTH consecutive lanes (WIDTH in {4,8,16}); every lane of the group gets the result
+template <int WIDTH> __device__ __forceinline__ float group_sum(float v) {
+  static_assert(WIDTH == 4 || WIDTH == 8 || WIDTH == 16, "row-local reduction");
+  v += dpp_mov<ZN_DPP_XOR1>(v);
+  v += dpp_mov<ZN_DPP_XOR2>(v);
+  if (WIDTH >= 8) v += dpp_mov<ZN_DPP_HALF_MIRROR>(v);
+  if (WIDTH >= 16) v += dpp_mov<ZN_DPP_MIRROR>(v);
   return v;
+}
+template <int WIDTH> __device__ __forceinline__ float group_max(float v) {
+  static_assert(WIDTH == 4 || WIDTH == 8 || WIDTH == 16, "row-local reduction");
+  v = fmaxf(v, dpp_mov<ZN_DPP_XOR1>(v));
+  v = fmaxf(v, dpp_mov<ZN_DPP_XOR2>(v));
+  if (WIDTH >= 8) v = fmaxf(v, dpp_mov<ZN_DPP_HALF_MIRROR>(v));
+  if (WIDTH >= 16) v = fmaxf(v, dpp_mov<ZN_DPP_MIRROR>(v));
+  return v;
+}
+// whole-wave reductions: row totals by DPP, then the four rows through v_readlane (wave-uniform result)
+__device__ __forceinline__ float wave_sum(float v) {
+  v = group_sum<16>(v);
+  return (readlane_f(v, 0) + readlane_f(v, 16)) + (readlane_f(v, 32) + readlane_f(v, 48));
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
-  return v;
+  v = group_max<16>(v);
+  return fmaxf(fmaxf(readlane_f(v, 0), readlane_f(v, 16)), fmaxf(readlane_f(v, 32), readlane_f(v, 48)));
 }
-// reduce over groups of `width` consecutive lanes (width power of two <= 64)
-template <int WIDTH> __device__ __forceinline__ float group_sum(float v) {
-#pragma unroll
-  for (int o = WIDTH / 2; o > 0; o >>= 1) v += __shfl_xor(v, o);
+// sum over the lanes of one 16-lane row that share (lane % 4)
+__device__ __forceinline__ float row_stride4_sum(float v) {
+  v += dpp_mov<ZN_DPP_ROR4>(v);
+  v += dpp_mov<ZN_DPP_ROR8>(v);
   return v;
 }
 

@@ -6,7 +6,7 @@
 #include "zn_common.h"
 
 // ------------------------------------------------------------------------------------------------ GEMV
-enum { PRO_NONE = 0, PRO_LN = 1, PRO_ATTN = 2 };
+enum { PRO_NONE = 0, PRO_LN = 1 };
 enum { EPI_STORE = 0, EPI_RESID = 1, EPI_SILU = 2, EPI_ROPE_KV = 3, EPI_F32 = 4 };
 
 struct GemvArgs {
@@ -18,10 +18,8 @@ struct GemvArgs {
   const bf16_t* x;  // bf16 [rows][K]
   const bf16_t *ln_w, *ln_b;
   float eps;
-  // PRO_ATTN: partial attention results per 512-key block (see attn_pv_kernel)
-  const float *pacc, *pl, *pm;
   const int* lengths;  // int32 [rows]: keys already in the cache (position of the new token)
-  int nb_cap, hd, n_heads;
+  int hd, n_heads;
   // epilogue
   bf16_t* out;           // bf16 [rows][N] (EPI_SILU: [rows][N/2])
   const bf16_t* resid;   // EPI_RESID
@@ -33,6 +31,28 @@ struct GemvArgs {
   int max_len, n_heads_kv, rope_positions;
 };
 
+// Weight tile of one work unit (two weight rows) held in registers.
+template <int NCH> struct WTile { u32x4 a[NCH], b[NCH]; };
+
+template <int NCH, int KSPLIT, int EPI>
+ZN_DEVINL void gemv_load_unit(const GemvArgs& a, int u, int lane, int kw, int kbase, WTile<NCH>& t) {
+  const int F = a.N >> 1;
+  const bool u_ok = u < a.units;
+  int rowA, rowB;
+  if constexpr (EPI == EPI_SILU) { rowA = u; rowB = u + F; }
+  else { rowA = 2 * u; rowB = 2 * u + 1; }
+  const bool b_ok = u_ok && rowB < a.N;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int k = (c * 64 + lane) * 8;
+    t.a[c] = u32x4{0, 0, 0, 0}; t.b[c] = u32x4{0, 0, 0, 0};
+    if (u_ok && k < kw) {
+      t.a[c] = ld_nt16(a.W + (size_t)rowA * a.K + kbase + k);
+      if (b_ok) t.b[c] = ld_nt16(a.W + (size_t)rowB * a.K + kbase + k);
+    }
+  }
+}
+
 template <int R, int NCH, int KSPLIT, int PRO, int EPI>
 __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs a) {
   const int lane = threadIdx.x & 63;
@@ -41,6 +61,11 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs a) {
   const int kw = K / KSPLIT;                      // k-range of this wave
   const int kbase = (KSPLIT == 1) ? 0 : wave * kw;
   __shared__ float red[4][2][R];
+  const int u0 = (KSPLIT == 1) ? (blockIdx.x * 4 + wave) * a.upw : blockIdx.x * a.upw;
+
+  // the first unit's weights do not depend on the activations: get them in flight before the prologue
+  WTile<NCH> wt;
+  gemv_load_unit<NCH, KSPLIT, EPI>(a, u0, lane, kw, kbase, wt);
 
   // ---------------- prologue: this lane's slices of the activation rows, packed bf16 in registers
   u32x4 xr[NCH][R];
@@ -49,98 +74,67 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs a) {
     const int k = (c * 64 + lane) * 8;
     const bool kv_ok = k < kw;
 #pragma unroll
-    for (int r = 0; r < R; ++r) xr[c][r] = u32x4{0, 0, 0, 0};
-    if constexpr (PRO == PRO_NONE || PRO == PRO_LN) {
-#pragma unroll
-      for (int r = 0; r < R; ++r)
-        if (kv_ok && r < a.nrows) xr[c][r] = ld16(a.x + (size_t)r * K + kbase + k);
+    for (int r = 0; r < R; ++r) {
+      xr[c][r] = u32x4{0, 0, 0, 0};
+      if (kv_ok && r < a.nrows) xr[c][r] = ld16(a.x + (size_t)r * K + kbase + k);
     }
   }
   if constexpr (PRO == PRO_LN) {
     // nn.LayerNorm (_torch.py:278,280,155): fp32 statistics, biased variance, affine, bf16 out.  KSPLIT == 1.
     const float invK = 1.0f / (float)K;
+    float s[R], ss[R], mean[R], rstd[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-      float s = 0.f;
+      s[r] = 0.f;
 #pragma unroll
       for (int c = 0; c < NCH; ++c) {
         const u32x4 v = xr[c][r];
-        s += lo_f(v.x) + hi_f(v.x) + lo_f(v.y) + hi_f(v.y) + lo_f(v.z) + hi_f(v.z) + lo_f(v.w) + hi_f(v.w);
+        s[r] += lo_f(v.x) + hi_f(v.x) + lo_f(v.y) + hi_f(v.y) + lo_f(v.z) + hi_f(v.z) + lo_f(v.w) + hi_f(v.w);
       }
-      const float mean = wave_sum(s) * invK;
-      float ss = 0.f;
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) mean[r] = wave_sum(s[r]) * invK;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      ss[r] = 0.f;
 #pragma unroll
       for (int c = 0; c < NCH; ++c) {
         if ((c * 64 + lane) * 8 < kw) {
           const u32x4 v = xr[c][r];
           float d;
-          d = lo_f(v.x) - mean; ss += d * d; d = hi_f(v.x) - mean; ss += d * d;
-          d = lo_f(v.y) - mean; ss += d * d; d = hi_f(v.y) - mean; ss += d * d;
-          d = lo_f(v.z) - mean; ss += d * d; d = hi_f(v.z) - mean; ss += d * d;
-          d = lo_f(v.w) - mean; ss += d * d; d = hi_f(v.w) - mean; ss += d * d;
+          d = lo_f(v.x) - mean[r]; ss[r] += d * d; d = hi_f(v.x) - mean[r]; ss[r] += d * d;
+          d = lo_f(v.y) - mean[r]; ss[r] += d * d; d = hi_f(v.y) - mean[r]; ss[r] += d * d;
+          d = lo_f(v.z) - mean[r]; ss[r] += d * d; d = hi_f(v.z) - mean[r]; ss[r] += d * d;
+          d = lo_f(v.w) - mean[r]; ss[r] += d * d; d = hi_f(v.w) - mean[r]; ss[r] += d * d;
         }
       }
-      const float rstd = 1.0f / sqrtf(wave_sum(ss) * invK + a.eps);
+    }
 #pragma unroll
-      for (int c = 0; c < NCH; ++c) {
-        const int k = (c * 64 + lane) * 8;
-        if (k < kw) {
-          const u32x4 g = ld16(a.ln_w + k), b = ld16(a.ln_b + k), v = xr[c][r];
+    for (int r = 0; r < R; ++r) rstd[r] = 1.0f / sqrtf(wave_sum(ss[r]) * invK + a.eps);
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int k = (c * 64 + lane) * 8;
+      if (k < kw) {
+        const u32x4 g = ld16(a.ln_w + k), b = ld16(a.ln_b + k);
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          const u32x4 v = xr[c][r];
+          const float m = mean[r], q = rstd[r];
           u32x4 o;
-          o.x = pack2((lo_f(v.x) - mean) * rstd * lo_f(g.x) + lo_f(b.x), (hi_f(v.x) - mean) * rstd * hi_f(g.x) + hi_f(b.x));
-          o.y = pack2((lo_f(v.y) - mean) * rstd * lo_f(g.y) + lo_f(b.y), (hi_f(v.y) - mean) * rstd * hi_f(g.y) + hi_f(b.y));
-          o.z = pack2((lo_f(v.z) - mean) * rstd * lo_f(g.z) + lo_f(b.z), (hi_f(v.z) - mean) * rstd * hi_f(g.z) + hi_f(b.z));
-          o.w = pack2((lo_f(v.w) - mean) * rstd * lo_f(g.w) + lo_f(b.w), (hi_f(v.w) - mean) * rstd * hi_f(g.w) + hi_f(b.w));
+          o.x = pack2((lo_f(v.x) - m) * q * lo_f(g.x) + lo_f(b.x), (hi_f(v.x) - m) * q * hi_f(g.x) + hi_f(b.x));
+          o.y = pack2((lo_f(v.y) - m) * q * lo_f(g.y) + lo_f(b.y), (hi_f(v.y) - m) * q * hi_f(g.y) + hi_f(b.y));
+          o.z = pack2((lo_f(v.z) - m) * q * lo_f(g.z) + lo_f(b.z), (hi_f(v.z) - m) * q * hi_f(g.z) + hi_f(b.z));
+          o.w = pack2((lo_f(v.w) - m) * q * lo_f(g.w) + lo_f(b.w), (hi_f(v.w) - m) * q * hi_f(g.w) + hi_f(b.w));
           xr[c][r] = o;
         }
       }
     }
   }
-  if constexpr (PRO == PRO_ATTN) {
-    // Combine the per-512-key-block partials exactly as the reference's CPU flash attention walks its KV blocks:
-    // acc = acc*exp(m_prev - m_new) + P.V ; sum likewise ; out = bf16(acc * (1/sum)).
-#pragma unroll
-    for (int c = 0; c < NCH; ++c) {
-      const int k = kbase + (c * 64 + lane) * 8;
-      if ((c * 64 + lane) * 8 < kw) {
-        const int h = k / a.hd, d0 = k % a.hd;
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-          if (r < a.nrows) {
-            const int L = a.lengths[r] + 1;
-            const int nb = (L + 511) >> 9;
-            const size_t hb = ((size_t)r * a.n_heads + h) * a.nb_cap;
-            float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-            float l = 0.f, mprev = 0.f;
-            for (int j = 0; j < nb; ++j) {
-              const float mj = a.pm[hb + j];
-              const float f = (j == 0) ? 0.f : expf(mprev - mj);
-              mprev = mj;
-              l = __fadd_rn(a.pl[hb + j], __fmul_rn(f, l));
-              const float* pa = a.pacc + (hb + j) * a.hd + d0;
-              const f32x4 p0 = *(const f32x4*)pa, p1 = *(const f32x4*)(pa + 4);
-              acc[0] = __fadd_rn(__fmul_rn(acc[0], f), p0.x); acc[1] = __fadd_rn(__fmul_rn(acc[1], f), p0.y);
-              acc[2] = __fadd_rn(__fmul_rn(acc[2], f), p0.z); acc[3] = __fadd_rn(__fmul_rn(acc[3], f), p0.w);
-              acc[4] = __fadd_rn(__fmul_rn(acc[4], f), p1.x); acc[5] = __fadd_rn(__fmul_rn(acc[5], f), p1.y);
-              acc[6] = __fadd_rn(__fmul_rn(acc[6], f), p1.z); acc[7] = __fadd_rn(__fmul_rn(acc[7], f), p1.w);
-            }
-            const float rl = 1.0f / l;
-            u32x4 o;
-            o.x = pack2(__fmul_rn(acc[0], rl), __fmul_rn(acc[1], rl)); o.y = pack2(__fmul_rn(acc[2], rl), __fmul_rn(acc[3], rl));
-            o.z = pack2(__fmul_rn(acc[4], rl), __fmul_rn(acc[5], rl)); o.w = pack2(__fmul_rn(acc[6], rl), __fmul_rn(acc[7], rl));
-            xr[c][r] = o;
-          }
-        }
-      }
-    }
-  }
 
-  // ---------------- main loop over work units
+  // ---------------- main loop over work units (next unit's weights are requested before this one is reduced)
   const int F = a.N >> 1;  // EPI_SILU: gate rows start at N/2
   for (int it = 0; it < a.upw; ++it) {
-    int u;
-    if constexpr (KSPLIT == 1) u = (blockIdx.x * 4 + wave) * a.upw + it;
-    else u = blockIdx.x * a.upw + it;
+    const int u = u0 + it;
     const bool u_ok = u < a.units;  // wave-uniform (block-uniform for KSPLIT=4)
     int rowA, rowB;
     if constexpr (EPI == EPI_SILU) { rowA = u; rowB = u + F; }
@@ -149,24 +143,14 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs a) {
     float accA[R], accB[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) { accA[r] = 0.f; accB[r] = 0.f; }
-    if (u_ok) {
-      u32x4 wa[NCH], wb[NCH];
+    WTile<NCH> cur = wt;
+    if (it + 1 < a.upw) gemv_load_unit<NCH, KSPLIT, EPI>(a, u + 1, lane, kw, kbase, wt);
 #pragma unroll
-      for (int c = 0; c < NCH; ++c) {
-        const int k = (c * 64 + lane) * 8;
-        wa[c] = u32x4{0, 0, 0, 0}; wb[c] = u32x4{0, 0, 0, 0};
-        if (k < kw) {
-          wa[c] = ld_nt16(a.W + (size_t)rowA * K + kbase + k);
-          if (b_ok) wb[c] = ld_nt16(a.W + (size_t)rowB * K + kbase + k);
-        }
-      }
+    for (int c = 0; c < NCH; ++c) {
 #pragma unroll
-      for (int c = 0; c < NCH; ++c) {
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-          accA[r] = dot8(wa[c], xr[c][r], accA[r]);
-          accB[r] = dot8(wb[c], xr[c][r], accB[r]);
-        }
+      for (int r = 0; r < R; ++r) {
+        accA[r] = dot8(cur.a[c], xr[c][r], accA[r]);
+        accB[r] = dot8(cur.b[c], xr[c][r], accB[r]);
       }
     }
 #pragma unroll
@@ -242,168 +226,151 @@ struct AttnArgs {
   const int* lengths;   // position of the newest key (already appended): L = lengths[r] + 1 keys
   const int* ext;       // optional int32 [rows]: keys the reference's block loop spans (prefill emulation)
   int ext_scalar;       // used when ext == NULL and > 0
-  int max_len, n_heads, n_heads_kv, lcap, nb_cap;
+  int max_len, n_heads, n_heads_kv;
   float scale;
-  float* scores;        // [rows][Hq][lcap]
-  float* cmax;          // [rows][Hq][lcap/128]
-  float *pacc, *pl, *pm;  // [rows][Hq][nb_cap][hd], [rows][Hq][nb_cap] x2
+  bf16_t* out;          // [rows][Hq*hd]
 };
 
+// One workgroup (16 waves) per (32-wide head-dim slice, kv head, row).  It walks the key blocks of 512 in order,
+// exactly like the reference's CPU kernel does: scores of the block (K straight to registers, dot over 8-element
+// lane slices, DPP reduce) -> LDS -> block max -> e/p -> P.V on this workgroup's 32 value columns, with the running
+// (max, sum, acc) rescaled between blocks.  No cross-workgroup state, so one launch and no partial buffers; the 4
+// slice workgroups of a head group re-read K from L2 (KV is ~3 % of the step's bytes at 10 s of context).
 template <int HD, int G>
-__global__ __launch_bounds__(256) void attn_scores_kernel(AttnArgs a) {
-  constexpr int LPP = HD / 8;      // lanes per key
-  constexpr int PPW = 64 / LPP;    // keys per wave-wide load
-  const int chunk = blockIdx.x, kvh = blockIdx.y, r = blockIdx.z;
+__global__ __launch_bounds__(1024) void attn_decode_kernel(AttnArgs a) {
+  constexpr int LPP = HD / 8;      // lanes per key in the K pass
+  constexpr int PPW = 64 / LPP;    // keys per wave-wide K load
+  constexpr int NKL = 32 / PPW;    // K loads per wave per 512-key block
+  const int slice = blockIdx.x, kvh = blockIdx.y, r = blockIdx.z;
   const int L = a.lengths[r] + 1;
-  if (chunk * 128 >= L) return;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int sub = lane % LPP, grp = lane / LPP;
+  int E = a.ext ? a.ext[r] : (a.ext_scalar > 0 ? a.ext_scalar : L);
+  if (E < L) E = L;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int sub = lane % LPP, grp = lane / LPP;      // K pass: 8-element slice, key within the load
+  const int vsub = lane & 3, vgrp = lane >> 2;       // V pass: 4 lanes cover the 32-wide slice, 16 keys per load
+  __shared__ float s_p[G][512];
+  __shared__ float s_red[16][G];
+  __shared__ float s_acc[64][G][32];   // one partial per 16-lane row of every wave
+  const size_t kvrow = (size_t)2 * a.n_heads_kv * HD;
+  const bf16_t* kbase = a.kv + (size_t)r * a.max_len * kvrow + (size_t)kvh * HD + sub * 8;
+  const bf16_t* vbase = a.kv + (size_t)r * a.max_len * kvrow + (size_t)(a.n_heads_kv + kvh) * HD + slice * 32 + vsub * 8;
   u32x4 qv[G];
 #pragma unroll
   for (int g = 0; g < G; ++g) qv[g] = ld16(a.q + ((size_t)r * a.n_heads + kvh * G + g) * HD + sub * 8);
-  float mx[G];
-#pragma unroll
-  for (int g = 0; g < G; ++g) mx[g] = -INFINITY;
-  const size_t kvrow = (size_t)2 * a.n_heads_kv * HD;
-  const bf16_t* kbase = a.kv + (size_t)r * a.max_len * kvrow + (size_t)kvh * HD + sub * 8;
-#pragma unroll
-  for (int i = 0; i < 32 / PPW; ++i) {
-    const int t = chunk * 128 + wave * 32 + i * PPW + grp;
-    const bool ok = t < L;
-    u32x4 kk = u32x4{0, 0, 0, 0};
-    if (ok) kk = ld16(kbase + (size_t)t * kvrow);
-#pragma unroll
-    for (int g = 0; g < G; ++g) {
-      float d = group_sum<LPP>(dot8(kk, qv[g], 0.f));
-      const float s = __fmul_rn(d, a.scale);
-      if (ok) {
-        mx[g] = fmaxf(mx[g], s);
-        if (sub == 0) a.scores[((size_t)r * a.n_heads + kvh * G + g) * a.lcap + t] = s;
-      }
-    }
-  }
-  __shared__ float sm[4][G];
+  float acc[G][8], lsum[G], m_run[G];
 #pragma unroll
   for (int g = 0; g < G; ++g) {
-    const float m = wave_max(mx[g]);
-    if (lane == 0) sm[wave][g] = m;
-  }
-  __syncthreads();
-  if (threadIdx.x < G) {
-    const int g = threadIdx.x;
-    a.cmax[((size_t)r * a.n_heads + kvh * G + g) * (a.lcap >> 7) + chunk] = fmaxf(fmaxf(sm[0][g], sm[1][g]), fmaxf(sm[2][g], sm[3][g]));
-  }
-}
-
-template <int HD, int G>
-__global__ __launch_bounds__(1024) void attn_pv_kernel(AttnArgs a) {
-  constexpr int LPP = HD / 8, PPW = 64 / LPP;
-  const int j = blockIdx.x, kvh = blockIdx.y, r = blockIdx.z;
-  const int L = a.lengths[r] + 1;
-  if (j * 512 >= L) return;
-  int E = a.ext ? a.ext[r] : (a.ext_scalar > 0 ? a.ext_scalar : L);
-  if (E < L) E = L;
-  const int nblk = min(512, E - j * 512);
-  const int nvec = nblk & ~15;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int sub = lane % LPP, grp = lane / LPP;
-  // running max through this block = max over the 128-key chunk maxima of blocks 0..j
-  float m[G];
-  const int nch = min(4 * (j + 1), (L + 127) >> 7);
-#pragma unroll
-  for (int g = 0; g < G; ++g) {
-    const float* cm = a.cmax + ((size_t)r * a.n_heads + kvh * G + g) * (a.lcap >> 7);
-    float v = -INFINITY;
-    for (int c = 0; c < nch; ++c) v = fmaxf(v, cm[c]);
-    m[g] = v;
-  }
-  float acc[G][8], lsum[G];
-#pragma unroll
-  for (int g = 0; g < G; ++g) {
-    lsum[g] = 0.f;
+    lsum[g] = 0.f; m_run[g] = -INFINITY;
 #pragma unroll
     for (int e = 0; e < 8; ++e) acc[g][e] = 0.f;
   }
-  const size_t kvrow = (size_t)2 * a.n_heads_kv * HD;
-  const bf16_t* vbase = a.kv + (size_t)r * a.max_len * kvrow + (size_t)(a.n_heads_kv + kvh) * HD + sub * 8;
+  const int nblocks = (L + 511) >> 9;
+  for (int j = 0; j < nblocks; ++j) {
+    const int t0 = j * 512;
+    // ---- issue this block's K and V loads together
+    u32x4 kk[NKL], vv[2];
 #pragma unroll
-  for (int i = 0; i < 32 / PPW; ++i) {
-    const int idx = wave * 32 + i * PPW + grp;  // index inside the 512-key block
-    const int t = j * 512 + idx;
-    const bool ok = t < L;
-    u32x4 vv = u32x4{0, 0, 0, 0};
-    if (ok) vv = ld16(vbase + (size_t)t * kvrow);
-    const float v0 = lo_f(vv.x), v1 = hi_f(vv.x), v2 = lo_f(vv.y), v3 = hi_f(vv.y);
-    const float v4 = lo_f(vv.z), v5 = hi_f(vv.z), v6 = lo_f(vv.w), v7 = hi_f(vv.w);
+    for (int i = 0; i < NKL; ++i) {
+      const int t = t0 + wave * 32 + i * PPW + grp;
+      kk[i] = u32x4{0, 0, 0, 0};
+      if (t < L) kk[i] = ld16(kbase + (size_t)t * kvrow);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int t = t0 + wave * 32 + i * 16 + vgrp;
+      vv[i] = u32x4{0, 0, 0, 0};
+      if (t < L) vv[i] = ld16(vbase + (size_t)t * kvrow);
+    }
+    // ---- scores -> LDS, per-wave max
+    float mx[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) mx[g] = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < NKL; ++i) {
+      const int idx = wave * 32 + i * PPW + grp;
+      const bool ok = t0 + idx < L;
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        const float s = __fmul_rn(group_sum<LPP>(dot8(kk[i], qv[g], 0.f)), a.scale);
+        if (ok) { mx[g] = fmaxf(mx[g], s); if (sub == 0) s_p[g][idx] = s; }
+      }
+    }
+#pragma unroll
+    for (int g = 0; g < G; ++g) { const float m = wave_max(mx[g]); if (lane == 0) s_red[wave][g] = m; }
+    __syncthreads();
+    // ---- running max, rescale of the running sum / accumulator (exp(m_old - m_new), libm exp like the reference)
+    float f[G], mnew[G];
 #pragma unroll
     for (int g = 0; g < G; ++g) {
-      float e = 0.f;
-      if (ok) {
-        const float x = __fsub_rn(a.scores[((size_t)r * a.n_heads + kvh * G + g) * a.lcap + t], m[g]);
-        e = (idx < nvec) ? zn_fexp_u20(x) : expf(x);
-      }
-      if (sub == 0) lsum[g] += e;
-      const float p = bfround(e);
-      acc[g][0] = fmaf(p, v0, acc[g][0]); acc[g][1] = fmaf(p, v1, acc[g][1]);
-      acc[g][2] = fmaf(p, v2, acc[g][2]); acc[g][3] = fmaf(p, v3, acc[g][3]);
-      acc[g][4] = fmaf(p, v4, acc[g][4]); acc[g][5] = fmaf(p, v5, acc[g][5]);
-      acc[g][6] = fmaf(p, v6, acc[g][6]); acc[g][7] = fmaf(p, v7, acc[g][7]);
+      float bm = s_red[0][g];
+#pragma unroll
+      for (int w = 1; w < 16; ++w) bm = fmaxf(bm, s_red[w][g]);
+      mnew[g] = fmaxf(m_run[g], bm);
+      f[g] = (j == 0) ? 0.f : expf(m_run[g] - mnew[g]);
+      m_run[g] = mnew[g];
     }
+    // ---- e = exp(s - m): fexp_u20 on the SIMD part of the block, libm exp on its tail; P = bf16(e)
+    const int nblk = min(512, E - t0), nvec = nblk & ~15;
+    float ladd[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) ladd[g] = 0.f;
+    if (tid < 512) {
+      const bool ok = t0 + tid < L;
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        float e = 0.f;
+        if (ok) { const float x = __fsub_rn(s_p[g][tid], mnew[g]); e = (tid < nvec) ? zn_fexp_u20(x) : expf(x); }
+        ladd[g] = e;
+        s_p[g][tid] = bfround(e);
+      }
+    }
+#pragma unroll
+    for (int g = 0; g < G; ++g) { const float ls = wave_sum(ladd[g]); lsum[g] = __fmul_rn(lsum[g], f[g]); if (lane == 0 && wave < 8) lsum[g] += ls; }
+    __syncthreads();
+    // ---- P.V on this workgroup's value columns (fp32 accumulate of exact bf16 x bf16 products)
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[g][e] = __fmul_rn(acc[g][e], f[g]);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int idx = wave * 32 + i * 16 + vgrp;
+      const float v0 = lo_f(vv[i].x), v1 = hi_f(vv[i].x), v2 = lo_f(vv[i].y), v3 = hi_f(vv[i].y);
+      const float v4 = lo_f(vv[i].z), v5 = hi_f(vv[i].z), v6 = lo_f(vv[i].w), v7 = hi_f(vv[i].w);
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        const float p = s_p[g][idx];
+        acc[g][0] = fmaf(p, v0, acc[g][0]); acc[g][1] = fmaf(p, v1, acc[g][1]);
+        acc[g][2] = fmaf(p, v2, acc[g][2]); acc[g][3] = fmaf(p, v3, acc[g][3]);
+        acc[g][4] = fmaf(p, v4, acc[g][4]); acc[g][5] = fmaf(p, v5, acc[g][5]);
+        acc[g][6] = fmaf(p, v6, acc[g][6]); acc[g][7] = fmaf(p, v7, acc[g][7]);
+      }
+    }
+    __syncthreads();   // s_p / s_red are rewritten by the next block
   }
-  // reduce over the PPW key groups of the wave, then over the 16 waves through LDS (fixed order: deterministic)
-  __shared__ float sacc[16][G][HD];
-  __shared__ float sl[16][G];
+  // ---- reduce: the 4 key lanes of each 16-lane row (DPP), then the 64 rows of the workgroup through LDS in a fixed
+  // order (deterministic), then 1/sum and bf16
+  const int row = lane >> 4;
 #pragma unroll
   for (int g = 0; g < G; ++g) {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      float v = acc[g][e];
+    for (int e = 0; e < 8; ++e) acc[g][e] = row_stride4_sum(acc[g][e]);
+    if ((lane & 15) < 4) {
 #pragma unroll
-      for (int o = LPP; o < 64; o <<= 1) v += __shfl_xor(v, o);
-      acc[g][e] = v;
+      for (int e = 0; e < 8; ++e) s_acc[wave * 4 + row][g][(lane & 3) * 8 + e] = acc[g][e];
     }
-    const float ls = wave_sum(lsum[g]);
-    if (lane == 0) sl[wave][g] = ls;
-    if (grp == 0) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) sacc[wave][g][sub * 8 + e] = acc[g][e];
-    }
+    if (lane == 0) s_red[wave][g] = (wave < 8) ? lsum[g] : 0.f;
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < G * HD; i += 1024) {
-    const int g = i / HD, d = i % HD;
-    float v = 0.f;
+  if (tid < G * 32) {
+    const int g = tid >> 5, d = tid & 31;
+    float v = 0.f, l = 0.f;
+#pragma unroll 8
+    for (int w = 0; w < 64; ++w) v += s_acc[w][g][d];
 #pragma unroll
-    for (int w = 0; w < 16; ++w) v += sacc[w][g][d];
-    a.pacc[(((size_t)r * a.n_heads + kvh * G + g) * a.nb_cap + j) * HD + d] = v;
-  }
-  if (threadIdx.x < G) {
-    const int g = threadIdx.x;
-    float v = 0.f;
-#pragma unroll
-    for (int w = 0; w < 16; ++w) v += sl[w][g];
-    const size_t o = ((size_t)r * a.n_heads + kvh * G + g) * a.nb_cap + j;
-    a.pl[o] = v;
-    a.pm[o] = m[g];
-  }
-}
-
-// standalone combine of the per-block partials (same math as the PRO_ATTN GEMV prologue) -> bf16 [rows][Hq*HD]
-__global__ __launch_bounds__(256) void attn_combine_kernel(AttnArgs a, bf16_t* out, int hd) {
-  const int r = blockIdx.x;
-  const int L = a.lengths[r] + 1, nb = (L + 511) >> 9;
-  for (int k = threadIdx.x; k < a.n_heads * hd; k += blockDim.x) {
-    const int h = k / hd, d = k % hd;
-    const size_t hb = ((size_t)r * a.n_heads + h) * a.nb_cap;
-    float acc = 0.f, l = 0.f, mprev = 0.f;
-    for (int j = 0; j < nb; ++j) {
-      const float mj = a.pm[hb + j];
-      const float f = (j == 0) ? 0.f : expf(mprev - mj);
-      mprev = mj;
-      l = __fadd_rn(a.pl[hb + j], __fmul_rn(f, l));
-      acc = __fadd_rn(__fmul_rn(acc, f), a.pacc[(hb + j) * hd + d]);
-    }
-    out[(size_t)r * a.n_heads * hd + k] = f2bf(__fmul_rn(acc, 1.0f / l));
+    for (int w = 0; w < 16; ++w) l += s_red[w][g];
+    a.out[((size_t)r * a.n_heads + kvh * G + g) * HD + slice * 32 + d] = f2bf(__fmul_rn(v, 1.0f / l));
   }
 }
 
