@@ -54,5 +54,23 @@ def main():
         print(f"  {name:16s} {t.value * 1e3:7.2f} us  {by.value / t.value / 1e6:7.1f} GB/s", flush=True)
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and not (len(sys.argv) > 1 and sys.argv[1] == "sweep"):
     main()
+
+
+def sweep():
+    """python tools/kbench.py sweep : GEMV grid-size sweep through zn_debug_tune + zn_bench_kernel."""
+    dev = "cuda:0"
+    model, _ = build_model(synth.FULL_CFG, 1234, dev)
+    eng = model.engine(1)
+    st = _lib.stream_ptr()
+    t, by = C.c_float(0), C.c_double(0)
+    for key, which, name in ((2, 0, "fc1"), (3, 1, "fc2"), (1, 2, "out_proj"), (4, 3, "heads")):
+        for tb in (128, 192, 256, 384, 512, 768, 1024, 1536, 2048):
+            eng.call("zn_debug_tune", key, tb)
+            eng.call("zn_bench_kernel", which, 2, 260, C.byref(t), C.byref(by), st)
+            print(f"{name:9s} target_blocks {tb:5d}: {t.value * 1e3:7.2f} us  {by.value / t.value / 1e6:7.1f} GB/s", flush=True)
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "sweep":
+    sweep()

@@ -24,6 +24,8 @@ struct zn_handle_s {
   bf16_t *x = nullptr, *q = nullptr, *o1 = nullptr, *mbuf = nullptr;
   float *logits_raw = nullptr, *last_logits = nullptr;
   int* tok_raw = nullptr;
+  float *scores = nullptr, *cmax = nullptr, *pacc = nullptr, *pl = nullptr;
+  int lcap = 0;
   GenState* st = nullptr;
   int *remaining = nullptr, *stopping = nullptr;
   int* done_host = nullptr;  // pinned
@@ -36,6 +38,7 @@ struct zn_handle_s {
   int *lengths = nullptr, *codes = nullptr;
   int force_eos_step = -1;
   float eos_bias = 0.f;
+  int tune[8] = {512, 512, 512, 1024, 256, 0, 0, 0};   // target workgroups: in_proj, out_proj, fc1, fc2, heads
   const int* tok_override = nullptr;
   int tok_override_calls = 0;
   hipStream_t cap_stream = nullptr;
@@ -76,7 +79,7 @@ static void free_graph(zn_handle h) {
 extern "C" int zn_destroy(zn_handle h) {
   if (!h) return ZN_OK;
   free_graph(h);
-  void* ptrs[] = {h->emb_tables_dev, h->x, h->q, h->o1, h->mbuf, h->logits_raw, h->last_logits, h->tok_raw, h->st, h->remaining, h->stopping};
+  void* ptrs[] = {h->emb_tables_dev, h->x, h->q, h->o1, h->mbuf, h->logits_raw, h->last_logits, h->tok_raw, h->scores, h->cmax, h->pacc, h->pl, h->st, h->remaining, h->stopping};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (h->done_host) (void)hipHostFree(h->done_host);
   if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
@@ -187,24 +190,42 @@ static int run_gemv(zn_handle h, GemvArgs a, int rows, int target_blocks, hipStr
 template <int HD>
 static int launch_attn_g(const AttnArgs& a, int G, dim3 grid, hipStream_t s) {
   switch (G) {
-    case 1: hipLaunchKernelGGL((attn_decode_kernel<HD, 1>), grid, dim3(1024), 0, s, a); return 0;
-    case 2: hipLaunchKernelGGL((attn_decode_kernel<HD, 2>), grid, dim3(1024), 0, s, a); return 0;
-    case 4: hipLaunchKernelGGL((attn_decode_kernel<HD, 4>), grid, dim3(1024), 0, s, a); return 0;
-    case 8: hipLaunchKernelGGL((attn_decode_kernel<HD, 8>), grid, dim3(1024), 0, s, a); return 0;
+#define ZN_ATTN_CASE(GG) case GG: hipLaunchKernelGGL((attn_scores_kernel<HD, GG>), grid, dim3(256), 0, s, a); \
+                                  hipLaunchKernelGGL((attn_pv_kernel<HD, GG>), grid, dim3(256), 0, s, a); return 0;
+    ZN_ATTN_CASE(1) ZN_ATTN_CASE(2) ZN_ATTN_CASE(4) ZN_ATTN_CASE(8)
+#undef ZN_ATTN_CASE
   }
   return -1;
+}
+
+static int ensure_attn_ws(zn_handle h, int max_len) {
+  const int lcap = ((max_len + 511) / 512) * 512;
+  if (lcap <= h->lcap) return ZN_OK;
+  free_graph(h);
+  for (float** p : {&h->scores, &h->cmax, &h->pacc, &h->pl}) if (*p) { (void)hipFree(*p); *p = nullptr; }
+  const size_t RH = (size_t)h->max_rows * h->cfg.n_heads;
+  const int nc = lcap / ZN_ACHUNK;
+  HIPCHK(h, hipMalloc(&h->scores, RH * lcap * sizeof(float)));
+  HIPCHK(h, hipMalloc(&h->cmax, RH * nc * sizeof(float)));
+  HIPCHK(h, hipMalloc(&h->pacc, RH * nc * h->hd * sizeof(float)));
+  HIPCHK(h, hipMalloc(&h->pl, RH * nc * sizeof(float)));
+  h->lcap = lcap;
+  return ZN_OK;
 }
 
 static int run_attention(zn_handle h, const bf16_t* q, const bf16_t* kv, int max_len, const int* lengths, const int* ext, int ext_scalar,
                          bf16_t* out, int rows, hipStream_t s) {
   const zn_config& c = h->cfg;
+  if (max_len > h->lcap || rows > h->max_rows) ZN_FAIL(h, ZN_ERR_STATE, "attention workspace too small (max_len %d rows %d)", max_len, rows);
   AttnArgs a{};
   a.q = q; a.kv = kv; a.lengths = lengths; a.ext = ext; a.ext_scalar = ext_scalar; a.max_len = max_len;
-  a.n_heads = c.n_heads; a.n_heads_kv = c.n_heads_kv; a.scale = (float)(1.0 / std::sqrt((double)h->hd)); a.out = out;
+  a.n_heads = c.n_heads; a.n_heads_kv = c.n_heads_kv; a.lcap = h->lcap; a.scale = (float)(1.0 / std::sqrt((double)h->hd));
+  a.scores = h->scores; a.cmax = h->cmax; a.pacc = h->pacc; a.pl = h->pl; a.out = out;
   const int hd = h->hd;
-  dim3 grid(hd / 32, c.n_heads_kv, rows);
+  dim3 grid((max_len + ZN_ACHUNK - 1) / ZN_ACHUNK, c.n_heads_kv, rows);
   int r2 = hd == 128 ? launch_attn_g<128>(a, h->G, grid, s) : hd == 64 ? launch_attn_g<64>(a, h->G, grid, s) : launch_attn_g<32>(a, h->G, grid, s);
   if (r2) ZN_FAIL(h, ZN_ERR_UNSUPPORTED, "attention: unsupported group %d", h->G);
+  hipLaunchKernelGGL(attn_combine_kernel, dim3(c.n_heads, rows), dim3(128), 0, s, a, hd);
   return ZN_OK;
 }
 
@@ -221,7 +242,7 @@ static int layer_decode(zn_handle h, int li, bf16_t* x, bf16_t* kv, int max_len,
     a.ln_w = (const bf16_t*)lw.norm_w; a.ln_b = (const bf16_t*)lw.norm_b; a.eps = c.norm_eps;
     a.lengths = lengths; a.hd = hd; a.n_heads = c.n_heads; a.n_heads_kv = c.n_heads_kv;
     a.q_out = h->q; a.kv = kv; a.rope = h->rope; a.max_len = max_len; a.rope_positions = c.rope_positions;
-    if ((rc = run_gemv<PRO_LN, EPI_ROPE_KV>(h, a, rows, 512, s))) return rc;
+    if ((rc = run_gemv<PRO_LN, EPI_ROPE_KV>(h, a, rows, h->tune[0], s))) return rc;
   }
   // KV-cached GQA attention over keys [0, lengths+1) (_torch.py:413-417) -> attention output in h->o1
   if ((rc = run_attention(h, h->q, kv, max_len, lengths, ext, ext_scalar, h->o1, rows, s))) return rc;
@@ -230,25 +251,25 @@ static int layer_decode(zn_handle h, int li, bf16_t* x, bf16_t* kv, int max_len,
     a.W = (const bf16_t*)lw.out_proj; a.N = d; a.K = nq; a.x = h->o1;
     if (c.double_out_proj) {
       a.out = h->q;   // q is dead after attention: reuse it for the intermediate projection
-      if ((rc = run_gemv<PRO_NONE, EPI_STORE>(h, a, rows, 512, s))) return rc;
+      if ((rc = run_gemv<PRO_NONE, EPI_STORE>(h, a, rows, h->tune[1], s))) return rc;
       GemvArgs b{};
       b.W = (const bf16_t*)lw.out_proj; b.N = d; b.K = nq; b.x = h->q; b.resid = x; b.out = x;
-      if ((rc = run_gemv<PRO_NONE, EPI_RESID>(h, b, rows, 512, s))) return rc;
+      if ((rc = run_gemv<PRO_NONE, EPI_RESID>(h, b, rows, h->tune[1], s))) return rc;
     } else {
       a.resid = x; a.out = x;
-      if ((rc = run_gemv<PRO_NONE, EPI_RESID>(h, a, rows, 512, s))) return rc;
+      if ((rc = run_gemv<PRO_NONE, EPI_RESID>(h, a, rows, h->tune[1], s))) return rc;
     }
   }
   {  // LayerNorm -> fc1 -> y * silu(gate)
     GemvArgs a{};
     a.W = (const bf16_t*)lw.fc1; a.N = 2 * c.d_ff; a.K = d; a.x = x;
     a.ln_w = (const bf16_t*)lw.norm2_w; a.ln_b = (const bf16_t*)lw.norm2_b; a.eps = c.norm_eps; a.out = h->mbuf;
-    if ((rc = run_gemv<PRO_LN, EPI_SILU>(h, a, rows, 1024, s))) return rc;
+    if ((rc = run_gemv<PRO_LN, EPI_SILU>(h, a, rows, h->tune[2], s))) return rc;
   }
   {  // fc2 -> residual
     GemvArgs a{};
     a.W = (const bf16_t*)lw.fc2; a.N = d; a.K = c.d_ff; a.x = h->mbuf; a.resid = x; a.out = x;
-    if ((rc = run_gemv<PRO_NONE, EPI_RESID>(h, a, rows, 1024, s))) return rc;
+    if ((rc = run_gemv<PRO_NONE, EPI_RESID>(h, a, rows, h->tune[3], s))) return rc;
   }
   return ZN_OK;
 }
@@ -258,7 +279,7 @@ static int heads_logits(zn_handle h, const bf16_t* x, int rows, hipStream_t s) {
   GemvArgs a{};
   a.W = (const bf16_t*)h->heads; a.N = c.n_codebooks * c.vocab_head; a.K = c.d_model; a.x = x;
   a.ln_w = (const bf16_t*)h->norm_f_w; a.ln_b = (const bf16_t*)h->norm_f_b; a.eps = c.norm_eps; a.out_f32 = h->logits_raw;
-  return run_gemv<PRO_LN, EPI_F32>(h, a, rows, 1024, s);
+  return run_gemv<PRO_LN, EPI_F32>(h, a, rows, h->tune[4], s);
 }
 
 static SampleArgs make_sample_args(zn_handle h, const zn_sampling& sp) {
@@ -309,6 +330,8 @@ extern "C" int zn_gen_begin(zn_handle h, int32_t batch, const void* const* kv_la
   if (cfg_scale == 1.0f) ZN_FAIL(h, ZN_ERR_ARG, "cfg_scale == 1 is not supported (zonos/model.py:399)");
   if (sp->repetition_penalty_window < 0 || sp->repetition_penalty_window > 64) ZN_FAIL(h, ZN_ERR_ARG, "repetition_penalty_window out of range");
   hipStream_t s = (hipStream_t)stream;
+  int rc = ensure_attn_ws(h, max_len);
+  if (rc) return rc;
   free_graph(h);
   h->batch = batch; h->rows = 2 * batch; h->max_len = max_len; h->t_total = t_total; h->offset0 = offset0; h->max_new = max_new_tokens;
   h->cfg_scale = cfg_scale; h->sp = *sp;
@@ -421,6 +444,11 @@ extern "C" int zn_debug_token_override(zn_handle h, const int32_t* tokens_dev, i
   free_graph(h);
   return ZN_OK;
 }
+extern "C" int zn_debug_tune(zn_handle h, int32_t key, int32_t value) {
+  if (!h || key < 0 || key >= 8 || value < 1) return ZN_ERR_ARG;
+  h->tune[key] = value; free_graph(h);
+  return ZN_OK;
+}
 extern "C" int zn_debug_eos_bias(zn_handle h, float bias) { if (!h) return ZN_ERR_ARG; h->eos_bias = bias; return ZN_OK; }
 
 // ------------------------------------------------------------------------------------------------ measurement
@@ -450,13 +478,13 @@ extern "C" int zn_bench_kernel(zn_handle h, int32_t which, int32_t rows, int32_t
       a.eps = c.norm_eps;
       if (which == 0) {
         a.W = (const bf16_t*)lw.fc1; a.N = 2 * c.d_ff; a.K = d; a.x = h->x; a.ln_w = (const bf16_t*)lw.norm2_w; a.ln_b = (const bf16_t*)lw.norm2_b; a.out = h->mbuf;
-        rc = run_gemv<PRO_LN, EPI_SILU>(h, a, rows, 1024, s);
+        rc = run_gemv<PRO_LN, EPI_SILU>(h, a, rows, h->tune[2], s);
       } else if (which == 1) {
         a.W = (const bf16_t*)lw.fc2; a.N = d; a.K = c.d_ff; a.x = h->mbuf; a.resid = h->x; a.out = h->x;
-        rc = run_gemv<PRO_NONE, EPI_RESID>(h, a, rows, 1024, s);
+        rc = run_gemv<PRO_NONE, EPI_RESID>(h, a, rows, h->tune[3], s);
       } else if (which == 2) {
         a.W = (const bf16_t*)lw.out_proj; a.N = d; a.K = c.n_heads * h->hd; a.x = h->o1; a.resid = h->x; a.out = h->x;
-        rc = run_gemv<PRO_NONE, EPI_RESID>(h, a, rows, 512, s);
+        rc = run_gemv<PRO_NONE, EPI_RESID>(h, a, rows, h->tune[1], s);
       } else {
         rc = heads_logits(h, h->x, rows, s);
       }
@@ -507,7 +535,9 @@ extern "C" int zn_op_layer_decode(zn_handle h, int32_t layer, void* x, void* kv,
   if (!h) return ZN_ERR_ARG;
   if (!x || !kv || !lengths || layer < 0 || layer >= h->cfg.n_layer || rows < 1 || rows > h->max_rows || max_len < 1)
     ZN_FAIL(h, ZN_ERR_ARG, "zn_op_layer_decode: bad argument");
-  int rc = layer_decode(h, layer, (bf16_t*)x, (bf16_t*)kv, max_len, lengths, ext, 0, rows, (hipStream_t)stream);
+  int rc = ensure_attn_ws(h, max_len);
+  if (rc) return rc;
+  rc = layer_decode(h, layer, (bf16_t*)x, (bf16_t*)kv, max_len, lengths, ext, 0, rows, (hipStream_t)stream);
   if (rc) return rc;
   HIPCHK(h, hipGetLastError());
   return ZN_OK;
@@ -517,7 +547,10 @@ extern "C" int zn_op_attn_decode(zn_handle h, const void* q, const void* kv, int
                                  void* out, int32_t rows, zn_stream stream) {
   if (!h) return ZN_ERR_ARG;
   if (!q || !kv || !lengths || !out || rows < 1 || max_len < 1) ZN_FAIL(h, ZN_ERR_ARG, "zn_op_attn_decode: bad argument");
-  int rc = run_attention(h, (const bf16_t*)q, (const bf16_t*)kv, max_len, lengths, ext, 0, (bf16_t*)out, rows, (hipStream_t)stream);
+  if (rows > h->max_rows) ZN_FAIL(h, ZN_ERR_ARG, "zn_op_attn_decode: rows > max_rows");
+  int rc = ensure_attn_ws(h, max_len);
+  if (rc) return rc;
+  rc = run_attention(h, (const bf16_t*)q, (const bf16_t*)kv, max_len, lengths, ext, 0, (bf16_t*)out, rows, (hipStream_t)stream);
   if (rc) return rc;
   HIPCHK(h, hipGetLastError());
   return ZN_OK;

@@ -32,10 +32,14 @@ struct GemvArgs {
 };
 
 // Weight tile of one work unit (two weight rows) held in registers.
-template <int NCH> struct WTile { u32x4 a[NCH], b[NCH]; };
+template <int NCH> struct WTile {
+  u32x4 a[NCH], b[NCH];
+  unsigned resid;   // EPI_RESID: this lane's (row = lane) residual pair, requested with the weights so that the
+  float cs, sn;     // EPI_ROPE_KV: cos/sin      epilogue never has to wait behind the next unit's prefetch
+};
 
 template <int NCH, int KSPLIT, int EPI>
-ZN_DEVINL void gemv_load_unit(const GemvArgs& a, int u, int lane, int kw, int kbase, WTile<NCH>& t) {
+ZN_DEVINL void gemv_load_unit(const GemvArgs& a, int u, int lane, int kw, int kbase, int pos, WTile<NCH>& t) {
   const int F = a.N >> 1;
   const bool u_ok = u < a.units;
   int rowA, rowB;
@@ -51,6 +55,22 @@ ZN_DEVINL void gemv_load_unit(const GemvArgs& a, int u, int lane, int kw, int kb
       if (b_ok) t.b[c] = ld_nt16(a.W + (size_t)rowB * a.K + kbase + k);
     }
   }
+  t.resid = 0; t.cs = 1.f; t.sn = 0.f;
+  if (u_ok && lane < a.nrows) {
+    if constexpr (EPI == EPI_RESID) {
+      const size_t o = (size_t)lane * a.N + rowA;
+      t.resid = b_ok ? *(const unsigned*)(a.resid + o) : (unsigned)a.resid[o];
+    }
+    if constexpr (EPI == EPI_ROPE_KV) {
+      const int hd = a.hd;
+      if (rowA < (a.n_heads + a.n_heads_kv) * hd) {
+        const int i = (rowA % hd) >> 1;
+        const int p = pos < a.rope_positions ? pos : a.rope_positions - 1;
+        const float2 c2 = *(const float2*)(a.rope + ((size_t)p * (hd >> 1) + i) * 2);
+        t.cs = c2.x; t.sn = c2.y;
+      }
+    }
+  }
 }
 
 template <int R, int NCH, int KSPLIT, int PRO, int EPI>
@@ -63,9 +83,11 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs a) {
   __shared__ float red[4][2][R];
   const int u0 = (KSPLIT == 1) ? (blockIdx.x * 4 + wave) * a.upw : blockIdx.x * a.upw;
 
+  int pos = 0;
+  if constexpr (EPI == EPI_ROPE_KV) { if (lane < a.nrows) pos = a.lengths[lane]; }
   // the first unit's weights do not depend on the activations: get them in flight before the prologue
   WTile<NCH> wt;
-  gemv_load_unit<NCH, KSPLIT, EPI>(a, u0, lane, kw, kbase, wt);
+  gemv_load_unit<NCH, KSPLIT, EPI>(a, u0, lane, kw, kbase, pos, wt);
 
   // ---------------- prologue: this lane's slices of the activation rows, packed bf16 in registers
   u32x4 xr[NCH][R];
@@ -144,7 +166,7 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs a) {
 #pragma unroll
     for (int r = 0; r < R; ++r) { accA[r] = 0.f; accB[r] = 0.f; }
     WTile<NCH> cur = wt;
-    if (it + 1 < a.upw) gemv_load_unit<NCH, KSPLIT, EPI>(a, u + 1, lane, kw, kbase, wt);
+    if (it + 1 < a.upw) gemv_load_unit<NCH, KSPLIT, EPI>(a, u + 1, lane, kw, kbase, pos, wt);
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
 #pragma unroll
@@ -185,10 +207,9 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs a) {
     } else if constexpr (EPI == EPI_RESID) {
       // x + linear(...) with both operands bf16 (_torch.py:326-327)
       const size_t o = (size_t)r * a.N + rowA;
-      if (b_ok) {
-        const unsigned rs = *(const unsigned*)(a.resid + o);
-        *(unsigned*)(a.out + o) = pack2(lo_f(rs) + bfround(vA), hi_f(rs) + bfround(vB));
-      } else a.out[o] = f2bf(bf2f(a.resid[o]) + bfround(vA));
+      const unsigned rs = cur.resid;
+      if (b_ok) *(unsigned*)(a.out + o) = pack2(lo_f(rs) + bfround(vA), hi_f(rs) + bfround(vB));
+      else a.out[o] = f2bf(lo_f(rs) + bfround(vA));
     } else if constexpr (EPI == EPI_SILU) {
       // y * silu(gate), fc1(x).chunk(2) (_torch.py:473-474): bf16 roundings after fc1, silu and mul
       const float y = bfround(vA), g = bfround(vB);
@@ -198,11 +219,8 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs a) {
       // split q|k|v (_torch.py:399-405), interleaved-pair RoPE in fp32 (_torch.py:57-68), KV append (:105-106)
       const int hd = a.hd, nq = a.n_heads * hd, nk = a.n_heads_kv * hd;
       const float x0 = bfround(vA), x1 = bfround(vB);
-      const int pos = a.lengths[r];
       if (rowA < nq + nk) {
-        const int i = (rowA % hd) >> 1;
-        const int p = pos < a.rope_positions ? pos : a.rope_positions - 1;
-        const float cs = a.rope[((size_t)p * (hd >> 1) + i) * 2], sn = a.rope[((size_t)p * (hd >> 1) + i) * 2 + 1];
+        const float cs = cur.cs, sn = cur.sn;
         const float re = __fsub_rn(__fmul_rn(x0, cs), __fmul_rn(x1, sn));
         const float im = __fadd_rn(__fmul_rn(x1, cs), __fmul_rn(x0, sn));
         if (rowA < nq) *(unsigned*)(a.q_out + (size_t)r * nq + rowA) = pack2(re, im);
@@ -226,151 +244,173 @@ struct AttnArgs {
   const int* lengths;   // position of the newest key (already appended): L = lengths[r] + 1 keys
   const int* ext;       // optional int32 [rows]: keys the reference's block loop spans (prefill emulation)
   int ext_scalar;       // used when ext == NULL and > 0
-  int max_len, n_heads, n_heads_kv;
+  int max_len, n_heads, n_heads_kv, lcap;   // lcap = scores row stride (multiple of 512)
   float scale;
+  float* scores;        // [rows][Hq][lcap]
+  float* cmax;          // [rows][Hq][lcap/64]   per-64-key-chunk maxima
+  float* pacc;          // [rows][Hq][lcap/64][hd] per-chunk P.V partials
+  float* pl;            // [rows][Hq][lcap/64]     per-chunk sums of e
   bf16_t* out;          // [rows][Hq*hd]
 };
+#define ZN_ACHUNK 64
 
-// One workgroup (16 waves) per (32-wide head-dim slice, kv head, row).  It walks the key blocks of 512 in order,
-// exactly like the reference's CPU kernel does: scores of the block (K straight to registers, dot over 8-element
-// lane slices, DPP reduce) -> LDS -> block max -> e/p -> P.V on this workgroup's 32 value columns, with the running
-// (max, sum, acc) rescaled between blocks.  No cross-workgroup state, so one launch and no partial buffers; the 4
-// slice workgroups of a head group re-read K from L2 (KV is ~3 % of the step's bytes at 10 s of context).
+// A single CU sustains only a few tens of GB/s, so the KV read of a (row, kv-head) pair is spread over one workgroup
+// per 64-key chunk (grid = chunks x Hkv x rows, ~112 workgroups at 10 s of context).  Pass 1: scores + chunk maxima.
 template <int HD, int G>
-__global__ __launch_bounds__(1024) void attn_decode_kernel(AttnArgs a) {
-  constexpr int LPP = HD / 8;      // lanes per key in the K pass
-  constexpr int PPW = 64 / LPP;    // keys per wave-wide K load
-  constexpr int NKL = 32 / PPW;    // K loads per wave per 512-key block
-  const int slice = blockIdx.x, kvh = blockIdx.y, r = blockIdx.z;
+__global__ __launch_bounds__(256) void attn_scores_kernel(AttnArgs a) {
+  constexpr int LPP = HD / 8;      // lanes per key
+  constexpr int PPW = 64 / LPP;    // keys per wave-wide load
+  constexpr int NKL = 16 / PPW;    // loads per wave (16 keys per wave)
+  const int chunk = blockIdx.x, kvh = blockIdx.y, r = blockIdx.z;
   const int L = a.lengths[r] + 1;
-  int E = a.ext ? a.ext[r] : (a.ext_scalar > 0 ? a.ext_scalar : L);
-  if (E < L) E = L;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int sub = lane % LPP, grp = lane / LPP;      // K pass: 8-element slice, key within the load
-  const int vsub = lane & 3, vgrp = lane >> 2;       // V pass: 4 lanes cover the 32-wide slice, 16 keys per load
-  __shared__ float s_p[G][512];
-  __shared__ float s_red[16][G];
-  __shared__ float s_acc[64][G][32];   // one partial per 16-lane row of every wave
+  if (chunk * ZN_ACHUNK >= L) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int sub = lane % LPP, grp = lane / LPP;
   const size_t kvrow = (size_t)2 * a.n_heads_kv * HD;
   const bf16_t* kbase = a.kv + (size_t)r * a.max_len * kvrow + (size_t)kvh * HD + sub * 8;
-  const bf16_t* vbase = a.kv + (size_t)r * a.max_len * kvrow + (size_t)(a.n_heads_kv + kvh) * HD + slice * 32 + vsub * 8;
+  u32x4 kk[NKL];
+#pragma unroll
+  for (int i = 0; i < NKL; ++i) {
+    const int t = chunk * ZN_ACHUNK + wave * 16 + i * PPW + grp;
+    kk[i] = u32x4{0, 0, 0, 0};
+    if (t < L) kk[i] = ld16(kbase + (size_t)t * kvrow);
+  }
   u32x4 qv[G];
 #pragma unroll
   for (int g = 0; g < G; ++g) qv[g] = ld16(a.q + ((size_t)r * a.n_heads + kvh * G + g) * HD + sub * 8);
-  float acc[G][8], lsum[G], m_run[G];
+  float mx[G];
+#pragma unroll
+  for (int g = 0; g < G; ++g) mx[g] = -INFINITY;
+#pragma unroll
+  for (int i = 0; i < NKL; ++i) {
+    const int t = chunk * ZN_ACHUNK + wave * 16 + i * PPW + grp;
+    const bool ok = t < L;
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      const float s = __fmul_rn(group_sum<LPP>(dot8(kk[i], qv[g], 0.f)), a.scale);
+      if (ok) {
+        mx[g] = fmaxf(mx[g], s);
+        if (sub == 0) a.scores[((size_t)r * a.n_heads + kvh * G + g) * a.lcap + t] = s;
+      }
+    }
+  }
+  __shared__ float sm[4][G];
+#pragma unroll
+  for (int g = 0; g < G; ++g) { const float m = wave_max(mx[g]); if (lane == 0) sm[wave][g] = m; }
+  __syncthreads();
+  if (threadIdx.x < G) {
+    const int g = threadIdx.x;
+    a.cmax[((size_t)r * a.n_heads + kvh * G + g) * (a.lcap / ZN_ACHUNK) + chunk] = fmaxf(fmaxf(sm[0][g], sm[1][g]), fmaxf(sm[2][g], sm[3][g]));
+  }
+}
+
+// Pass 2: e/p with the reference's rounding (running max through the END of the chunk's 512-key block = max over the
+// chunk maxima of blocks 0..j), P.V partial and partial sum of the chunk.
+template <int HD, int G>
+__global__ __launch_bounds__(256) void attn_pv_kernel(AttnArgs a) {
+  constexpr int LPP = HD / 8, PPW = 64 / LPP, NVL = 16 / PPW;
+  const int chunk = blockIdx.x, kvh = blockIdx.y, r = blockIdx.z;
+  const int L = a.lengths[r] + 1;
+  if (chunk * ZN_ACHUNK >= L) return;
+  int E = a.ext ? a.ext[r] : (a.ext_scalar > 0 ? a.ext_scalar : L);
+  if (E < L) E = L;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int sub = lane % LPP, grp = lane / LPP;
+  const size_t kvrow = (size_t)2 * a.n_heads_kv * HD;
+  const bf16_t* vbase = a.kv + (size_t)r * a.max_len * kvrow + (size_t)(a.n_heads_kv + kvh) * HD + sub * 8;
+  u32x4 vv[NVL];
+  float sc[NVL][G];
+#pragma unroll
+  for (int i = 0; i < NVL; ++i) {
+    const int t = chunk * ZN_ACHUNK + wave * 16 + i * PPW + grp;
+    vv[i] = u32x4{0, 0, 0, 0};
+    if (t < L) vv[i] = ld16(vbase + (size_t)t * kvrow);
+#pragma unroll
+    for (int g = 0; g < G; ++g) sc[i][g] = (t < L) ? a.scores[((size_t)r * a.n_heads + kvh * G + g) * a.lcap + t] : 0.f;
+  }
+  const int j = (chunk * ZN_ACHUNK) >> 9;                       // 512-key block of this chunk
+  const int t0 = j * 512;
+  const int nch = min(8 * (j + 1), (L + ZN_ACHUNK - 1) / ZN_ACHUNK);
+  float m[G];
 #pragma unroll
   for (int g = 0; g < G; ++g) {
-    lsum[g] = 0.f; m_run[g] = -INFINITY;
+    const float* cm = a.cmax + ((size_t)r * a.n_heads + kvh * G + g) * (a.lcap / ZN_ACHUNK);
+    float v = -INFINITY;
+    for (int c = lane; c < nch; c += 64) v = fmaxf(v, cm[c]);
+    m[g] = wave_max(v);
+  }
+  const int nblk = min(512, E - t0), nvec = nblk & ~15;
+  float acc[G][8], lsum[G];
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    lsum[g] = 0.f;
 #pragma unroll
     for (int e = 0; e < 8; ++e) acc[g][e] = 0.f;
   }
-  const int nblocks = (L + 511) >> 9;
-  for (int j = 0; j < nblocks; ++j) {
-    const int t0 = j * 512;
-    // ---- issue this block's K and V loads together
-    u32x4 kk[NKL], vv[2];
 #pragma unroll
-    for (int i = 0; i < NKL; ++i) {
-      const int t = t0 + wave * 32 + i * PPW + grp;
-      kk[i] = u32x4{0, 0, 0, 0};
-      if (t < L) kk[i] = ld16(kbase + (size_t)t * kvrow);
-    }
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int t = t0 + wave * 32 + i * 16 + vgrp;
-      vv[i] = u32x4{0, 0, 0, 0};
-      if (t < L) vv[i] = ld16(vbase + (size_t)t * kvrow);
-    }
-    // ---- scores -> LDS, per-wave max
-    float mx[G];
-#pragma unroll
-    for (int g = 0; g < G; ++g) mx[g] = -INFINITY;
-#pragma unroll
-    for (int i = 0; i < NKL; ++i) {
-      const int idx = wave * 32 + i * PPW + grp;
-      const bool ok = t0 + idx < L;
-#pragma unroll
-      for (int g = 0; g < G; ++g) {
-        const float s = __fmul_rn(group_sum<LPP>(dot8(kk[i], qv[g], 0.f)), a.scale);
-        if (ok) { mx[g] = fmaxf(mx[g], s); if (sub == 0) s_p[g][idx] = s; }
-      }
-    }
-#pragma unroll
-    for (int g = 0; g < G; ++g) { const float m = wave_max(mx[g]); if (lane == 0) s_red[wave][g] = m; }
-    __syncthreads();
-    // ---- running max, rescale of the running sum / accumulator (exp(m_old - m_new), libm exp like the reference)
-    float f[G], mnew[G];
+  for (int i = 0; i < NVL; ++i) {
+    const int t = chunk * ZN_ACHUNK + wave * 16 + i * PPW + grp;
+    const int idx = t - t0;
+    const bool ok = t < L;
+    const float v0 = lo_f(vv[i].x), v1 = hi_f(vv[i].x), v2 = lo_f(vv[i].y), v3 = hi_f(vv[i].y);
+    const float v4 = lo_f(vv[i].z), v5 = hi_f(vv[i].z), v6 = lo_f(vv[i].w), v7 = hi_f(vv[i].w);
 #pragma unroll
     for (int g = 0; g < G; ++g) {
-      float bm = s_red[0][g];
-#pragma unroll
-      for (int w = 1; w < 16; ++w) bm = fmaxf(bm, s_red[w][g]);
-      mnew[g] = fmaxf(m_run[g], bm);
-      f[g] = (j == 0) ? 0.f : expf(m_run[g] - mnew[g]);
-      m_run[g] = mnew[g];
+      float e = 0.f;
+      if (ok) { const float x = __fsub_rn(sc[i][g], m[g]); e = (idx < nvec) ? zn_fexp_u20(x) : expf(x); }
+      if (sub == 0) lsum[g] += e;
+      const float p = bfround(e);
+      acc[g][0] = fmaf(p, v0, acc[g][0]); acc[g][1] = fmaf(p, v1, acc[g][1]);
+      acc[g][2] = fmaf(p, v2, acc[g][2]); acc[g][3] = fmaf(p, v3, acc[g][3]);
+      acc[g][4] = fmaf(p, v4, acc[g][4]); acc[g][5] = fmaf(p, v5, acc[g][5]);
+      acc[g][6] = fmaf(p, v6, acc[g][6]); acc[g][7] = fmaf(p, v7, acc[g][7]);
     }
-    // ---- e = exp(s - m): fexp_u20 on the SIMD part of the block, libm exp on its tail; P = bf16(e)
-    const int nblk = min(512, E - t0), nvec = nblk & ~15;
-    float ladd[G];
-#pragma unroll
-    for (int g = 0; g < G; ++g) ladd[g] = 0.f;
-    if (tid < 512) {
-      const bool ok = t0 + tid < L;
-#pragma unroll
-      for (int g = 0; g < G; ++g) {
-        float e = 0.f;
-        if (ok) { const float x = __fsub_rn(s_p[g][tid], mnew[g]); e = (tid < nvec) ? zn_fexp_u20(x) : expf(x); }
-        ladd[g] = e;
-        s_p[g][tid] = bfround(e);
-      }
-    }
-#pragma unroll
-    for (int g = 0; g < G; ++g) { const float ls = wave_sum(ladd[g]); lsum[g] = __fmul_rn(lsum[g], f[g]); if (lane == 0 && wave < 8) lsum[g] += ls; }
-    __syncthreads();
-    // ---- P.V on this workgroup's value columns (fp32 accumulate of exact bf16 x bf16 products)
-#pragma unroll
-    for (int g = 0; g < G; ++g) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) acc[g][e] = __fmul_rn(acc[g][e], f[g]);
-    }
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int idx = wave * 32 + i * 16 + vgrp;
-      const float v0 = lo_f(vv[i].x), v1 = hi_f(vv[i].x), v2 = lo_f(vv[i].y), v3 = hi_f(vv[i].y);
-      const float v4 = lo_f(vv[i].z), v5 = hi_f(vv[i].z), v6 = lo_f(vv[i].w), v7 = hi_f(vv[i].w);
-#pragma unroll
-      for (int g = 0; g < G; ++g) {
-        const float p = s_p[g][idx];
-        acc[g][0] = fmaf(p, v0, acc[g][0]); acc[g][1] = fmaf(p, v1, acc[g][1]);
-        acc[g][2] = fmaf(p, v2, acc[g][2]); acc[g][3] = fmaf(p, v3, acc[g][3]);
-        acc[g][4] = fmaf(p, v4, acc[g][4]); acc[g][5] = fmaf(p, v5, acc[g][5]);
-        acc[g][6] = fmaf(p, v6, acc[g][6]); acc[g][7] = fmaf(p, v7, acc[g][7]);
-      }
-    }
-    __syncthreads();   // s_p / s_red are rewritten by the next block
   }
-  // ---- reduce: the 4 key lanes of each 16-lane row (DPP), then the 64 rows of the workgroup through LDS in a fixed
-  // order (deterministic), then 1/sum and bf16
-  const int row = lane >> 4;
+  // every (wave, key-group) pair writes its partial to LDS; fixed-order sum (deterministic)
+  constexpr int NP = 4 * PPW;
+  __shared__ float sacc[NP][G][HD];
+  __shared__ float sl[4][G];
 #pragma unroll
   for (int g = 0; g < G; ++g) {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) acc[g][e] = row_stride4_sum(acc[g][e]);
-    if ((lane & 15) < 4) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) s_acc[wave * 4 + row][g][(lane & 3) * 8 + e] = acc[g][e];
-    }
-    if (lane == 0) s_red[wave][g] = (wave < 8) ? lsum[g] : 0.f;
+    for (int e = 0; e < 8; ++e) sacc[wave * PPW + grp][g][sub * 8 + e] = acc[g][e];
+    const float ls = wave_sum(lsum[g]);
+    if (lane == 0) sl[wave][g] = ls;
   }
   __syncthreads();
-  if (tid < G * 32) {
-    const int g = tid >> 5, d = tid & 31;
-    float v = 0.f, l = 0.f;
-#pragma unroll 8
-    for (int w = 0; w < 64; ++w) v += s_acc[w][g][d];
+  for (int i = threadIdx.x; i < G * HD; i += 256) {
+    const int g = i / HD, d = i % HD;
+    float v = 0.f;
 #pragma unroll
-    for (int w = 0; w < 16; ++w) l += s_red[w][g];
-    a.out[((size_t)r * a.n_heads + kvh * G + g) * HD + slice * 32 + d] = f2bf(__fmul_rn(v, 1.0f / l));
+    for (int w = 0; w < NP; ++w) v += sacc[w][g][d];
+    a.pacc[(((size_t)r * a.n_heads + kvh * G + g) * (a.lcap / ZN_ACHUNK) + chunk) * HD + d] = v;
+  }
+  if (threadIdx.x < G) {
+    const int g = threadIdx.x;
+    a.pl[((size_t)r * a.n_heads + kvh * G + g) * (a.lcap / ZN_ACHUNK) + chunk] = (sl[0][g] + sl[1][g]) + (sl[2][g] + sl[3][g]);
+  }
+}
+
+// Pass 3: per (row, head): block sums in chunk order, then the reference's sequential walk over its 512-key blocks
+// (acc = acc*exp(m_prev - m_new) + P.V, sum likewise), out = bf16(acc * (1/sum)).
+__global__ __launch_bounds__(128) void attn_combine_kernel(AttnArgs a, int hd) {
+  const int h = blockIdx.x, r = blockIdx.y;
+  const int L = a.lengths[r] + 1;
+  const int nchunks = (L + ZN_ACHUNK - 1) / ZN_ACHUNK, nb = (L + 511) >> 9;
+  const int cstride = a.lcap / ZN_ACHUNK;
+  const size_t hb = ((size_t)r * a.n_heads + h) * cstride;
+  for (int d = threadIdx.x; d < hd; d += blockDim.x) {
+    float acc = 0.f, l = 0.f, mrun = -INFINITY;
+    for (int j = 0; j < nb; ++j) {
+      const int c0 = j * 8, c1 = min(c0 + 8, nchunks);
+      float pv = 0.f, ls = 0.f, mj = mrun;
+      for (int c = c0; c < c1; ++c) { pv += a.pacc[(hb + c) * hd + d]; ls += a.pl[hb + c]; mj = fmaxf(mj, a.cmax[hb + c]); }
+      const float f = (j == 0) ? 0.f : expf(mrun - mj);
+      mrun = mj;
+      l = __fadd_rn(ls, __fmul_rn(f, l));
+      acc = __fadd_rn(__fmul_rn(acc, f), pv);
+    }
+    a.out[((size_t)r * a.n_heads + h) * hd + d] = f2bf(__fmul_rn(acc, 1.0f / l));
   }
 }
 
