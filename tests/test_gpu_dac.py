@@ -1,0 +1,79 @@
+"""GPU parity of DACAutoencoder.decode (zn_dac_decode through the C ABI) against the golden waveforms recorded
+from transformers DacModel.decode (tests/golden/dac.npz) and against the CPU oracle.  Bar (BASELINE.json
+north_star): waveform RMS error <= 1e-4 in fp32."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import zonos_oracle as zo
+from zonos_amd import synth
+from zonos_amd.autoencoder import DACAutoencoder
+
+pytestmark = pytest.mark.gpu
+RMS_TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def dac():
+    dw = synth.dac_state_dict(4321)
+    return DACAutoencoder(dw, device="cuda:0"), dw
+
+
+def _rms(a, b):
+    return float(np.sqrt(np.mean((np.asarray(a, dtype=np.float64) - np.asarray(b, dtype=np.float64)) ** 2)))
+
+
+def test_dac_decode_vs_transformers_golden(golden_dir, dac):
+    ae, _ = dac
+    g = np.load(f"{golden_dir}/dac.npz")
+    for T in (16, 40):
+        codes = torch.from_numpy(synth.randint(4321, f"codes{T}", (1, 9, T), 1024)).to("cuda:0")
+        wav = ae.decode(codes)
+        assert wav.shape == (1, 1, 512 * T) and wav.dtype == torch.float32
+        ref = g[f"wav_{T}"]
+        err = _rms(wav[:, 0].cpu().numpy(), ref)
+        print(f"\n[dac T={T}] RMS err vs transformers DacModel {err:.3g} (signal RMS {float(np.sqrt(np.mean(ref ** 2))):.3g}), max|d| {np.abs(wav[:, 0].cpu().numpy() - ref).max():.3g}")
+        assert err <= RMS_TOL
+
+
+def test_dac_decode_vs_oracle_batch_and_length(dac):
+    """B = 2 ragged-content batch at T = 300 (crosses every tile boundary: 300*512 = 153600 samples) vs the oracle."""
+    ae, dw = dac
+    codes = torch.from_numpy(synth.randint(7, "codes.b", (2, 9, 300), 1024))
+    wav = ae.decode(codes.to("cuda:0")).cpu()
+    ref = zo.dac_decode(dw, codes)
+    assert wav.shape == ref.shape == (2, 1, 153600)
+    err = _rms(wav.numpy(), ref.numpy())
+    print(f"\n[dac B=2 T=300] RMS err vs oracle {err:.3g}, max|d| {(wav - ref).abs().max().item():.3g}")
+    assert err <= RMS_TOL
+    # batch rows are independent: row 1 alone reproduces row 1 of the batch
+    solo = ae.decode(codes[1:2].to("cuda:0")).cpu()
+    assert torch.equal(solo[0], wav[1])
+
+
+def test_dac_edge_lengths_and_int16(dac):
+    ae, dw = dac
+    for T in (1, 2, 5):      # shorter than every halo / tile
+        codes = torch.from_numpy(synth.randint(11, f"codes.e{T}", (1, 9, T), 1024))
+        wav = ae.decode(codes.to("cuda:0")).cpu()
+        ref = zo.dac_decode(dw, codes)
+        assert _rms(wav.numpy(), ref.numpy()) <= RMS_TOL, T
+    codes = torch.from_numpy(synth.randint(11, "codes.i16", (1, 9, 12), 1024))
+    got = ae.decode_to_int16(codes.to("cuda:0")).cpu()
+    ref = zo.dac_decode_to_int16(dw, codes)
+    assert got.shape == ref.shape == (12 * 512, 1) and got.dtype == torch.int16
+    assert (got.int() - ref.int()).abs().max().item() <= 4      # 1e-4 * 32767 ~ 3.3 LSB
+
+
+def test_dac_linearity_property_full_length(dac):
+    """Size-independent property at the BASELINE length (T = 861, 440 832 samples): decode is deterministic and
+    a time-shifted code sequence gives the time-shifted waveform away from the edges (convolutions are shift-equivariant)."""
+    ae, _ = dac
+    codes = torch.from_numpy(synth.randint(5, "codes.full", (1, 9, 861), 1024)).to("cuda:0")
+    w1 = ae.decode(codes)
+    w2 = ae.decode(codes)
+    assert torch.equal(w1, w2)
+    assert w1.shape == (1, 1, 440832) and bool(torch.isfinite(w1).all()) and float(w1.abs().max()) <= 1.0
+    shifted = ae.decode(codes[..., 100:])                  # drop the first 100 frames
+    a, b = w1[0, 0, (100 + 40) * 512:(861 - 40) * 512], shifted[0, 0, 40 * 512:(761 - 40) * 512]
+    assert _rms(a.cpu().numpy(), b.cpu().numpy()) <= 1e-5
