@@ -24,7 +24,7 @@ struct zn_handle_s {
   bf16_t *x = nullptr, *q = nullptr, *o1 = nullptr, *mbuf = nullptr;
   float *logits_raw = nullptr, *last_logits = nullptr;
   int* tok_raw = nullptr;
-  float *scores = nullptr, *cmax = nullptr, *pacc = nullptr, *pl = nullptr;
+  float *scores = nullptr, *cmax = nullptr;
   int lcap = 0;
   GenState* st = nullptr;
   int *remaining = nullptr, *stopping = nullptr;
@@ -79,7 +79,7 @@ static void free_graph(zn_handle h) {
 extern "C" int zn_destroy(zn_handle h) {
   if (!h) return ZN_OK;
   free_graph(h);
-  void* ptrs[] = {h->emb_tables_dev, h->x, h->q, h->o1, h->mbuf, h->logits_raw, h->last_logits, h->tok_raw, h->scores, h->cmax, h->pacc, h->pl, h->st, h->remaining, h->stopping};
+  void* ptrs[] = {h->emb_tables_dev, h->x, h->q, h->o1, h->mbuf, h->logits_raw, h->last_logits, h->tok_raw, h->scores, h->cmax, h->st, h->remaining, h->stopping};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (h->done_host) (void)hipHostFree(h->done_host);
   if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
@@ -128,28 +128,29 @@ extern "C" int zn_create(const zn_config* cfg, const zn_weights* w, int32_t max_
 
 // ------------------------------------------------------------------------------------------------ launches
 template <int R, int NCH, int KS, int PRO, int EPI>
-static void launch_gemv_t(const GemvArgs& a, int blocks, hipStream_t s) {
-  hipLaunchKernelGGL((gemv_kernel<R, NCH, KS, PRO, EPI>), dim3(blocks), dim3(256), 0, s, a);
+static void launch_gemv_t(const GemvArgs& a, int blocks, bool full, hipStream_t s) {
+  if (full) hipLaunchKernelGGL((gemv_kernel<R, NCH, KS, PRO, EPI, true>), dim3(blocks), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((gemv_kernel<R, NCH, KS, PRO, EPI, false>), dim3(blocks), dim3(256), 0, s, a);
 }
 template <int R, int KS, int PRO, int EPI>
-static int launch_gemv_nch(const GemvArgs& a, int nch, int blocks, hipStream_t s) {
+static int launch_gemv_nch(const GemvArgs& a, int nch, int blocks, bool full, hipStream_t s) {
   switch (nch) {
-    case 1: launch_gemv_t<R, 1, KS, PRO, EPI>(a, blocks, s); return 0;
-    case 2: launch_gemv_t<R, 2, KS, PRO, EPI>(a, blocks, s); return 0;
-    case 4: launch_gemv_t<R, 4, KS, PRO, EPI>(a, blocks, s); return 0;
-    case 8: launch_gemv_t<R, 8, KS, PRO, EPI>(a, blocks, s); return 0;
+    case 1: launch_gemv_t<R, 1, KS, PRO, EPI>(a, blocks, full, s); return 0;
+    case 2: launch_gemv_t<R, 2, KS, PRO, EPI>(a, blocks, full, s); return 0;
+    case 4: launch_gemv_t<R, 4, KS, PRO, EPI>(a, blocks, full, s); return 0;
+    case 8: launch_gemv_t<R, 8, KS, PRO, EPI>(a, blocks, full, s); return 0;
   }
   return -1;
 }
 template <int PRO, int EPI>
-static int launch_gemv_rows(const GemvArgs& a, int rgroup, int ks, int nch, int blocks, hipStream_t s) {
+static int launch_gemv_rows(const GemvArgs& a, int rgroup, int ks, int nch, int blocks, bool full, hipStream_t s) {
   if (ks == 1) {
-    if (rgroup <= 2) return launch_gemv_nch<2, 1, PRO, EPI>(a, nch, blocks, s);
-    return launch_gemv_nch<4, 1, PRO, EPI>(a, nch, blocks, s);
+    if (rgroup <= 2) return launch_gemv_nch<2, 1, PRO, EPI>(a, nch, blocks, full && rgroup == 2, s);
+    return launch_gemv_nch<4, 1, PRO, EPI>(a, nch, blocks, full && rgroup == 4, s);
   }
   if constexpr (PRO == PRO_NONE) {
-    if (rgroup <= 2) return launch_gemv_nch<2, 4, PRO, EPI>(a, nch, blocks, s);
-    return launch_gemv_nch<4, 4, PRO, EPI>(a, nch, blocks, s);
+    if (rgroup <= 2) return launch_gemv_nch<2, 4, PRO, EPI>(a, nch, blocks, full && rgroup == 2, s);
+    return launch_gemv_nch<4, 4, PRO, EPI>(a, nch, blocks, full && rgroup == 4, s);
   }
   return -1;
 }
@@ -171,6 +172,7 @@ static int run_gemv(zn_handle h, GemvArgs a, int rows, int target_blocks, hipStr
   if (upw < 1) upw = 1;
   a.upw = upw;
   const int blocks = (a.units + upw * lanes_units - 1) / (upw * lanes_units);
+  const bool full = (kw == nch * 512) && (a.N % 2 == 0) && (a.units == blocks * lanes_units * upw);
   for (int r0 = 0; r0 < rows; r0 += 4) {
     GemvArgs g = a;
     const int nr = rows - r0 < 4 ? rows - r0 : 4;
@@ -182,7 +184,7 @@ static int run_gemv(zn_handle h, GemvArgs a, int rows, int target_blocks, hipStr
     if (g.lengths) g.lengths += r0;
     if (g.q_out) g.q_out += (size_t)r0 * a.n_heads * a.hd;
     if (g.kv) g.kv += (size_t)r0 * a.max_len * 2 * a.n_heads_kv * a.hd;
-    if (launch_gemv_rows<PRO, EPI>(g, nr, ks, nch, blocks, s) != 0) ZN_FAIL(h, ZN_ERR_UNSUPPORTED, "gemv: no kernel for ks=%d nch=%d", ks, nch);
+    if (launch_gemv_rows<PRO, EPI>(g, nr, ks, nch, blocks, full, s) != 0) ZN_FAIL(h, ZN_ERR_UNSUPPORTED, "gemv: no kernel for ks=%d nch=%d", ks, nch);
   }
   return ZN_OK;
 }
@@ -191,7 +193,7 @@ template <int HD>
 static int launch_attn_g(const AttnArgs& a, int G, dim3 grid, hipStream_t s) {
   switch (G) {
 #define ZN_ATTN_CASE(GG) case GG: hipLaunchKernelGGL((attn_scores_kernel<HD, GG>), grid, dim3(256), 0, s, a); \
-                                  hipLaunchKernelGGL((attn_pv_kernel<HD, GG>), grid, dim3(256), 0, s, a); return 0;
+                                  hipLaunchKernelGGL((attn_pv_kernel<HD, GG>), dim3(HD / 32, grid.y, grid.z), dim3(512), 0, s, a); return 0;
     ZN_ATTN_CASE(1) ZN_ATTN_CASE(2) ZN_ATTN_CASE(4) ZN_ATTN_CASE(8)
 #undef ZN_ATTN_CASE
   }
@@ -202,13 +204,11 @@ static int ensure_attn_ws(zn_handle h, int max_len) {
   const int lcap = ((max_len + 511) / 512) * 512;
   if (lcap <= h->lcap) return ZN_OK;
   free_graph(h);
-  for (float** p : {&h->scores, &h->cmax, &h->pacc, &h->pl}) if (*p) { (void)hipFree(*p); *p = nullptr; }
+  for (float** p : {&h->scores, &h->cmax}) if (*p) { (void)hipFree(*p); *p = nullptr; }
   const size_t RH = (size_t)h->max_rows * h->cfg.n_heads;
   const int nc = lcap / ZN_ACHUNK;
   HIPCHK(h, hipMalloc(&h->scores, RH * lcap * sizeof(float)));
   HIPCHK(h, hipMalloc(&h->cmax, RH * nc * sizeof(float)));
-  HIPCHK(h, hipMalloc(&h->pacc, RH * nc * h->hd * sizeof(float)));
-  HIPCHK(h, hipMalloc(&h->pl, RH * nc * sizeof(float)));
   h->lcap = lcap;
   return ZN_OK;
 }
@@ -220,12 +220,11 @@ static int run_attention(zn_handle h, const bf16_t* q, const bf16_t* kv, int max
   AttnArgs a{};
   a.q = q; a.kv = kv; a.lengths = lengths; a.ext = ext; a.ext_scalar = ext_scalar; a.max_len = max_len;
   a.n_heads = c.n_heads; a.n_heads_kv = c.n_heads_kv; a.lcap = h->lcap; a.scale = (float)(1.0 / std::sqrt((double)h->hd));
-  a.scores = h->scores; a.cmax = h->cmax; a.pacc = h->pacc; a.pl = h->pl; a.out = out;
+  a.scores = h->scores; a.cmax = h->cmax; a.out = out;
   const int hd = h->hd;
   dim3 grid((max_len + ZN_ACHUNK - 1) / ZN_ACHUNK, c.n_heads_kv, rows);
   int r2 = hd == 128 ? launch_attn_g<128>(a, h->G, grid, s) : hd == 64 ? launch_attn_g<64>(a, h->G, grid, s) : launch_attn_g<32>(a, h->G, grid, s);
   if (r2) ZN_FAIL(h, ZN_ERR_UNSUPPORTED, "attention: unsupported group %d", h->G);
-  hipLaunchKernelGGL(attn_combine_kernel, dim3(c.n_heads, rows), dim3(128), 0, s, a, hd);
   return ZN_OK;
 }
 

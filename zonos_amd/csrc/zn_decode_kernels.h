@@ -38,21 +38,26 @@ template <int NCH> struct WTile {
   float cs, sn;     // EPI_ROPE_KV: cos/sin      epilogue never has to wait behind the next unit's prefetch
 };
 
-template <int NCH, int KSPLIT, int EPI>
+template <int NCH, int KSPLIT, int EPI, bool FULL>
 ZN_DEVINL void gemv_load_unit(const GemvArgs& a, int u, int lane, int kw, int kbase, int pos, WTile<NCH>& t) {
   const int F = a.N >> 1;
-  const bool u_ok = u < a.units;
+  const bool u_ok = FULL || u < a.units;
   int rowA, rowB;
   if constexpr (EPI == EPI_SILU) { rowA = u; rowB = u + F; }
   else { rowA = 2 * u; rowB = 2 * u + 1; }
-  const bool b_ok = u_ok && rowB < a.N;
+  const bool b_ok = FULL || (u_ok && rowB < a.N);
 #pragma unroll
   for (int c = 0; c < NCH; ++c) {
     const int k = (c * 64 + lane) * 8;
-    t.a[c] = u32x4{0, 0, 0, 0}; t.b[c] = u32x4{0, 0, 0, 0};
-    if (u_ok && k < kw) {
+    if constexpr (FULL) {
       t.a[c] = ld_nt16(a.W + (size_t)rowA * a.K + kbase + k);
-      if (b_ok) t.b[c] = ld_nt16(a.W + (size_t)rowB * a.K + kbase + k);
+      t.b[c] = ld_nt16(a.W + (size_t)rowB * a.K + kbase + k);
+    } else {
+      t.a[c] = u32x4{0, 0, 0, 0}; t.b[c] = u32x4{0, 0, 0, 0};
+      if (u_ok && k < kw) {
+        t.a[c] = ld_nt16(a.W + (size_t)rowA * a.K + kbase + k);
+        if (b_ok) t.b[c] = ld_nt16(a.W + (size_t)rowB * a.K + kbase + k);
+      }
     }
   }
   t.resid = 0; t.cs = 1.f; t.sn = 0.f;
@@ -73,7 +78,9 @@ ZN_DEVINL void gemv_load_unit(const GemvArgs& a, int u, int lane, int kw, int kb
   }
 }
 
-template <int R, int NCH, int KSPLIT, int PRO, int EPI>
+// FULL = no masking anywhere: K == NCH*512*KSPLIT, N even, every wave's units exist, nrows == R (host-checked).  The
+// masked variant turns each guarded load into an exec branch with early waits, which serialises the weight stream.
+template <int R, int NCH, int KSPLIT, int PRO, int EPI, bool FULL>
 __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs a) {
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
@@ -85,22 +92,31 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs a) {
 
   int pos = 0;
   if constexpr (EPI == EPI_ROPE_KV) { if (lane < a.nrows) pos = a.lengths[lane]; }
-  // the first unit's weights do not depend on the activations: get them in flight before the prologue
-  WTile<NCH> wt;
-  gemv_load_unit<NCH, KSPLIT, EPI>(a, u0, lane, kw, kbase, pos, wt);
-
-  // ---------------- prologue: this lane's slices of the activation rows, packed bf16 in registers
+  // Issue order matters (vmcnt retires in order): the small L2-resident loads the prologue needs first, then the first
+  // unit's weights (they do not depend on the activations), then pin that order; the prologue then waits only for the
+  // former while the HBM stream is already in flight.
   u32x4 xr[NCH][R];
+  u32x4 lng[PRO == PRO_LN ? NCH : 1], lnb[PRO == PRO_LN ? NCH : 1];
 #pragma unroll
   for (int c = 0; c < NCH; ++c) {
     const int k = (c * 64 + lane) * 8;
-    const bool kv_ok = k < kw;
+    const bool kv_ok = FULL || k < kw;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-      xr[c][r] = u32x4{0, 0, 0, 0};
-      if (kv_ok && r < a.nrows) xr[c][r] = ld16(a.x + (size_t)r * K + kbase + k);
+      if constexpr (FULL) xr[c][r] = ld16(a.x + (size_t)r * K + kbase + k);
+      else {
+        xr[c][r] = u32x4{0, 0, 0, 0};
+        if (kv_ok && r < a.nrows) xr[c][r] = ld16(a.x + (size_t)r * K + kbase + k);
+      }
+    }
+    if constexpr (PRO == PRO_LN) {
+      lng[c] = u32x4{0, 0, 0, 0}; lnb[c] = u32x4{0, 0, 0, 0};
+      if (kv_ok) { lng[c] = ld16(a.ln_w + k); lnb[c] = ld16(a.ln_b + k); }
     }
   }
+  WTile<NCH> wt;
+  gemv_load_unit<NCH, KSPLIT, EPI, FULL>(a, u0, lane, kw, kbase, pos, wt);
+  __builtin_amdgcn_sched_barrier(0);
   if constexpr (PRO == PRO_LN) {
     // nn.LayerNorm (_torch.py:278,280,155): fp32 statistics, biased variance, affine, bf16 out.  KSPLIT == 1.
     const float invK = 1.0f / (float)K;
@@ -121,7 +137,7 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs a) {
       ss[r] = 0.f;
 #pragma unroll
       for (int c = 0; c < NCH; ++c) {
-        if ((c * 64 + lane) * 8 < kw) {
+        if (FULL || (c * 64 + lane) * 8 < kw) {
           const u32x4 v = xr[c][r];
           float d;
           d = lo_f(v.x) - mean[r]; ss[r] += d * d; d = hi_f(v.x) - mean[r]; ss[r] += d * d;
@@ -136,8 +152,8 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs a) {
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
       const int k = (c * 64 + lane) * 8;
-      if (k < kw) {
-        const u32x4 g = ld16(a.ln_w + k), b = ld16(a.ln_b + k);
+      if (FULL || k < kw) {
+        const u32x4 g = lng[c], b = lnb[c];
 #pragma unroll
         for (int r = 0; r < R; ++r) {
           const u32x4 v = xr[c][r];
@@ -157,16 +173,16 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs a) {
   const int F = a.N >> 1;  // EPI_SILU: gate rows start at N/2
   for (int it = 0; it < a.upw; ++it) {
     const int u = u0 + it;
-    const bool u_ok = u < a.units;  // wave-uniform (block-uniform for KSPLIT=4)
+    const bool u_ok = FULL || u < a.units;  // wave-uniform (block-uniform for KSPLIT=4)
     int rowA, rowB;
     if constexpr (EPI == EPI_SILU) { rowA = u; rowB = u + F; }
     else { rowA = 2 * u; rowB = 2 * u + 1; }
-    const bool b_ok = u_ok && rowB < a.N;
+    const bool b_ok = FULL || (u_ok && rowB < a.N);
     float accA[R], accB[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) { accA[r] = 0.f; accB[r] = 0.f; }
     WTile<NCH> cur = wt;
-    if (it + 1 < a.upw) gemv_load_unit<NCH, KSPLIT, EPI>(a, u + 1, lane, kw, kbase, pos, wt);
+    if (it + 1 < a.upw) gemv_load_unit<NCH, KSPLIT, EPI, FULL>(a, u + 1, lane, kw, kbase, pos, wt);
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
 #pragma unroll
@@ -196,7 +212,7 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs a) {
     float vA = 0.f, vB = 0.f;
 #pragma unroll
     for (int r = 0; r < R; ++r) if (lane == r) { vA = accA[r]; vB = accB[r]; }
-    if (lane >= a.nrows) continue;
+    if (lane >= (FULL ? R : a.nrows)) continue;
     const int r = lane;
     if constexpr (EPI == EPI_STORE) {
       if (b_ok) *(unsigned*)(a.out + (size_t)r * a.N + rowA) = pack2(vA, vB);
@@ -248,8 +264,6 @@ struct AttnArgs {
   float scale;
   float* scores;        // [rows][Hq][lcap]
   float* cmax;          // [rows][Hq][lcap/64]   per-64-key-chunk maxima
-  float* pacc;          // [rows][Hq][lcap/64][hd] per-chunk P.V partials
-  float* pl;            // [rows][Hq][lcap/64]     per-chunk sums of e
   bf16_t* out;          // [rows][Hq*hd]
 };
 #define ZN_ACHUNK 64
@@ -304,113 +318,151 @@ __global__ __launch_bounds__(256) void attn_scores_kernel(AttnArgs a) {
   }
 }
 
-// Pass 2: e/p with the reference's rounding (running max through the END of the chunk's 512-key block = max over the
-// chunk maxima of blocks 0..j), P.V partial and partial sum of the chunk.
+// Pass 2: one workgroup per (32-wide value slice, kv head, row) walks ALL keys in the reference's order (512-key blocks,
+// running max taken from the chunk maxima of pass 1), forms e/P with the reference's rounding, accumulates P.V on its
+// value columns and writes the final bf16 output — no cross-workgroup partials, no combine launch.  V is read as
+// 64-B row pieces (L x 64 B per workgroup, ~58 KB at 10 s of context).
 template <int HD, int G>
-__global__ __launch_bounds__(256) void attn_pv_kernel(AttnArgs a) {
-  constexpr int LPP = HD / 8, PPW = 64 / LPP, NVL = 16 / PPW;
-  const int chunk = blockIdx.x, kvh = blockIdx.y, r = blockIdx.z;
+__global__ __launch_bounds__(512) void attn_pv_kernel(AttnArgs a) {
+  constexpr int NW = 8;                                   // waves per workgroup; 16 keys per wave-load -> 128 keys per round
+  constexpr int NR = 512 / (NW * 16);                     // rounds per 512-key block
+  constexpr int GL = (G + 3) / 4;                         // heads a lane evaluates: g = vsub + 4*q
+  const int slice = blockIdx.x, kvh = blockIdx.y, r = blockIdx.z;
   const int L = a.lengths[r] + 1;
-  if (chunk * ZN_ACHUNK >= L) return;
   int E = a.ext ? a.ext[r] : (a.ext_scalar > 0 ? a.ext_scalar : L);
   if (E < L) E = L;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int sub = lane % LPP, grp = lane / LPP;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int vsub = lane & 3, vkey = lane >> 2;           // 4 lanes x 16 B cover the 32-wide slice; 16 keys per wave-load
   const size_t kvrow = (size_t)2 * a.n_heads_kv * HD;
-  const bf16_t* vbase = a.kv + (size_t)r * a.max_len * kvrow + (size_t)(a.n_heads_kv + kvh) * HD + sub * 8;
-  u32x4 vv[NVL];
-  float sc[NVL][G];
+  const bf16_t* vbase = a.kv + (size_t)r * a.max_len * kvrow + (size_t)(a.n_heads_kv + kvh) * HD + slice * 32 + vsub * 8;
+  const int cstride = a.lcap / ZN_ACHUNK;
+  const int nchunks = (L + ZN_ACHUNK - 1) / ZN_ACHUNK, nb = (L + 511) >> 9;
+  // this lane evaluates e only for heads vsub, vsub+4, ... and quad-broadcasts them (DPP); P.V needs all G heads
+  const float* srow[GL];
+  const float* crow[GL];
 #pragma unroll
-  for (int i = 0; i < NVL; ++i) {
-    const int t = chunk * ZN_ACHUNK + wave * 16 + i * PPW + grp;
-    vv[i] = u32x4{0, 0, 0, 0};
-    if (t < L) vv[i] = ld16(vbase + (size_t)t * kvrow);
-#pragma unroll
-    for (int g = 0; g < G; ++g) sc[i][g] = (t < L) ? a.scores[((size_t)r * a.n_heads + kvh * G + g) * a.lcap + t] : 0.f;
+  for (int q = 0; q < GL; ++q) {
+    const int g = min(vsub + 4 * q, G - 1);
+    srow[q] = a.scores + ((size_t)r * a.n_heads + kvh * G + g) * a.lcap;
+    crow[q] = a.cmax + ((size_t)r * a.n_heads + kvh * G + g) * cstride;
   }
-  const int j = (chunk * ZN_ACHUNK) >> 9;                       // 512-key block of this chunk
-  const int t0 = j * 512;
-  const int nch = min(8 * (j + 1), (L + ZN_ACHUNK - 1) / ZN_ACHUNK);
-  float m[G];
+  float acc[G][8], lsum[GL], m_run[GL];
 #pragma unroll
-  for (int g = 0; g < G; ++g) {
-    const float* cm = a.cmax + ((size_t)r * a.n_heads + kvh * G + g) * (a.lcap / ZN_ACHUNK);
-    float v = -INFINITY;
-    for (int c = lane; c < nch; c += 64) v = fmaxf(v, cm[c]);
-    m[g] = wave_max(v);
-  }
-  const int nblk = min(512, E - t0), nvec = nblk & ~15;
-  float acc[G][8], lsum[G];
-#pragma unroll
-  for (int g = 0; g < G; ++g) {
-    lsum[g] = 0.f;
+  for (int g = 0; g < G; ++g)
 #pragma unroll
     for (int e = 0; e < 8; ++e) acc[g][e] = 0.f;
-  }
 #pragma unroll
-  for (int i = 0; i < NVL; ++i) {
-    const int t = chunk * ZN_ACHUNK + wave * 16 + i * PPW + grp;
-    const int idx = t - t0;
-    const bool ok = t < L;
-    const float v0 = lo_f(vv[i].x), v1 = hi_f(vv[i].x), v2 = lo_f(vv[i].y), v3 = hi_f(vv[i].y);
-    const float v4 = lo_f(vv[i].z), v5 = hi_f(vv[i].z), v6 = lo_f(vv[i].w), v7 = hi_f(vv[i].w);
+  for (int q = 0; q < GL; ++q) { lsum[q] = 0.f; m_run[q] = -INFINITY; }
+  for (int j = 0; j < nb; ++j) {
+    const int t0 = j * 512;
+    const int nkeys = min(512, L - t0);
+    // requests of this block: chunk maxima, 4 value pieces and 4*GL scores per lane
+    float cm[GL];
+#pragma unroll
+    for (int q = 0; q < GL; ++q) { const int c = 8 * j + (lane >> 3); cm[q] = (c < nchunks && (lane >> 3) < 8) ? crow[q][c] : -INFINITY; }
+    u32x4 vv[NR];
+    float sc[NR][GL];
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+      const int idx = i * (NW * 16) + wave * 16 + vkey;
+      const bool ok = idx < nkeys;
+      vv[i] = u32x4{0, 0, 0, 0};
+      if (ok) vv[i] = ld16(vbase + (size_t)(t0 + idx) * kvrow);
+#pragma unroll
+      for (int q = 0; q < GL; ++q) sc[i][q] = ok ? srow[q][t0 + idx] : 0.f;
+    }
+    // running max of the block (max over its <= 8 chunk maxima: lanes 8c..8c+7 hold chunk c), rescale factors
+    float f[GL], mnew[GL];
+#pragma unroll
+    for (int q = 0; q < GL; ++q) {
+      // max over the lanes that hold THIS lane's head (equal lane & 3): rotate inside the row, then across the 4 rows
+      float bm = cm[q];
+      bm = fmaxf(bm, dpp_mov<ZN_DPP_ROR4>(bm));
+      bm = fmaxf(bm, dpp_mov<ZN_DPP_ROR8>(bm));
+      bm = fmaxf(bm, __shfl_xor(bm, 16));
+      bm = fmaxf(bm, __shfl_xor(bm, 32));
+      mnew[q] = fmaxf(m_run[q], bm);
+      f[q] = (j == 0) ? 0.f : expf(m_run[q] - mnew[q]);
+      m_run[q] = mnew[q];
+      lsum[q] = __fmul_rn(lsum[q], f[q]);
+    }
 #pragma unroll
     for (int g = 0; g < G; ++g) {
-      float e = 0.f;
-      if (ok) { const float x = __fsub_rn(sc[i][g], m[g]); e = (idx < nvec) ? zn_fexp_u20(x) : expf(x); }
-      if (sub == 0) lsum[g] += e;
-      const float p = bfround(e);
-      acc[g][0] = fmaf(p, v0, acc[g][0]); acc[g][1] = fmaf(p, v1, acc[g][1]);
-      acc[g][2] = fmaf(p, v2, acc[g][2]); acc[g][3] = fmaf(p, v3, acc[g][3]);
-      acc[g][4] = fmaf(p, v4, acc[g][4]); acc[g][5] = fmaf(p, v5, acc[g][5]);
-      acc[g][6] = fmaf(p, v6, acc[g][6]); acc[g][7] = fmaf(p, v7, acc[g][7]);
+      // factor of head g lives in lane (quad base + g%4), slot g/4
+      float fg = f[g / 4];
+      fg = (g % 4 == 0) ? dpp_mov<0x00>(fg) : (g % 4 == 1) ? dpp_mov<0x55>(fg) : (g % 4 == 2) ? dpp_mov<0xAA>(fg) : dpp_mov<0xFF>(fg);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[g][e] = __fmul_rn(acc[g][e], fg);
+    }
+    const int nblk = min(512, E - t0), nvec = nblk & ~15;
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+      const int base = i * (NW * 16);
+      const int idx = base + wave * 16 + vkey;
+      const bool ok = idx < nkeys;
+      float ev[GL];
+      if (base + NW * 16 <= nvec) {                       // whole round inside the SIMD part: fexp only (uniform branch)
+#pragma unroll
+        for (int q = 0; q < GL; ++q) ev[q] = ok ? zn_fexp_u20(__fsub_rn(sc[i][q], mnew[q])) : 0.f;
+      } else {
+#pragma unroll
+        for (int q = 0; q < GL; ++q) {
+          const float x = __fsub_rn(sc[i][q], mnew[q]);
+          ev[q] = ok ? ((idx < nvec) ? zn_fexp_u20(x) : expf(x)) : 0.f;
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < GL; ++q) if (vsub + 4 * q < G) lsum[q] += ev[q];
+      const float v0 = lo_f(vv[i].x), v1 = hi_f(vv[i].x), v2 = lo_f(vv[i].y), v3 = hi_f(vv[i].y);
+      const float v4 = lo_f(vv[i].z), v5 = hi_f(vv[i].z), v6 = lo_f(vv[i].w), v7 = hi_f(vv[i].w);
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        float p = bfround(ev[g / 4]);
+        p = (g % 4 == 0) ? dpp_mov<0x00>(p) : (g % 4 == 1) ? dpp_mov<0x55>(p) : (g % 4 == 2) ? dpp_mov<0xAA>(p) : dpp_mov<0xFF>(p);
+        acc[g][0] = fmaf(p, v0, acc[g][0]); acc[g][1] = fmaf(p, v1, acc[g][1]);
+        acc[g][2] = fmaf(p, v2, acc[g][2]); acc[g][3] = fmaf(p, v3, acc[g][3]);
+        acc[g][4] = fmaf(p, v4, acc[g][4]); acc[g][5] = fmaf(p, v5, acc[g][5]);
+        acc[g][6] = fmaf(p, v6, acc[g][6]); acc[g][7] = fmaf(p, v7, acc[g][7]);
+      }
     }
   }
-  // every (wave, key-group) pair writes its partial to LDS; fixed-order sum (deterministic)
-  constexpr int NP = 4 * PPW;
-  __shared__ float sacc[NP][G][HD];
-  __shared__ float sl[4][G];
+  // reduce: 4 key lanes per 16-lane row by DPP, then the rows of the workgroup through LDS in a fixed order
+  __shared__ float s_acc[NW * 4][G][32];
+  __shared__ float s_l[NW][G];
+  const int row = lane >> 4;
 #pragma unroll
   for (int g = 0; g < G; ++g) {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) sacc[wave * PPW + grp][g][sub * 8 + e] = acc[g][e];
-    const float ls = wave_sum(lsum[g]);
-    if (lane == 0) sl[wave][g] = ls;
+    for (int e = 0; e < 8; ++e) acc[g][e] = row_stride4_sum(acc[g][e]);
+    if ((lane & 15) < 4) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s_acc[wave * 4 + row][g][(lane & 3) * 8 + e] = acc[g][e];
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < GL; ++q) {
+    // lsum[q] of lane vsub belongs to head vsub + 4q: sum over the 16 lanes with that vsub, per wave
+    float ls = row_stride4_sum(lsum[q]);                                   // per row, lanes with equal vsub
+    ls = (readlane_f(ls, 0) + readlane_f(ls, 16)) + (readlane_f(ls, 32) + readlane_f(ls, 48));   // vsub 0 total
+    float l1 = row_stride4_sum(lsum[q]); l1 = (readlane_f(l1, 1) + readlane_f(l1, 17)) + (readlane_f(l1, 33) + readlane_f(l1, 49));
+    float l2 = row_stride4_sum(lsum[q]); l2 = (readlane_f(l2, 2) + readlane_f(l2, 18)) + (readlane_f(l2, 34) + readlane_f(l2, 50));
+    float l3 = row_stride4_sum(lsum[q]); l3 = (readlane_f(l3, 3) + readlane_f(l3, 19)) + (readlane_f(l3, 35) + readlane_f(l3, 51));
+    if (lane == 0) {
+      if (4 * q + 0 < G) s_l[wave][4 * q + 0] = ls;
+      if (4 * q + 1 < G) s_l[wave][4 * q + 1] = l1;
+      if (4 * q + 2 < G) s_l[wave][4 * q + 2] = l2;
+      if (4 * q + 3 < G) s_l[wave][4 * q + 3] = l3;
+    }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < G * HD; i += 256) {
-    const int g = i / HD, d = i % HD;
-    float v = 0.f;
+  if (tid < G * 32) {
+    const int g = tid >> 5, d = tid & 31;
+    float v = 0.f, l = 0.f;
 #pragma unroll
-    for (int w = 0; w < NP; ++w) v += sacc[w][g][d];
-    a.pacc[(((size_t)r * a.n_heads + kvh * G + g) * (a.lcap / ZN_ACHUNK) + chunk) * HD + d] = v;
-  }
-  if (threadIdx.x < G) {
-    const int g = threadIdx.x;
-    a.pl[((size_t)r * a.n_heads + kvh * G + g) * (a.lcap / ZN_ACHUNK) + chunk] = (sl[0][g] + sl[1][g]) + (sl[2][g] + sl[3][g]);
-  }
-}
-
-// Pass 3: per (row, head): block sums in chunk order, then the reference's sequential walk over its 512-key blocks
-// (acc = acc*exp(m_prev - m_new) + P.V, sum likewise), out = bf16(acc * (1/sum)).
-__global__ __launch_bounds__(128) void attn_combine_kernel(AttnArgs a, int hd) {
-  const int h = blockIdx.x, r = blockIdx.y;
-  const int L = a.lengths[r] + 1;
-  const int nchunks = (L + ZN_ACHUNK - 1) / ZN_ACHUNK, nb = (L + 511) >> 9;
-  const int cstride = a.lcap / ZN_ACHUNK;
-  const size_t hb = ((size_t)r * a.n_heads + h) * cstride;
-  for (int d = threadIdx.x; d < hd; d += blockDim.x) {
-    float acc = 0.f, l = 0.f, mrun = -INFINITY;
-    for (int j = 0; j < nb; ++j) {
-      const int c0 = j * 8, c1 = min(c0 + 8, nchunks);
-      float pv = 0.f, ls = 0.f, mj = mrun;
-      for (int c = c0; c < c1; ++c) { pv += a.pacc[(hb + c) * hd + d]; ls += a.pl[hb + c]; mj = fmaxf(mj, a.cmax[hb + c]); }
-      const float f = (j == 0) ? 0.f : expf(mrun - mj);
-      mrun = mj;
-      l = __fadd_rn(ls, __fmul_rn(f, l));
-      acc = __fadd_rn(__fmul_rn(acc, f), pv);
-    }
-    a.out[((size_t)r * a.n_heads + h) * hd + d] = f2bf(__fmul_rn(acc, 1.0f / l));
+    for (int w = 0; w < NW * 4; ++w) v += s_acc[w][g][d];
+#pragma unroll
+    for (int w = 0; w < NW; ++w) l += s_l[w][g];
+    a.out[((size_t)r * a.n_heads + kvh * G + g) * HD + slice * 32 + d] = f2bf(__fmul_rn(v, 1.0f / l));
   }
 }
 
