@@ -157,7 +157,7 @@ def main():
         ach = by.value / (ms.value * 1e-3)
         result["roofline"] = {"bound": "hbm", "kernel": "gemv_kernel<R=2,NCH=4,KSPLIT=1,PRO_LN,EPI_SILU> (LayerNorm+fc1+SiLU-gate)",
                               "achieved": round(ach / 1e9, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": round(ach / HBM_PEAK, 4),
-                              "traffic": None, "bytes_per_launch": by.value, "us_per_launch": round(ms.value * 1e3, 3)}
+                              "traffic": pmc_traffic(), "bytes_per_launch": by.value, "us_per_launch": round(ms.value * 1e3, 3)}
         Lavg = l_c + 1 + steps_per_utt / 2
         step_bytes = algorithmic_bytes_per_step(cfg, B, Lavg)
         step_s = t_ar / (steps_per_utt + 1)
@@ -204,6 +204,15 @@ def cpu_baseline(w_cpu, cfg, seed, l_c, max_steps: int = 24, budget_s: float = 2
             "sample": f"oracle/zonos_oracle.py generate() on the same utterance: prefill + {len(stamps)} decode steps, median step "
                       f"{s_per_step * 1e3:.1f} ms (torch CPU bf16, {cores} threads, wall budget {budget_s:g} s); DAC decode not included",
             "s_per_decode_step": round(s_per_step, 5)}
+
+
+def pmc_traffic():
+    """HBM bytes per launch of the dominant kernel from the PMC passes (FETCH_SIZE x2 + WRITE_SIZE; separate rocprofv3
+    --pmc runs of tools/pmc_kernel.py, summary committed as profiles/r01_d_pmc_fc1.json); None if not collected."""
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "r01_d_pmc_fc1.json")))["traffic_bytes_per_launch"]
+    except Exception:
+        return None
 
 
 def log(msg):

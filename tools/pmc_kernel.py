@@ -1,0 +1,16 @@
+"""Run only the dominant decode kernel (LayerNorm+fc1+SiLU GEMV) 260 times, cycling over the 26 layers' weights.
+Meant to be wrapped by rocprofv3 (--kernel-trace --stats, or --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes)."""
+import ctypes as C
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from zonos_amd import _lib, synth  # noqa: E402
+from zonos_amd.testing import build_model  # noqa: E402
+
+model, _ = build_model(synth.FULL_CFG, 1234, "cuda:0")
+eng = model.engine(1)
+t, by = C.c_float(0), C.c_double(0)
+which = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+eng.call("zn_bench_kernel", which, 2, 260, C.byref(t), C.byref(by), _lib.stream_ptr())
+print(f"kernel {which}: {t.value * 1e3:.2f} us/launch by HIP events, algorithmic {by.value / 1e6:.2f} MB/launch, {by.value / t.value / 1e6:.1f} GB/s")

@@ -457,8 +457,10 @@ extern "C" int zn_debug_eos_bias(zn_handle h, float bias) { if (!h) return ZN_ER
 extern "C" int zn_bench_kernel(zn_handle h, int32_t which, int32_t rows, int32_t iters, float* ms_per_launch, double* bytes_per_launch,
                                zn_stream stream) {
   if (!h) return ZN_ERR_ARG;
-  if (!ms_per_launch || !bytes_per_launch || iters < 1 || rows < 1 || rows > h->max_rows || which < 0 || which > 3)
+  if (!ms_per_launch || !bytes_per_launch || iters < 1 || (rows & 0xff) < 1 || (rows & 0xff) > h->max_rows || which < 0 || which > 3)
     ZN_FAIL(h, ZN_ERR_ARG, "zn_bench_kernel: bad argument");
+  const bool same_layer = (rows & 0x100) != 0;   // measurement variant: keep hitting layer 0 (weights stay in the Infinity Cache)
+  rows &= 0xff;
   hipStream_t s = (hipStream_t)stream;
   const zn_config& c = h->cfg;
   const int d = c.d_model;
@@ -472,7 +474,7 @@ extern "C" int zn_bench_kernel(zn_handle h, int32_t which, int32_t rows, int32_t
   for (int pass = 0; pass < 2 && rc == ZN_OK; ++pass) {   // pass 0 = warm-up
     if (pass == 1) HIPCHK(h, hipEventRecord(e0, s));
     for (int i = 0; i < (pass ? iters : (iters < 8 ? iters : 8)) && rc == ZN_OK; ++i) {
-      const zn_layer_weights& lw = h->layers[i % c.n_layer];
+      const zn_layer_weights& lw = h->layers[same_layer ? 0 : i % c.n_layer];
       GemvArgs a{};
       a.eps = c.norm_eps;
       if (which == 0) {
