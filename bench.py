@@ -44,6 +44,7 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--seconds", type=float, default=10.0, help="target audio length per utterance")
+    ap.add_argument("--batch-per-gpu", type=int, default=1, help="utterances per GPU (default 1 = BASELINE config 2; 8 = config 3's share)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dac", action="store_true")
     args = ap.parse_args()
@@ -69,7 +70,7 @@ def main():
 
     cfg, seed = synth.FULL_CFG, 1234
     max_new = int(round(args.seconds * FRAME_RATE))             # 861 for 10 s
-    l_c, B = 24, 1
+    l_c, B = 24, args.batch_per_gpu
     t0 = time.time()
     dac = None
     if not args.no_dac:
@@ -79,7 +80,7 @@ def main():
     log(f"rank {rank}: model built in {setup_s:.1f} s")
     eng = model.engine(B)
     eng.call("zn_debug_eos_bias", float("-inf"))                 # suppress EOS: all max_new+7 steps run
-    cond = synth.conditioning(seed + rank, "cond", 2 * B, l_c, cfg["d_model"]).to(dev)
+    cond = torch.cat([synth.conditioning(seed + rank * 64 + i, "cond", 2, l_c, cfg["d_model"])[j:j + 1] for j in (0, 1) for i in range(B)], 0).to(dev)
     steps_per_utt = max_new + 7
 
     use_dac = dac is not None
@@ -140,14 +141,14 @@ def main():
         "metric": "audio-sec/sec (RTF), Zonos-v0.1-transformer AR decode loop + DAC decode", "value": round(value, 3), "unit": "audio-sec/sec",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-        "config": {"workload": f"Zonos-v0.1-transformer bf16, batch=1 per GPU, {args.seconds:g} s target audio ({max_new} frames, "
+        "config": {"workload": f"Zonos-v0.1-transformer bf16, batch={B} per GPU, {args.seconds:g} s target audio ({max_new} frames, "
                                f"{steps_per_utt} decode steps + prefill of {l_c + 1} positions, EOS suppressed), greedy, cfg_scale 2",
                    "weights": "seeded synthetic (zonos_amd/synth.py)", "dac_decode_in_timed_region": bool(use_dac),
                    "codes_all_gather_in_timed_region": world > 1, "parallelism": f"dp{world} (utterance sharding, no data-path collective)"},
-        "dac_tokens_per_sec": round(world * args.steps * steps_per_utt * 9 / elapsed, 1) if world > 1 else round(args.steps * steps_per_utt * 9 / elapsed, 1),
+        "dac_tokens_per_sec": round(world * B * args.steps * steps_per_utt * 9 / elapsed, 1),
         "frames_per_sec": round(frames / elapsed, 1),
         "ar_only": {"s_per_utterance": round(t_ar, 4), "ms_per_decode_step": round(1e3 * t_ar / (steps_per_utt + 1), 4),
-                    "audio_sec_per_sec": round(max_new / FRAME_RATE / t_ar, 3)},
+                    "audio_sec_per_sec": round(B * max_new / FRAME_RATE / t_ar, 3)},
         "setup_s": round(setup_s, 1), "hipgraph_step": bool(eng.lib.zn_graph_active(eng.h)),
     }
     if rank == 0:
@@ -168,7 +169,7 @@ def main():
             eng.call("zn_bench_kernel", which, 2 * B, 260, C.byref(ms), C.byref(by), _lib.stream_ptr())
             others[name] = {"us_per_launch": round(ms.value * 1e3, 3), "GB/s": round(by.value / (ms.value * 1e-3) / 1e9, 1)}
         result["other_kernels"] = others
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and B == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(w_cpu, cfg, seed, l_c)
         print(json.dumps(result), flush=True)
     if dist is not None:

@@ -25,7 +25,8 @@ def main():
     t0 = time.time()
     model, _ = build_model(synth.FULL_CFG, 1234, dev)
     print(f"model built in {time.time() - t0:.1f} s", flush=True)
-    B, nq, max_new = 1, 9, L0 + n + 64
+    B = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+    nq, max_new = 9, L0 + n + 64
     eng = model.engine(B)
     eng.call("zn_debug_eos_bias", float("-inf"))
     ip = model.setup_cache(2 * B, L0 + n + 80)
@@ -47,7 +48,9 @@ def main():
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / n
-    print(f"context {L0}..{L0 + n}: {ms:.4f} ms/decode step  ({1e3 / ms / 86.1328:.2f}x real-time, graph={eng.lib.zn_graph_active(eng.h)})", flush=True)
+    print(f"B={B} context {L0}..{L0 + n}: {ms:.4f} ms/decode step  ({B * 1e3 / ms / 86.1328:.2f}x real-time aggregate, graph={eng.lib.zn_graph_active(eng.h)})", flush=True)
+    if B > 1:
+        return
     t, by = C.c_float(0), C.c_double(0)
     for which, name in ((0, "LN+fc1+SiLU"), (1, "fc2+resid"), (2, "out_proj+resid"), (3, "LN+heads")):
         eng.call("zn_bench_kernel", which, 2, 260, C.byref(t), C.byref(by), st)

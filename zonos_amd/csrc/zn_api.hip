@@ -21,7 +21,7 @@ struct zn_handle_s {
   const bf16_t** emb_tables_dev = nullptr;
   bool has_io = false;  // embeddings + heads bound (false: backbone-only handle)
   // workspace (device)
-  bf16_t *x = nullptr, *q = nullptr, *o1 = nullptr, *mbuf = nullptr;
+  bf16_t *x = nullptr, *q = nullptr, *o1 = nullptr, *mbuf = nullptr, *nbuf = nullptr;
   float *logits_raw = nullptr, *last_logits = nullptr;
   int* tok_raw = nullptr;
   float *scores = nullptr, *cmax = nullptr;
@@ -79,7 +79,7 @@ static void free_graph(zn_handle h) {
 extern "C" int zn_destroy(zn_handle h) {
   if (!h) return ZN_OK;
   free_graph(h);
-  void* ptrs[] = {h->emb_tables_dev, h->x, h->q, h->o1, h->mbuf, h->logits_raw, h->last_logits, h->tok_raw, h->scores, h->cmax, h->st, h->remaining, h->stopping};
+  void* ptrs[] = {h->emb_tables_dev, h->x, h->q, h->o1, h->mbuf, h->nbuf, h->logits_raw, h->last_logits, h->tok_raw, h->scores, h->cmax, h->st, h->remaining, h->stopping};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (h->done_host) (void)hipHostFree(h->done_host);
   if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
@@ -113,6 +113,7 @@ extern "C" int zn_create(const zn_config* cfg, const zn_weights* w, int32_t max_
   ZC(hipMalloc(&h->q, R * c.d_model * 2));
   ZC(hipMalloc(&h->o1, R * c.d_model * 2));
   ZC(hipMalloc(&h->mbuf, R * c.d_ff * 2));
+  ZC(hipMalloc(&h->nbuf, R * c.d_model * 2));
   ZC(hipMalloc(&h->logits_raw, R * c.n_codebooks * c.vocab_head * sizeof(float)));
   ZC(hipMalloc(&h->last_logits, (R / 2) * c.n_codebooks * c.vocab_head * sizeof(float)));
   ZC(hipMalloc(&h->tok_raw, (R / 2) * c.n_codebooks * sizeof(int)));
@@ -157,8 +158,44 @@ static int launch_gemv_rows(const GemvArgs& a, int rgroup, int ks, int nch, int 
 
 // Runs one fused GEMV over `rows` activation rows (groups of <= 4 rows per launch; weights are re-streamed per
 // group, so batches beyond 2 utterances pay extra HBM traffic until the MFMA small-M path lands).
+// rows in (4, 16]: one weight pass on the matrix cores (gemm16_kernel); LayerNorm, when fused in the GEMV, is a row-wise
+// launch here (amortised over the batch).
+template <int PRO, int EPI>
+static int run_gemm16(zn_handle h, GemvArgs a, int rows, hipStream_t s) {
+  const int K = a.K;
+  // few weight-row tiles (N = d_model: 128 workgroups) -> more waves per workgroup so that every CU still keeps enough
+  // loads in flight
+  const int tiles_n = (EPI == EPI_SILU) ? (a.N / 2) / 16 : (a.N + 15) / 16;
+  int nw = 4;
+  if (tiles_n <= 256 && K % 256 == 0) nw = 8;
+  if (tiles_n <= 256 && K >= 8192 && K % 512 == 0) nw = 16;
+  if (K % (nw * 32)) ZN_FAIL(h, ZN_ERR_UNSUPPORTED, "gemm16: K=%d not a multiple of %d", K, nw * 32);
+  if (EPI == EPI_SILU && (a.N / 2) % 16) ZN_FAIL(h, ZN_ERR_UNSUPPORTED, "gemm16: d_ff must be a multiple of 16");
+  const int tiles = (EPI == EPI_SILU) ? (a.N / 2) / 16 : (a.N + 15) / 16;
+  for (int r0 = 0; r0 < rows; r0 += 16) {
+    GemvArgs g = a;
+    const int nr = rows - r0 < 16 ? rows - r0 : 16;
+    g.nrows = nr;
+    if (PRO == PRO_LN) {
+      hipLaunchKernelGGL(layernorm_kernel, dim3(nr), dim3(64), 0, s, a.x + (size_t)r0 * K, a.ln_w, a.ln_b, h->nbuf, K, a.eps);
+      g.x = h->nbuf;
+    } else g.x = a.x + (size_t)r0 * K;
+    if (g.out) g.out += (size_t)r0 * (EPI == EPI_SILU ? a.N / 2 : a.N);
+    if (g.resid) g.resid += (size_t)r0 * a.N;
+    if (g.out_f32) g.out_f32 += (size_t)r0 * a.N;
+    if (g.lengths) g.lengths += r0;
+    if (g.q_out) g.q_out += (size_t)r0 * a.n_heads * a.hd;
+    if (g.kv) g.kv += (size_t)r0 * a.max_len * 2 * a.n_heads_kv * a.hd;
+    if (nw == 16) hipLaunchKernelGGL((gemm16_kernel<16, EPI>), dim3(tiles), dim3(1024), 0, s, g);
+    else if (nw == 8) hipLaunchKernelGGL((gemm16_kernel<8, EPI>), dim3(tiles), dim3(512), 0, s, g);
+    else hipLaunchKernelGGL((gemm16_kernel<4, EPI>), dim3(tiles), dim3(256), 0, s, g);
+  }
+  return ZN_OK;
+}
+
 template <int PRO, int EPI>
 static int run_gemv(zn_handle h, GemvArgs a, int rows, int target_blocks, hipStream_t s) {
+  if (rows > 4) return run_gemm16<PRO, EPI>(h, a, rows, s);
   const int K = a.K;
   int ks = 1;
   if (PRO == PRO_NONE && K >= 4096 && K % 2048 == 0) ks = 4;

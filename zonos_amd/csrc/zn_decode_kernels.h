@@ -31,6 +31,43 @@ struct GemvArgs {
   int max_len, n_heads_kv, rope_positions;
 };
 
+// Fused epilogues shared by the GEMV (rows <= 4) and the small-M MFMA kernel (rows <= 16): finishes activation row r
+// for the weight-row pair (rowA, rowB) of work unit u.
+template <int EPI>
+ZN_DEVINL void gemv_epilogue(const GemvArgs& a, int r, int rowA, int rowB, bool b_ok, int u, float vA, float vB, unsigned resid, float cs,
+                             float sn, int pos) {
+  if constexpr (EPI == EPI_STORE) {
+    if (b_ok) *(unsigned*)(a.out + (size_t)r * a.N + rowA) = pack2(vA, vB);
+    else a.out[(size_t)r * a.N + rowA] = f2bf(vA);
+  } else if constexpr (EPI == EPI_F32) {
+    a.out_f32[(size_t)r * a.N + rowA] = bfround(vA);
+    if (b_ok) a.out_f32[(size_t)r * a.N + rowB] = bfround(vB);
+  } else if constexpr (EPI == EPI_RESID) {
+    // x + linear(...) with both operands bf16 (_torch.py:326-327)
+    const size_t o = (size_t)r * a.N + rowA;
+    if (b_ok) *(unsigned*)(a.out + o) = pack2(lo_f(resid) + bfround(vA), hi_f(resid) + bfround(vB));
+    else a.out[o] = f2bf(lo_f(resid) + bfround(vA));
+  } else if constexpr (EPI == EPI_SILU) {
+    // y * silu(gate), fc1(x).chunk(2) (_torch.py:473-474): bf16 roundings after fc1, silu and mul
+    const float y = bfround(vA), g = bfround(vB);
+    const float s = bfround(g / (1.0f + expf(-g)));
+    a.out[(size_t)r * (a.N >> 1) + u] = f2bf(y * s);
+  } else if constexpr (EPI == EPI_ROPE_KV) {
+    // split q|k|v (_torch.py:399-405), interleaved-pair RoPE in fp32 (_torch.py:57-68), KV append (:105-106)
+    const int hd = a.hd, nq = a.n_heads * hd, nk = a.n_heads_kv * hd;
+    const float x0 = bfround(vA), x1 = bfround(vB);
+    if (rowA < nq + nk) {
+      const float re = __fsub_rn(__fmul_rn(x0, cs), __fmul_rn(x1, sn));
+      const float im = __fadd_rn(__fmul_rn(x1, cs), __fmul_rn(x0, sn));
+      if (rowA < nq) *(unsigned*)(a.q_out + (size_t)r * nq + rowA) = pack2(re, im);
+      else if (pos < a.max_len)
+        *(unsigned*)(a.kv + (((size_t)r * a.max_len + pos) * 2 + 0) * nk + (rowA - nq)) = pack2(re, im);
+    } else if (pos < a.max_len) {
+      *(unsigned*)(a.kv + (((size_t)r * a.max_len + pos) * 2 + 1) * nk + (rowA - nq - nk)) = pack2(x0, x1);
+    }
+  }
+}
+
 // Weight tile of one work unit (two weight rows) held in registers.
 template <int NCH> struct WTile {
   u32x4 a[NCH], b[NCH];
@@ -213,39 +250,91 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs a) {
 #pragma unroll
     for (int r = 0; r < R; ++r) if (lane == r) { vA = accA[r]; vB = accB[r]; }
     if (lane >= (FULL ? R : a.nrows)) continue;
-    const int r = lane;
-    if constexpr (EPI == EPI_STORE) {
-      if (b_ok) *(unsigned*)(a.out + (size_t)r * a.N + rowA) = pack2(vA, vB);
-      else a.out[(size_t)r * a.N + rowA] = f2bf(vA);
-    } else if constexpr (EPI == EPI_F32) {
-      a.out_f32[(size_t)r * a.N + rowA] = bfround(vA);
-      if (b_ok) a.out_f32[(size_t)r * a.N + rowB] = bfround(vB);
-    } else if constexpr (EPI == EPI_RESID) {
-      // x + linear(...) with both operands bf16 (_torch.py:326-327)
-      const size_t o = (size_t)r * a.N + rowA;
-      const unsigned rs = cur.resid;
-      if (b_ok) *(unsigned*)(a.out + o) = pack2(lo_f(rs) + bfround(vA), hi_f(rs) + bfround(vB));
-      else a.out[o] = f2bf(lo_f(rs) + bfround(vA));
-    } else if constexpr (EPI == EPI_SILU) {
-      // y * silu(gate), fc1(x).chunk(2) (_torch.py:473-474): bf16 roundings after fc1, silu and mul
-      const float y = bfround(vA), g = bfround(vB);
-      const float s = bfround(g / (1.0f + expf(-g)));
-      a.out[(size_t)r * F + u] = f2bf(y * s);
-    } else if constexpr (EPI == EPI_ROPE_KV) {
-      // split q|k|v (_torch.py:399-405), interleaved-pair RoPE in fp32 (_torch.py:57-68), KV append (:105-106)
-      const int hd = a.hd, nq = a.n_heads * hd, nk = a.n_heads_kv * hd;
-      const float x0 = bfround(vA), x1 = bfround(vB);
-      if (rowA < nq + nk) {
-        const float cs = cur.cs, sn = cur.sn;
-        const float re = __fsub_rn(__fmul_rn(x0, cs), __fmul_rn(x1, sn));
-        const float im = __fadd_rn(__fmul_rn(x1, cs), __fmul_rn(x0, sn));
-        if (rowA < nq) *(unsigned*)(a.q_out + (size_t)r * nq + rowA) = pack2(re, im);
-        else if (pos < a.max_len)
-          *(unsigned*)(a.kv + (((size_t)r * a.max_len + pos) * 2 + 0) * nk + (rowA - nq)) = pack2(re, im);
-      } else if (pos < a.max_len) {
-        *(unsigned*)(a.kv + (((size_t)r * a.max_len + pos) * 2 + 1) * nk + (rowA - nq - nk)) = pack2(x0, x1);
+    gemv_epilogue<EPI>(a, lane, rowA, rowB, b_ok, u, vA, vB, cur.resid, cur.cs, cur.sn, pos);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ small-M MFMA
+// 5..16 activation rows (batches of 3..8 utterances): one weight pass serves all rows on the matrix cores.  A workgroup
+// owns 16 consecutive weight rows (EPI_SILU: the value tile and its gate tile); its NW waves split K, each streaming its
+// 16 x K/NW weight slab straight into MFMA B fragments (v_mfma_f32_16x16x32_bf16: lane = (row n = l&15, k-group l>>4),
+// 16 B per lane per 32-deep step) with the activation fragment fetched from L2; the partial 16x16 tiles meet in LDS
+// and the shared epilogues finish them.  HBM-bound like the GEMV; MFMA only replaces 16 rows x dot2 on the VALU.
+typedef __attribute__((ext_vector_type(8))) __bf16 zn_bf16x8;
+template <int NW, int EPI>
+__global__ __launch_bounds__(NW * 64) void gemm16_kernel(GemvArgs a) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n = lane & 15, g = lane >> 4;
+  const int u = blockIdx.x;                       // tile of 16 weight rows
+  const int F = a.N >> 1;
+  const int rowbaseA = (EPI == EPI_SILU) ? 16 * u : 16 * u;
+  const int rowbaseB = F + 16 * u;                // EPI_SILU only
+  const int K = a.K, kw = K / NW, kbase = wave * kw;
+  const bool n_ok = rowbaseA + n < ((EPI == EPI_SILU) ? F : a.N);
+  const bf16_t* wa = a.W + (size_t)(rowbaseA + (n_ok ? n : 0)) * K + kbase + 8 * g;
+  const bf16_t* wb = a.W + (size_t)(rowbaseB + (n_ok ? n : 0)) * K + kbase + 8 * g;
+  const bool m_ok = n < a.nrows;                  // A fragment: lane's activation row is (lane & 15)
+  const bf16_t* xa = a.x + (size_t)(m_ok ? n : 0) * K + kbase + 8 * g;
+  f32x4 accA = {0.f, 0.f, 0.f, 0.f}, accB = {0.f, 0.f, 0.f, 0.f};
+  constexpr int UN = 8;                           // k-steps in flight
+  for (int k0 = 0; k0 < kw; k0 += 32 * UN) {
+    u32x4 fa[UN], fb[UN], fx[UN];
+#pragma unroll
+    for (int s = 0; s < UN; ++s) {
+      const int k = k0 + 32 * s;
+      const bool ok = k < kw;
+      fa[s] = (ok && n_ok) ? ld_nt16(wa + k) : u32x4{0, 0, 0, 0};
+      if constexpr (EPI == EPI_SILU) fb[s] = (ok && n_ok) ? ld_nt16(wb + k) : u32x4{0, 0, 0, 0};
+      fx[s] = (ok && m_ok) ? ld16(xa + k) : u32x4{0, 0, 0, 0};
+    }
+#pragma unroll
+    for (int s = 0; s < UN; ++s) {
+      const zn_bf16x8 xf = __builtin_bit_cast(zn_bf16x8, fx[s]);
+      accA = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf, __builtin_bit_cast(zn_bf16x8, fa[s]), accA, 0, 0, 0);
+      if constexpr (EPI == EPI_SILU) accB = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf, __builtin_bit_cast(zn_bf16x8, fb[s]), accB, 0, 0, 0);
+    }
+  }
+  // C layout: col (weight row) = lane & 15, row (activation row) = 4*(lane>>4) + reg
+  __shared__ float s_t[NW][2][16][17];
+#pragma unroll
+  for (int reg = 0; reg < 4; ++reg) {
+    s_t[wave][0][4 * g + reg][n] = accA[reg];
+    if constexpr (EPI == EPI_SILU) s_t[wave][1][4 * g + reg][n] = accB[reg];
+  }
+  __syncthreads();
+  const int t = threadIdx.x;
+  if constexpr (EPI == EPI_SILU) {
+    if (t >= 256) return;
+    const int m = t >> 4, nn = t & 15;
+    if (m >= a.nrows || 16 * u + nn >= F) return;
+    float vA = 0.f, vB = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) { vA += s_t[w][0][m][nn]; vB += s_t[w][1][m][nn]; }
+    gemv_epilogue<EPI>(a, m, 16 * u + nn, F + 16 * u + nn, true, 16 * u + nn, vA, vB, 0u, 1.f, 0.f, 0);
+  } else {
+    if (t >= 128) return;
+    const int m = t >> 3, np = t & 7;
+    const int rowA = 16 * u + 2 * np, rowB = rowA + 1;
+    if (m >= a.nrows || rowA >= a.N) return;
+    const bool b_ok = rowB < a.N;
+    float vA = 0.f, vB = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) { vA += s_t[w][0][m][2 * np]; vB += s_t[w][0][m][2 * np + 1]; }
+    unsigned resid = 0; float cs = 1.f, sn = 0.f; int pos = 0;
+    if constexpr (EPI == EPI_RESID) {
+      const size_t o = (size_t)m * a.N + rowA;
+      resid = b_ok ? *(const unsigned*)(a.resid + o) : (unsigned)a.resid[o];
+    }
+    if constexpr (EPI == EPI_ROPE_KV) {
+      pos = a.lengths[m];
+      if (rowA < (a.n_heads + a.n_heads_kv) * a.hd) {
+        const int i = (rowA % a.hd) >> 1;
+        const int p = pos < a.rope_positions ? pos : a.rope_positions - 1;
+        const float2 c2 = *(const float2*)(a.rope + ((size_t)p * (a.hd >> 1) + i) * 2);
+        cs = c2.x; sn = c2.y;
       }
     }
+    gemv_epilogue<EPI>(a, m, rowA, rowB, b_ok, rowA >> 1, vA, vB, resid, cs, sn, pos);
   }
 }
 
