@@ -119,6 +119,9 @@ int zn_debug_force_eos(zn_handle h, int32_t step);
  * tokens_dev[k] (int32 [calls, B, n_codebooks], device) so that the EOS bookkeeping, frame writes and stop
  * cadence can be checked bit-exactly against the reference's recorded token stream.  NULL = off. */
 int zn_debug_token_override(zn_handle h, const int32_t* tokens_dev, int32_t calls);
+/* Test hook: 1 = batched prefill (default: MFMA GEMMs + tiled causal attention over all positions), 0 = position by
+ * position through the decode kernels (both reproduce the reference's rounding points). */
+int zn_debug_prefill_mode(zn_handle h, int32_t mode);
 /* Tuning hook: target workgroup count of a GEMV class (0 in_proj, 1 out_proj, 2 fc1, 3 fc2, 4 heads). */
 int zn_debug_tune(zn_handle h, int32_t key, int32_t value);
 /* Test/benchmark hook: add `bias` to the codebook-0 EOS logit on every step (-inf suppresses EOS so that all

@@ -64,6 +64,7 @@ SIGNATURES = {
     "zn_get_step_outputs": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "zn_debug_force_eos": (C.c_int, [C.c_void_p, C.c_int32]),
     "zn_debug_token_override": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),
+    "zn_debug_prefill_mode": (C.c_int, [C.c_void_p, C.c_int32]),
     "zn_debug_tune": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
     "zn_debug_eos_bias": (C.c_int, [C.c_void_p, C.c_float]),
     "zn_bench_kernel": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_double), C.c_void_p]),

@@ -2,9 +2,11 @@
 // workspace, launch geometry, hipGraph capture of one decode step.
 #include "../../include/zonos_hip.h"
 #include "zn_decode_kernels.h"
+#include "zn_prefill_kernels.h"
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -25,6 +27,9 @@ struct zn_handle_s {
   float *logits_raw = nullptr, *last_logits = nullptr;
   int* tok_raw = nullptr;
   float *scores = nullptr, *cmax = nullptr;
+  bf16_t *pf_x = nullptr, *pf_n = nullptr, *pf_qkv = nullptr, *pf_a = nullptr, *pf_u = nullptr, *pf_m = nullptr;   // batched-prefill workspace
+  size_t pf_rows = 0;
+  int prefill_mode = 1;     // 1 = batched (MFMA GEMMs + tiled attention), 0 = position by position through the decode kernels
   int lcap = 0;
   GenState* st = nullptr;
   int *remaining = nullptr, *stopping = nullptr;
@@ -79,7 +84,7 @@ static void free_graph(zn_handle h) {
 extern "C" int zn_destroy(zn_handle h) {
   if (!h) return ZN_OK;
   free_graph(h);
-  void* ptrs[] = {h->emb_tables_dev, h->x, h->q, h->o1, h->mbuf, h->nbuf, h->logits_raw, h->last_logits, h->tok_raw, h->scores, h->cmax, h->st, h->remaining, h->stopping};
+  void* ptrs[] = {h->emb_tables_dev, h->x, h->q, h->o1, h->mbuf, h->nbuf, h->logits_raw, h->last_logits, h->tok_raw, h->scores, h->cmax, h->pf_x, h->pf_n, h->pf_qkv, h->pf_a, h->pf_u, h->pf_m, h->st, h->remaining, h->stopping};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (h->done_host) (void)hipHostFree(h->done_host);
   if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
@@ -102,6 +107,7 @@ extern "C" int zn_create(const zn_config* cfg, const zn_weights* w, int32_t max_
   if (max_rows < 2 || max_rows % 2) ZN_FAIL((zn_handle) nullptr, ZN_ERR_ARG, "max_rows must be even and >= 2");
   zn_handle h = new zn_handle_s();
   h->cfg = c; h->max_rows = max_rows; h->hd = hd; h->G = G;
+  if (const char* e = getenv("ZN_PREFILL_MODE")) h->prefill_mode = atoi(e);
   h->layers.assign(w->layers, w->layers + c.n_layer);
   h->heads = w->heads; h->norm_f_w = w->norm_f_w; h->norm_f_b = w->norm_f_b; h->rope = w->rope_table;
 #define ZC(call) do { hipError_t _e = (call); if (_e != hipSuccess) { g_create_err = std::string(#call) + ": " + hipGetErrorString(_e); zn_destroy(h); return ZN_ERR_HIP; } } while (0)
@@ -384,7 +390,75 @@ extern "C" int zn_gen_begin(zn_handle h, int32_t batch, const void* const* kv_la
   return ZN_OK;
 }
 
-static int qsplit(int S) { return S >= 768 ? 256 : S >= 192 ? 64 : 32; }
+
+static int ensure_prefill_ws(zn_handle h, size_t M) {
+  if (M <= h->pf_rows) return ZN_OK;
+  const zn_config& c = h->cfg;
+  for (bf16_t** p : {&h->pf_x, &h->pf_n, &h->pf_qkv, &h->pf_a, &h->pf_u, &h->pf_m}) if (*p) { (void)hipFree(*p); *p = nullptr; }
+  h->pf_rows = 0;
+  const size_t nqkv = (size_t)(c.n_heads + 2 * c.n_heads_kv) * h->hd;
+  HIPCHK(h, hipMalloc(&h->pf_x, M * c.d_model * 2));
+  HIPCHK(h, hipMalloc(&h->pf_n, M * c.d_model * 2));
+  HIPCHK(h, hipMalloc(&h->pf_qkv, M * nqkv * 2));
+  HIPCHK(h, hipMalloc(&h->pf_a, M * (size_t)c.n_heads * h->hd * 2));
+  HIPCHK(h, hipMalloc(&h->pf_u, M * 2 * (size_t)c.d_ff * 2));
+  HIPCHK(h, hipMalloc(&h->pf_m, M * (size_t)c.d_ff * 2));
+  h->pf_rows = M;
+  return ZN_OK;
+}
+
+static void launch_gemm(const bf16_t* A, int lda, const bf16_t* W, bf16_t* out, int ldo, const bf16_t* resid, int M, int N, int K, hipStream_t s) {
+  GemmArgs g{A, W, out, resid, M, N, K, lda, ldo};
+  dim3 grid((N + 127) / 128, (M + 127) / 128);
+  if (resid) hipLaunchKernelGGL((gemm_bf16_kernel<1>), grid, dim3(256), 0, s, g);
+  else hipLaunchKernelGGL((gemm_bf16_kernel<0>), grid, dim3(256), 0, s, g);
+}
+
+template <int HD>
+static int launch_prefill_attn(const PrefillAttnArgs& a, int G, int R, hipStream_t s) {
+  switch (G) {
+#define ZN_PA(GG) case GG: hipLaunchKernelGGL((attn_prefill_kernel<HD, GG>), dim3((a.S + 64 / GG - 1) / (64 / GG), a.n_heads_kv, R), dim3(256), 0, s, a); return 0;
+    ZN_PA(1) ZN_PA(2) ZN_PA(4) ZN_PA(8)
+#undef ZN_PA
+  }
+  return -1;
+}
+
+static int qsplit(int S) { return S >= 768 ? 256 : S >= 192 ? 64 : 32; }   // query split of the CPU flash kernel
+
+// All S positions at once: row-wise kernels over M = R*S rows, MFMA GEMMs, tiled exact causal attention.
+static int prefill_batched(zn_handle h, const bf16_t* hidden, int S, hipStream_t s) {
+  const zn_config& c = h->cfg;
+  const int R = h->rows, M = R * S, d = c.d_model, hd = h->hd, nq = c.n_heads * hd, nkv = c.n_heads_kv * hd, nqkv = nq + 2 * nkv, F = c.d_ff;
+  int rc = ensure_prefill_ws(h, (size_t)M);
+  if (rc) return rc;
+  HIPCHK(h, hipMemcpyAsync(h->pf_x, hidden, (size_t)M * d * 2, hipMemcpyDeviceToDevice, s));
+  for (int li = 0; li < c.n_layer; ++li) {
+    const zn_layer_weights& lw = h->layers[li];
+    bf16_t* kv = (bf16_t*)h->kv_layers[li];
+    hipLaunchKernelGGL(layernorm_kernel, dim3(M), dim3(64), 0, s, h->pf_x, (const bf16_t*)lw.norm_w, (const bf16_t*)lw.norm_b, h->pf_n, d, c.norm_eps);
+    launch_gemm(h->pf_n, d, (const bf16_t*)lw.in_proj, h->pf_qkv, nqkv, nullptr, M, nqkv, d, s);
+    hipLaunchKernelGGL(rope_kv_rows_kernel, dim3(S, R), dim3(256), 0, s, h->pf_qkv, kv, h->rope, S, 0, h->max_len, c.n_heads, c.n_heads_kv, hd, c.rope_positions);
+    PrefillAttnArgs pa{};
+    pa.q = h->pf_qkv; pa.ldq = nqkv; pa.kv = kv; pa.out = h->pf_a; pa.ldo = nq; pa.S = S; pa.base = 0; pa.max_len = h->max_len;
+    pa.n_heads = c.n_heads; pa.n_heads_kv = c.n_heads_kv; pa.qsplit = qsplit(S); pa.scale = (float)(1.0 / std::sqrt((double)hd));
+    int r2 = hd == 128 ? launch_prefill_attn<128>(pa, h->G, R, s) : hd == 64 ? launch_prefill_attn<64>(pa, h->G, R, s) : launch_prefill_attn<32>(pa, h->G, R, s);
+    if (r2) ZN_FAIL(h, ZN_ERR_UNSUPPORTED, "prefill attention: unsupported group %d", h->G);
+    if (c.double_out_proj) {
+      launch_gemm(h->pf_a, nq, (const bf16_t*)lw.out_proj, h->pf_n, d, nullptr, M, d, nq, s);
+      launch_gemm(h->pf_n, d, (const bf16_t*)lw.out_proj, h->pf_x, d, h->pf_x, M, d, nq, s);
+    } else launch_gemm(h->pf_a, nq, (const bf16_t*)lw.out_proj, h->pf_x, d, h->pf_x, M, d, nq, s);
+    hipLaunchKernelGGL(layernorm_kernel, dim3(M), dim3(64), 0, s, h->pf_x, (const bf16_t*)lw.norm2_w, (const bf16_t*)lw.norm2_b, h->pf_n, d, c.norm_eps);
+    launch_gemm(h->pf_n, d, (const bf16_t*)lw.fc1, h->pf_u, 2 * F, nullptr, M, 2 * F, d, s);
+    hipLaunchKernelGGL(silu_mul_rows_kernel, dim3(M), dim3(256), 0, s, h->pf_u, h->pf_m, F);
+    launch_gemm(h->pf_m, F, (const bf16_t*)lw.fc2, h->pf_x, d, h->pf_x, M, d, F, s);
+  }
+  hipLaunchKernelGGL(gather_last_kernel, dim3(R), dim3(256), 0, s, h->pf_x, h->x, S, d);
+  hipLaunchKernelGGL(add_lengths_kernel, dim3(1), dim3(64 > R ? 64 : R), 0, s, h->lengths, R, S);
+  return ZN_OK;
+}
+
+extern "C" int zn_debug_prefill_mode(zn_handle h, int32_t mode) { if (!h) return ZN_ERR_ARG; h->prefill_mode = mode; return ZN_OK; }
 
 extern "C" int zn_prefill(zn_handle h, const void* hidden_dev, int32_t S, zn_stream stream) {
   if (!h) return ZN_ERR_ARG;
@@ -392,16 +466,20 @@ extern "C" int zn_prefill(zn_handle h, const void* hidden_dev, int32_t S, zn_str
   if (!hidden_dev || S < 1 || S > h->max_len) ZN_FAIL(h, ZN_ERR_ARG, "zn_prefill: bad S=%d (max_len %d)", S, h->max_len);
   hipStream_t s = (hipStream_t)stream;
   const zn_config& c = h->cfg;
-  // Position by position through the decode kernels.  Row-wise ops are independent of S; attention reproduces the
-  // reference's causal flash-attention blocking through `ext` = keys spanned by the query block of this position.
-  const int qb = qsplit(S);
   int rc;
-  for (int p = 0; p < S; ++p) {
-    hipLaunchKernelGGL(gather_pos_kernel, dim3(h->rows), dim3(256), 0, s, (const bf16_t*)hidden_dev, h->x, S, p, c.d_model);
-    int ext = (p / qb) * qb + qb; if (ext > S) ext = S;
-    for (int li = 0; li < c.n_layer; ++li)
-      if ((rc = layer_decode(h, li, h->x, (bf16_t*)h->kv_layers[li], h->max_len, h->lengths, nullptr, ext, h->rows, s))) return rc;
-    hipLaunchKernelGGL(add_lengths_kernel, dim3(1), dim3(64 > h->rows ? 64 : h->rows), 0, s, h->lengths, h->rows, 1);
+  if (h->prefill_mode == 1 && S > 1 && c.d_model % 32 == 0 && c.d_ff % 32 == 0) {
+    if ((rc = prefill_batched(h, (const bf16_t*)hidden_dev, S, s))) return rc;
+  } else {
+    // Position by position through the decode kernels.  Row-wise ops are independent of S; attention reproduces the
+    // reference's causal flash-attention blocking through `ext` = keys spanned by the query block of this position.
+    const int qb = qsplit(S);
+    for (int p = 0; p < S; ++p) {
+      hipLaunchKernelGGL(gather_pos_kernel, dim3(h->rows), dim3(256), 0, s, (const bf16_t*)hidden_dev, h->x, S, p, c.d_model);
+      int ext = (p / qb) * qb + qb; if (ext > S) ext = S;
+      for (int li = 0; li < c.n_layer; ++li)
+        if ((rc = layer_decode(h, li, h->x, (bf16_t*)h->kv_layers[li], h->max_len, h->lengths, nullptr, ext, h->rows, s))) return rc;
+      hipLaunchKernelGGL(add_lengths_kernel, dim3(1), dim3(64 > h->rows ? 64 : h->rows), 0, s, h->lengths, h->rows, 1);
+    }
   }
   if ((rc = heads_logits(h, h->x, h->rows, s))) return rc;
   HIPCHK(h, hipGetLastError());

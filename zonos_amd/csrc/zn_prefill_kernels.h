@@ -1,0 +1,241 @@
+// Batched prefill (S > 1): zonos/utilities/generation_utils.py:206-244 -> TorchZonosBackbone.forward with S positions.
+// Row-wise ops are the decode path's arithmetic applied to M = R*S rows; the dense contractions run on the bf16 matrix
+// cores (compute-bound here, unlike decode); attention reproduces the reference CPU flash kernel's per-row rounding
+// (512-key blocks, running max, fexp_u20 / libm exp split governed by the query block's key span, bf16 P).
+#pragma once
+#include "zn_common.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 zn_bf16x8p;
+
+// ------------------------------------------------------------------------------------------------ GEMM
+// out[M][N] = A[M][K] . W[N][K]^T  (bf16 in, fp32 accumulate, bf16 out; EPI 1: out = bf16(resid + bf16(acc))).
+// Workgroup tile 128 x 128, 4 waves as 2 x 2, each wave 64 x 64 = 4 x 4 tiles of v_mfma_f32_16x16x32_bf16.  Both
+// operands are K-contiguous, so a fragment is one 16-B load per lane (row = lane & 15, k-group = lane >> 4) straight
+// from L2: A panels are shared by the N/128 workgroups of a row, W panels by the M/128 of a column.
+struct GemmArgs {
+  const bf16_t* A; const bf16_t* W; bf16_t* out; const bf16_t* resid;
+  int M, N, K, lda, ldo;   // lda = row stride of A (elements), ldo = row stride of out / resid
+};
+template <int EPI>
+__global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs a) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int m0 = blockIdx.y * 128 + wm * 64, n0 = blockIdx.x * 128 + wn * 64;
+  const int fr = lane & 15, fg = lane >> 4;
+  const bf16_t* ap[4];
+  const bf16_t* wp[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = min(m0 + i * 16 + fr, a.M - 1), n = min(n0 + i * 16 + fr, a.N - 1);
+    ap[i] = a.A + (size_t)m * a.lda + 8 * fg;
+    wp[i] = a.W + (size_t)n * a.K + 8 * fg;
+  }
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  u32x4 fa[4], fw[4], na[4], nw[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { fa[i] = ld16(ap[i]); fw[i] = ld16(wp[i]); }
+  for (int k0 = 0; k0 < a.K; k0 += 32) {
+    const bool more = k0 + 32 < a.K;
+    if (more) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { na[i] = ld16(ap[i] + k0 + 32); nw[i] = ld16(wp[i] + k0 + 32); }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(zn_bf16x8p, fa[i]), __builtin_bit_cast(zn_bf16x8p, fw[j]), acc[i][j], 0, 0, 0);
+    if (more) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { fa[i] = na[i]; fw[i] = nw[i]; }
+    }
+  }
+  // C: col (n) = lane & 15, row (m) = 4 * (lane >> 4) + reg
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = n0 + j * 16 + fr;
+      if (n >= a.N) continue;
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int m = m0 + i * 16 + 4 * fg + reg;
+        if (m >= a.M) continue;
+        const size_t o = (size_t)m * a.ldo + n;
+        float v = bfround(acc[i][j][reg]);
+        if constexpr (EPI == 1) v = bf2f(a.resid[o]) + v;
+        a.out[o] = f2bf(v);
+      }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ row-wise pieces
+// q|k|v split, interleaved-pair RoPE (fp32, separate roundings) and KV append for all positions (_torch.py:399-411).
+// qkv [R][S][nq + 2*nkv]: q is rotated in place, k (rotated) and v go to the cache at position base + s.
+__global__ __launch_bounds__(256) void rope_kv_rows_kernel(bf16_t* qkv, bf16_t* kv, const float* rope, int S, int base, int max_len, int n_heads,
+                                                           int n_heads_kv, int hd, int rope_positions) {
+  const int s = blockIdx.x, r = blockIdx.y;
+  const int nq = n_heads * hd, nk = n_heads_kv * hd, ld = nq + 2 * nk;
+  const int pos = base + s;
+  const int p = pos < rope_positions ? pos : rope_positions - 1;
+  bf16_t* row = qkv + ((size_t)r * S + s) * ld;
+  for (int n = threadIdx.x * 2; n < ld; n += 512) {
+    const unsigned pr = *(const unsigned*)(row + n);
+    const float x0 = lo_f(pr), x1 = hi_f(pr);
+    if (n < nq + nk) {
+      const int i = (n % hd) >> 1;
+      const float cs = rope[((size_t)p * (hd >> 1) + i) * 2], sn = rope[((size_t)p * (hd >> 1) + i) * 2 + 1];
+      const unsigned o = pack2(__fsub_rn(__fmul_rn(x0, cs), __fmul_rn(x1, sn)), __fadd_rn(__fmul_rn(x1, cs), __fmul_rn(x0, sn)));
+      if (n < nq) *(unsigned*)(row + n) = o;
+      else if (pos < max_len) *(unsigned*)(kv + (((size_t)r * max_len + pos) * 2 + 0) * nk + (n - nq)) = o;
+    } else if (pos < max_len) {
+      *(unsigned*)(kv + (((size_t)r * max_len + pos) * 2 + 1) * nk + (n - nq - nk)) = pr;
+    }
+  }
+}
+// m = y * silu(gate) with bf16 roundings after silu and mul (_torch.py:473-474); u [M][2F] -> m [M][F]
+__global__ __launch_bounds__(256) void silu_mul_rows_kernel(const bf16_t* u, bf16_t* m, int F) {
+  const size_t row = blockIdx.x;
+  for (int i = threadIdx.x * 2; i < F; i += 512) {
+    const unsigned y = *(const unsigned*)(u + row * 2 * F + i), g = *(const unsigned*)(u + row * 2 * F + F + i);
+    const float g0 = lo_f(g), g1 = hi_f(g);
+    const float s0 = bfround(g0 / (1.0f + expf(-g0))), s1 = bfround(g1 / (1.0f + expf(-g1)));
+    *(unsigned*)(m + row * F + i) = pack2(lo_f(y) * s0, hi_f(y) * s1);
+  }
+}
+__global__ void gather_last_kernel(const bf16_t* xP, bf16_t* x, int S, int d) {
+  const int r = blockIdx.x;
+  for (int k = threadIdx.x * 8; k < d; k += blockDim.x * 8) *(u32x4*)(x + (size_t)r * d + k) = *(const u32x4*)(xP + ((size_t)r * S + S - 1) * d + k);
+}
+
+// ------------------------------------------------------------------------------------------------ causal attention
+// One workgroup = 64 (position, head) rows of one (sequence row r, kv head): 64/G consecutive positions x G heads; wave w
+// owns rows 16w..16w+15, lane = (row, key quarter): the 4 lanes of a row split every staged 64-key chunk.  K and V chunks
+// are staged in LDS (padded rows) and reused by all 64 rows.  Each 512-key block takes two passes over its chunks:
+// pass 1 = row max, pass 2 = recompute the scores, e/P with the reference's rounding, P.V — so no score buffer.
+struct PrefillAttnArgs {
+  const bf16_t* q; int ldq;     // rows (r*S + s), head h at column h*HD
+  const bf16_t* kv;             // [R][max_len][2][Hkv][HD]
+  bf16_t* out; int ldo;
+  int S, base, max_len, n_heads, n_heads_kv, qsplit;
+  float scale;
+};
+template <int HD, int G>
+__global__ __launch_bounds__(256) void attn_prefill_kernel(PrefillAttnArgs a) {
+  constexpr int TQ = 64 / G;              // positions per workgroup
+  constexpr int KP = HD + 8;              // padded LDS row (bf16 elements): 16 B of padding breaks the 256-B bank period
+  constexpr int NQ = HD / 8;              // 16-B pieces per head row
+  __shared__ __attribute__((aligned(16))) bf16_t s_k[64 * KP];
+  __shared__ __attribute__((aligned(16))) bf16_t s_v[64 * KP];
+  const int s0 = blockIdx.x * TQ, kvh = blockIdx.y, r = blockIdx.z;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int rw = lane & 15, kq = lane >> 4;
+  const int row = wave * 16 + rw;                     // 0..63
+  const int s = s0 + row / G, g = row % G;
+  const bool row_ok = s < a.S;
+  const int L_row = row_ok ? a.base + s + 1 : 0;      // keys this row may see
+  const int Lmax = a.base + min(s0 + TQ, a.S);
+  const int sq = row_ok ? s : s0;
+  const int E = a.base + min((sq / a.qsplit) * a.qsplit + a.qsplit, a.S);   // keys spanned by this row's query block in the reference
+  u32x4 qv[NQ];
+  {
+    const bf16_t* qp = a.q + ((size_t)r * a.S + (row_ok ? s : a.S - 1)) * a.ldq + (size_t)(kvh * G + g) * HD;
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) qv[i] = ld16(qp + 8 * i);
+  }
+  float acc[HD];
+#pragma unroll
+  for (int d = 0; d < HD; ++d) acc[d] = 0.f;
+  float lsum = 0.f, m_run = -INFINITY;
+  const size_t kvrow = (size_t)2 * a.n_heads_kv * HD;
+  const bf16_t* kg = a.kv + (size_t)r * a.max_len * kvrow + (size_t)kvh * HD;
+  const bf16_t* vg = kg + (size_t)a.n_heads_kv * HD;
+
+  for (int t0 = 0; t0 < Lmax; t0 += 512) {
+    const int nch = min(8, (Lmax - t0 + 63) / 64);
+    const int nblk = min(512, E - t0), nvec = nblk & ~15;
+    // ---------------- pass 1: block max of this row
+    float mx = -INFINITY;
+    for (int c = 0; c < nch; ++c) {
+      __syncthreads();
+      for (int i = tid; i < 64 * NQ; i += 256) {
+        const int key = i / NQ, pc = i % NQ, t = t0 + c * 64 + key;
+        *(u32x4*)(s_k + key * KP + 8 * pc) = (t < Lmax) ? ld16(kg + (size_t)t * kvrow + 8 * pc) : u32x4{0, 0, 0, 0};
+      }
+      __syncthreads();
+#pragma unroll 4
+      for (int kk = 0; kk < 16; ++kk) {
+        const int key = kq * 16 + kk, t = t0 + c * 64 + key;
+        float dsum = 0.f;
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) dsum = dot8(*(const u32x4*)(s_k + key * KP + 8 * i), qv[i], dsum);
+        const float sc = __fmul_rn(dsum, a.scale);
+        if (t < L_row) mx = fmaxf(mx, sc);
+      }
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 16));
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float mnew = fmaxf(m_run, mx);
+    const float f = (t0 == 0) ? 0.f : expf(m_run - mnew);
+    m_run = mnew;
+    lsum = __fmul_rn(lsum, f);
+#pragma unroll
+    for (int d = 0; d < HD; ++d) acc[d] = __fmul_rn(acc[d], f);
+    // ---------------- pass 2: e / P / P.V
+    for (int c = 0; c < nch; ++c) {
+      __syncthreads();
+      for (int i = tid; i < 64 * NQ; i += 256) {
+        const int key = i / NQ, pc = i % NQ, t = t0 + c * 64 + key;
+        const bool ok = t < Lmax;
+        *(u32x4*)(s_k + key * KP + 8 * pc) = ok ? ld16(kg + (size_t)t * kvrow + 8 * pc) : u32x4{0, 0, 0, 0};
+        *(u32x4*)(s_v + key * KP + 8 * pc) = ok ? ld16(vg + (size_t)t * kvrow + 8 * pc) : u32x4{0, 0, 0, 0};
+      }
+      __syncthreads();
+      for (int kk = 0; kk < 16; ++kk) {
+        const int key = kq * 16 + kk, idx = c * 64 + key, t = t0 + idx;
+        if (__all(t >= L_row)) continue;               // wave-uniform skip of fully masked keys
+        float dsum = 0.f;
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) dsum = dot8(*(const u32x4*)(s_k + key * KP + 8 * i), qv[i], dsum);
+        float e = 0.f;
+        if (t < L_row) { const float x = __fsub_rn(__fmul_rn(dsum, a.scale), mnew); e = (idx < nvec) ? zn_fexp_u20(x) : expf(x); }
+        lsum += e;
+        const float p = bfround(e);
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) {
+          const u32x4 v = *(const u32x4*)(s_v + key * KP + 8 * i);
+          acc[8 * i + 0] = fmaf(p, lo_f(v.x), acc[8 * i + 0]); acc[8 * i + 1] = fmaf(p, hi_f(v.x), acc[8 * i + 1]);
+          acc[8 * i + 2] = fmaf(p, lo_f(v.y), acc[8 * i + 2]); acc[8 * i + 3] = fmaf(p, hi_f(v.y), acc[8 * i + 3]);
+          acc[8 * i + 4] = fmaf(p, lo_f(v.z), acc[8 * i + 4]); acc[8 * i + 5] = fmaf(p, hi_f(v.z), acc[8 * i + 5]);
+          acc[8 * i + 6] = fmaf(p, lo_f(v.w), acc[8 * i + 6]); acc[8 * i + 7] = fmaf(p, hi_f(v.w), acc[8 * i + 7]);
+        }
+      }
+    }
+  }
+  // combine the 4 key quarters of each row (lanes l, l+16, l+32, l+48), normalise, store
+  lsum += __shfl_xor(lsum, 16);
+  lsum += __shfl_xor(lsum, 32);
+  const float rl = 1.0f / lsum;
+  bf16_t* op = a.out + ((size_t)r * a.S + (row_ok ? s : 0)) * a.ldo + (size_t)(kvh * G + g) * HD;
+#pragma unroll
+  for (int i = 0; i < NQ; ++i) {
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float x = acc[8 * i + e];
+      x += __shfl_xor(x, 16);
+      x += __shfl_xor(x, 32);
+      v[e] = __fmul_rn(x, rl);
+    }
+    // piece i is stored by key-quarter lane (i & 3): spreads the 16-B stores over the 4 lanes of the row
+    if (row_ok && kq == (i & 3)) {
+      u32x4 o;
+      o.x = pack2(v[0], v[1]); o.y = pack2(v[2], v[3]); o.z = pack2(v[4], v[5]); o.w = pack2(v[6], v[7]);
+      *(u32x4*)(op + 8 * i) = o;
+    }
+  }
+}
