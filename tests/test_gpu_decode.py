@@ -396,3 +396,85 @@ def test_prefill_batched_and_positionwise_vs_oracle(tiny, P):
         print(f"\n[prefill P={P} {name}] max|dlogit| {d.max():.4g}, exact {np.mean(d == 0):.4f}, argmax equal {same.mean():.3f}")
         assert d.max() <= 0.06, (mode, P, d.max())
         assert same[decisive].all()
+
+
+def test_embed_codes_bit_exact_vs_oracle(tiny):
+    """K1 (codec_utils.py:37): sequential bf16 adds over the 9 codebooks, incl. EOS (1024) and MASK (1025) rows."""
+    model, w, _ = tiny
+    codes = torch.from_numpy(synth.randint(21, "embed.codes", (3, 9, 11), 1026))
+    codes[0, :, 0] = 1025
+    codes[1, 0, 3] = 1024
+    got = model.embed_codes(codes.to("cuda:0")).cpu()
+    ref = zo.embed_codes(w, codes)
+    assert got.shape == ref.shape and torch.equal(got.view(torch.int16), ref.view(torch.int16))
+
+
+def test_long_context_teacher_forced_vs_oracle(tiny):
+    """Decode across the 512- and 1024-key block boundaries of the attention (context grows from 7 to ~1150): HIP logits
+    vs the oracle under teacher forcing, every 64th step compared; tolerance 0.06, decisive argmax equal."""
+    model, w, cond = tiny
+    N = 1140
+    otr = zo.GenTrace()
+    ref_out = zo.generate(w, synth.TINY_CFG, cond, max_new_tokens=N, sampling_params=GREEDY, trace=otr,
+                          logits_hook=lambda s, l: l.index_fill(2, torch.tensor([1024]), -float("inf")) if s >= 0 else l)
+    # the oracle's per-step inputs = delayed codes; rebuild them from its raw tokens through the override hook
+    toks = torch.stack(otr.tokens).numpy()            # [calls, 1, 9]
+    eng = model.engine(1)
+    eng.call("zn_debug_eos_bias", float("-inf"))
+    tk = torch.from_numpy(toks.astype(np.int32)).to("cuda:0").contiguous()
+    eng.call("zn_debug_token_override", tk.data_ptr(), tk.shape[0])
+    try:
+        tr = {"logits": []}
+        out = model.generate(cond.to("cuda:0"), max_new_tokens=N, sampling_params=GREEDY, _trace=tr)
+    finally:
+        eng.call("zn_debug_token_override", None, 0)
+        eng.call("zn_debug_eos_bias", 0.0)
+    assert torch.equal(out.cpu(), ref_out)
+    worst, checked = 0.0, 0
+    for k in list(range(0, len(otr.logits), 64)) + [len(otr.logits) - 1, 510, 511, 512, 513, 1023, 1024, 1025]:
+        if k >= len(otr.logits):
+            continue
+        a, b = tr["logits"][k].cpu().numpy(), otr.logits[k].numpy()
+        fin = np.isfinite(b)
+        d = np.abs(np.where(fin, a - b, 0.0)).max()
+        worst = max(worst, float(d))
+        t2 = np.sort(np.where(fin, b, -1e30), -1)[..., -2:]
+        dec = (t2[..., 1] - t2[..., 0]) > 0.15
+        assert (np.where(fin, a, -1e30).argmax(-1) == np.where(fin, b, -1e30).argmax(-1))[dec].all(), k
+        checked += 1
+    print(f"\n[long context] {checked} steps compared up to context {7 + N + 8}; worst |dlogit| {worst:.4g}")
+    assert worst <= 0.06
+
+
+def test_callback_stop_and_seeded_sampling(tiny):
+    model, w, cond = tiny
+    calls = []
+
+    def cb(frame, step, max_steps):
+        calls.append((step, max_steps))
+        return step < 5                      # model.py:508: returning False stops the loop
+
+    out = model.generate(cond.to("cuda:0"), max_new_tokens=40, sampling_params=GREEDY, callback=cb)
+    ref = zo.generate(w, synth.TINY_CFG, cond, max_new_tokens=40, sampling_params=GREEDY, callback=lambda f, s, m: s < 5)
+    assert calls[0] == (1, 48) and len(calls) == 5 and out.shape == ref.shape
+    sp = dict(min_p=0.1)                     # the reference's default sampling_params (model.py:362)
+    a = model.generate(cond.to("cuda:0"), max_new_tokens=30, sampling_params=sp, seed=7).cpu()
+    b = model.generate(cond.to("cuda:0"), max_new_tokens=30, sampling_params=sp, seed=7).cpu()
+    c = model.generate(cond.to("cuda:0"), max_new_tokens=30, sampling_params=sp, seed=8).cpu()
+    assert torch.equal(a, b) and a.shape[:2] == (1, 9) and int(a.min()) >= 0 and int(a.max()) <= 1023
+    assert a.shape != c.shape or not torch.equal(a, c)
+    app = dict(top_p=0.9, top_k=200, min_p=0.02, linear=0.5, conf=0.4, quad=0.0)    # audio_generation_pipeline.py:151-158
+    d = model.generate(cond.to("cuda:0"), max_new_tokens=30, sampling_params=app, seed=3).cpu()
+    assert d.shape[:2] == (1, 9) and int(d.min()) >= 0 and int(d.max()) <= 1023
+
+
+def test_errors_are_reported_not_crashes(tiny):
+    model, _, cond = tiny
+    with pytest.raises(AssertionError):
+        model.generate(cond.to("cuda:0"), max_new_tokens=4, cfg_scale=1.0)                # model.py:399
+    with pytest.raises(ValueError):
+        model.generate(cond[:1].to("cuda:0"), max_new_tokens=4)                          # rows != 2 * batch_size
+    with pytest.raises(TypeError):
+        model.generate(cond.to("cuda:0"), max_new_tokens=4, sampling_params=dict(bogus=1))
+    with pytest.raises(_lib.ZonosHipError):                                              # beyond the 16384-row RoPE table (_torch.py:206)
+        model.generate(cond.to("cuda:0"), max_new_tokens=16400, sampling_params=GREEDY)

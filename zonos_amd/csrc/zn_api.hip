@@ -370,6 +370,8 @@ extern "C" int zn_gen_begin(zn_handle h, int32_t batch, const void* const* kv_la
   if (batch < 1 || 2 * batch > h->max_rows) ZN_FAIL(h, ZN_ERR_ARG, "zn_gen_begin: batch %d exceeds max_rows %d / 2", batch, h->max_rows);
   if (max_len < 1 || t_total < 1 || offset0 < 1 || offset0 >= t_total) ZN_FAIL(h, ZN_ERR_ARG, "zn_gen_begin: bad lengths");
   if (cfg_scale == 1.0f) ZN_FAIL(h, ZN_ERR_ARG, "cfg_scale == 1 is not supported (zonos/model.py:399)");
+  if (max_len > h->cfg.rope_positions)
+    ZN_FAIL(h, ZN_ERR_ARG, "sequence length %d exceeds the %d-position RoPE table (zonos/backbone/_torch.py:206)", max_len, h->cfg.rope_positions);
   if (sp->repetition_penalty_window < 0 || sp->repetition_penalty_window > 64) ZN_FAIL(h, ZN_ERR_ARG, "repetition_penalty_window out of range");
   hipStream_t s = (hipStream_t)stream;
   int rc = ensure_attn_ws(h, max_len);
