@@ -139,6 +139,15 @@ int zn_bench_kernel(zn_handle h, int32_t which, int32_t rows, int32_t iters, flo
 /* nn.LayerNorm + nn.Linear(no bias): out[r,n] = bf16(sum_k LN(x)[r,k] W[n,k]); ln_w == NULL skips the norm. */
 int zn_op_linear(zn_handle h, const void* x_dev, const void* ln_w, const void* ln_b, const void* W_dev,
                  void* out_dev, int32_t rows, int32_t N, int32_t K, zn_stream stream);
+/* Prefix-conditioner pieces (zonos/conditioning.py): nn.Linear with bias (Conditioner.project, :52-60; bias added in fp32
+ * before the one bf16 rounding), nn.Embedding row gather (:364-365,467), FourierConditioner.apply_cond (:436-441), nn.SiLU. */
+int zn_op_linear_bias(zn_handle h, const void* x_dev, const void* W_dev, const void* bias_dev, void* out_dev, int32_t rows,
+                      int32_t N, int32_t K, zn_stream stream);
+int zn_op_gather_rows(zn_handle h, const void* table_dev, const int32_t* ids_dev, void* out_dev, int32_t n, int32_t d,
+                      int32_t table_rows, int32_t id_offset, zn_stream stream);
+int zn_op_fourier(zn_handle h, const float* x_dev, const void* weight_dev, void* out_dev, int32_t n, int32_t in_dim,
+                  int32_t half, float min_val, float max_val, zn_stream stream);
+int zn_op_silu(zn_handle h, const void* x_dev, void* out_dev, int64_t n, zn_stream stream);
 /* nn.LayerNorm (_torch.py:155 norm_f): bf16 [rows, d] -> bf16 [rows, d], fp32 statistics. */
 int zn_op_layernorm(zn_handle h, const void* x_dev, const void* w_dev, const void* b_dev, void* out_dev, int32_t rows,
                     int32_t d, zn_stream stream);

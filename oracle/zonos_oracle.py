@@ -327,6 +327,56 @@ def generate(w: dict, cfg: dict, prefix_conditioning: torch.Tensor, audio_prefix
     return torch.clamp(out[..., :valid], 0, 1023)                               # model.py:531-539
 
 
+# --------------------------------------------------------------------------- prefix conditioner (zonos/conditioning.py)
+def _cond_project(pw: dict, prefix: str, kind: str, x: torch.Tensor) -> torch.Tensor:
+    """conditioning.py:52-60 Conditioner.project: none | Linear | Linear-SiLU-Linear."""
+    if kind == "linear":
+        return F.linear(x, pw[prefix + "project.weight"], pw[prefix + "project.bias"])
+    if kind == "mlp":
+        h = F.silu(F.linear(x, pw[prefix + "project.0.weight"], pw[prefix + "project.0.bias"]))
+        return F.linear(h, pw[prefix + "project.2.weight"], pw[prefix + "project.2.bias"])
+    return x
+
+
+def prefix_conditioner_forward(pw: dict, conditioners: list, projection: str, cond_dict: dict, d: int) -> torch.Tensor:
+    """conditioning.py:513-522 over :364-365 (phoneme embedding of token ids), :436-441 (Fourier features in the
+    weight's dtype), :467 (integer embedding), :476 (passthrough), :104-109 (learned unconditional vector when the key
+    is absent).  `cond_dict["espeak"]` holds token ids [B, S] (tokenisation/phonemisation is outside the numeric path)."""
+    conds = []
+    for i, c in enumerate(conditioners):
+        p = f"conditioners.{i}."
+        v = cond_dict.get(c["name"])
+        if v is None:
+            conds.append(pw[p + "uncond_vector"].view(1, 1, -1))
+            continue
+        if c["type"] == "EspeakPhonemeConditioner":
+            e = F.embedding(v, pw[p + "phoneme_embedder.weight"])
+        elif c["type"] == "FourierConditioner":
+            w = pw[p + "weight"]
+            mn, mx = c.get("min_val", 0.0), c.get("max_val", 1.0)
+            x = (v - mn) / (mx - mn)
+            f = 2 * torch.pi * x.to(w.dtype) @ w.T
+            e = torch.cat([f.cos(), f.sin()], dim=-1)
+        elif c["type"] == "IntegerConditioner":
+            e = F.embedding(v.squeeze(-1) - c.get("min_val", 0), pw[p + "int_embedder.weight"])
+        else:
+            e = v
+        conds.append(_cond_project(pw, p, c.get("projection", "none"), e))
+    bsz = max(len(c) for c in conds)
+    x = torch.cat([c.expand(bsz, -1, -1) for c in conds], dim=-2)
+    return F.layer_norm(_cond_project(pw, "", projection, x), (d,), pw["norm.weight"], pw["norm.bias"], 1e-5)
+
+
+def prepare_conditioning(pw: dict, conditioners: list, projection: str, cond_dict: dict, d: int, cfg_scale: float = 2.0) -> torch.Tensor:
+    """conditioning_cache.py:165-171: [cond ‖ uncond], uncond = only the keys without a learned unconditional vector."""
+    if cfg_scale == 1.0:
+        return prefix_conditioner_forward(pw, conditioners, projection, cond_dict, d)
+    required = {c["name"] for c in conditioners if c.get("uncond_type") != "learned"}
+    uncond = {k: cond_dict[k] for k in required}
+    return torch.cat([prefix_conditioner_forward(pw, conditioners, projection, cond_dict, d),
+                      prefix_conditioner_forward(pw, conditioners, projection, uncond, d)])
+
+
 # --------------------------------------------------------------------------- DAC decode
 def snake(x: torch.Tensor, alpha: torch.Tensor) -> torch.Tensor:
     """modeling_dac.py:98 — x + (alpha + 1e-9)^-1 * sin(alpha x)^2, alpha [1,C,1]."""

@@ -130,7 +130,7 @@ def bf16_bits(t):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="tiny,full,ops,sampling,eos,dac,peaky")
+    ap.add_argument("--only", default="tiny,full,ops,sampling,eos,dac,peaky,cond")
     args = ap.parse_args()
     only = set(args.only.split(","))
     torch.manual_seed(0)
@@ -202,6 +202,34 @@ def main():
         c = gen_case(zm, model, cond, 160, keep=(0, 1, 100))
         np.savez_compressed(f"{HERE}/full_gen_peaky.npz", seed=seed, l_c=24, max_new=160, **c)
         print("peaky done")
+
+    if "cond" in only:
+        # reference PrefixConditioner (zonos/conditioning.py) with the transformer's conditioner list, bf16, synthetic weights;
+        # phonemisation (external espeak) is bypassed: the phoneme strings are given
+        import zonos.conditioning as zc
+        from zonos.config import PrefixConditionerConfig
+        out = {}
+        for d, seed, projection in ((128, 77, "none"), (2048, 1234, "none"), (128, 78, "mlp")):
+            pc = zc.PrefixConditioner(PrefixConditionerConfig(list(synth.TRANSFORMER_CONDITIONERS), projection), d).to(torch.bfloat16)
+            sd = synth.conditioner_state_dict(synth.TRANSFORMER_CONDITIONERS, d, seed, projection)
+            pc.load_state_dict(sd, strict=True)
+            phon = "h@l'oU w'3:ld, tEst!"
+            zc.phonemize = lambda texts, languages, _p=phon: [_p for _ in texts]
+            spk = torch.from_numpy(synth.normal(seed, "cond.speaker", (1, 1, 128))).to(torch.bfloat16)
+            cd = zc.make_cond_dict(text="ignored", language="en-us", speaker=spk, emotion=[0.5, 0.05, 0.05, 0.05, 0.05, 0.05, 0.1, 0.15],
+                                   fmax=22050.0, pitch_std=45.0, speaking_rate=13.0, device="cpu")
+            from zonos.utilities.conditioning_cache import prepare_conditioning_with_cache
+            with torch.inference_mode():
+                full = prepare_conditioning_with_cache(pc, cd, None, False, 2.0, None)
+            tag = f"d{d}_{projection}"
+            out[tag] = bf16_bits(full)
+            out[tag + "_ids"] = zc.tokenize_phonemes([phon])[0].numpy()
+            out[tag + "_seed"] = seed
+            out[tag + "_emotion"] = cd["emotion"].numpy()
+            out[tag + "_langid"] = cd["language_id"].numpy()
+        out["phonemes"] = np.array(phon)
+        np.savez_compressed(f"{HERE}/conditioner.npz", **out)
+        print("cond done")
 
     if "sampling" in only:
         import zonos.sampling as zs

@@ -69,6 +69,10 @@ SIGNATURES = {
     "zn_debug_eos_bias": (C.c_int, [C.c_void_p, C.c_float]),
     "zn_bench_kernel": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_double), C.c_void_p]),
     "zn_op_linear": (C.c_int, [C.c_void_p] + [C.c_void_p] * 5 + [C.c_int32] * 3 + [C.c_void_p]),
+    "zn_op_linear_bias": (C.c_int, [C.c_void_p] * 5 + [C.c_int32] * 3 + [C.c_void_p]),
+    "zn_op_gather_rows": (C.c_int, [C.c_void_p] * 4 + [C.c_int32] * 4 + [C.c_void_p]),
+    "zn_op_fourier": (C.c_int, [C.c_void_p] * 4 + [C.c_int32] * 3 + [C.c_float, C.c_float, C.c_void_p]),
+    "zn_op_silu": (C.c_int, [C.c_void_p] * 3 + [C.c_int64, C.c_void_p]),
     "zn_op_layernorm": (C.c_int, [C.c_void_p] * 5 + [C.c_int32, C.c_int32, C.c_void_p]),
     "zn_op_layer_decode": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
     "zn_op_attn_decode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),

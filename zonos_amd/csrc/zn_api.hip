@@ -3,6 +3,7 @@
 #include "../../include/zonos_hip.h"
 #include "zn_decode_kernels.h"
 #include "zn_prefill_kernels.h"
+#include "zn_cond_kernels.h"
 
 #include <cmath>
 #include <cstdio>
@@ -635,6 +636,49 @@ extern "C" int zn_op_linear(zn_handle h, const void* x, const void* ln_w, const 
     rc = run_gemv<PRO_LN, EPI_STORE>(h, a, rows, 1024, (hipStream_t)stream);
   } else rc = run_gemv<PRO_NONE, EPI_STORE>(h, a, rows, 1024, (hipStream_t)stream);
   if (rc) return rc;
+  HIPCHK(h, hipGetLastError());
+  return ZN_OK;
+}
+
+extern "C" int zn_op_linear_bias(zn_handle h, const void* x, const void* W, const void* bias, void* out, int32_t rows, int32_t N, int32_t K, zn_stream stream) {
+  if (!h) return ZN_ERR_ARG;
+  if (!x || !W || !out || rows < 1 || N < 1 || K < 8 || K % 8) ZN_FAIL(h, ZN_ERR_ARG, "zn_op_linear_bias: bad argument");
+  GemvArgs a{};
+  a.W = (const bf16_t*)W; a.N = N; a.K = K; a.x = (const bf16_t*)x; a.out = (bf16_t*)out; a.bias = (const bf16_t*)bias; a.eps = h->cfg.norm_eps;
+  hipStream_t s = (hipStream_t)stream;
+  for (int r0 = 0; r0 < rows; r0 += 4) {      // always the GEMV (its epilogue carries the bias); rows are few here
+    GemvArgs g = a;
+    g.x = a.x + (size_t)r0 * K; g.out = a.out + (size_t)r0 * N;
+    int rc = run_gemv<PRO_NONE, EPI_STORE>(h, g, rows - r0 < 4 ? rows - r0 : 4, 1024, s);
+    if (rc) return rc;
+  }
+  HIPCHK(h, hipGetLastError());
+  return ZN_OK;
+}
+
+extern "C" int zn_op_gather_rows(zn_handle h, const void* table, const int32_t* ids, void* out, int32_t n, int32_t d, int32_t table_rows, int32_t id_offset,
+                                 zn_stream stream) {
+  if (!h) return ZN_ERR_ARG;
+  if (!table || !ids || !out || n < 1 || d < 8 || d % 8 || table_rows < 1) ZN_FAIL(h, ZN_ERR_ARG, "zn_op_gather_rows: bad argument");
+  hipLaunchKernelGGL(gather_rows_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)table, ids, (bf16_t*)out, d, table_rows, id_offset);
+  HIPCHK(h, hipGetLastError());
+  return ZN_OK;
+}
+
+extern "C" int zn_op_fourier(zn_handle h, const float* x, const void* weight, void* out, int32_t n, int32_t in_dim, int32_t half, float min_val, float max_val,
+                             zn_stream stream) {
+  if (!h) return ZN_ERR_ARG;
+  if (!x || !weight || !out || n < 1 || in_dim < 1 || half < 1 || !(max_val > min_val)) ZN_FAIL(h, ZN_ERR_ARG, "zn_op_fourier: bad argument");
+  hipLaunchKernelGGL(fourier_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, x, (const bf16_t*)weight, (bf16_t*)out, in_dim, half, min_val, max_val);
+  HIPCHK(h, hipGetLastError());
+  return ZN_OK;
+}
+
+extern "C" int zn_op_silu(zn_handle h, const void* x, void* out, int64_t n, zn_stream stream) {
+  if (!h) return ZN_ERR_ARG;
+  if (!x || !out || n < 1) ZN_FAIL(h, ZN_ERR_ARG, "zn_op_silu: bad argument");
+  const int blocks = (int)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
+  hipLaunchKernelGGL(silu_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)out, (size_t)n);
   HIPCHK(h, hipGetLastError());
   return ZN_OK;
 }

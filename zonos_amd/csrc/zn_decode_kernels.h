@@ -23,6 +23,7 @@ struct GemvArgs {
   // epilogue
   bf16_t* out;           // bf16 [rows][N] (EPI_SILU: [rows][N/2])
   const bf16_t* resid;   // EPI_RESID
+  const bf16_t* bias;    // EPI_STORE: optional nn.Linear bias, added in fp32 before the single bf16 rounding
   float* out_f32;        // EPI_F32 [rows][N]
   // EPI_ROPE_KV
   bf16_t* q_out;         // [rows][Hq*hd]
@@ -37,6 +38,7 @@ template <int EPI>
 ZN_DEVINL void gemv_epilogue(const GemvArgs& a, int r, int rowA, int rowB, bool b_ok, int u, float vA, float vB, unsigned resid, float cs,
                              float sn, int pos) {
   if constexpr (EPI == EPI_STORE) {
+    if (a.bias) { vA += bf2f(a.bias[rowA]); if (b_ok) vB += bf2f(a.bias[rowB]); }
     if (b_ok) *(unsigned*)(a.out + (size_t)r * a.N + rowA) = pack2(vA, vB);
     else a.out[(size_t)r * a.N + rowA] = f2bf(vA);
   } else if constexpr (EPI == EPI_F32) {

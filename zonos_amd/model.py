@@ -18,6 +18,7 @@ from . import _lib
 from .autoencoder import DACAutoencoder
 from .backbone import BACKBONES, HipEngine
 from .codebook_pattern import apply_delay_pattern, revert_delay_pattern
+from .conditioning import ConditioningCache, PrefixConditioner, prepare_conditioning_with_cache
 from .config import InferenceParams, ZonosConfig
 from .utils import DEFAULT_DEVICE, find_multiple
 
@@ -46,7 +47,9 @@ class Zonos(nn.Module):
         self.masked_token_id = config.masked_token_id
         self.autoencoder = autoencoder if autoencoder is not None else DACAutoencoder()
         self.backbone = backbone_cls(config.backbone)
-        self.prefix_conditioner = None   # text/speaker conditioners: SURVEY.md §8f "next" row 1
+        self.prefix_conditioner = PrefixConditioner(config.prefix_conditioner, dim)
+        self.prefix_conditioner.attach(lambda: self.engine(1))
+        self._conditioning_cache = ConditioningCache(max_size=32)
         vocab_size = find_multiple(1026, 8)  # 1024 codes + EOS + MASK, padded to 1032 (model.py:79-80)
         self.embeddings = nn.ModuleList([nn.Embedding(vocab_size, dim) for _ in range(self.autoencoder.num_codebooks)])
         self.fused_heads = nn.Linear(dim, self.autoencoder.num_codebooks * 1025, bias=False)
@@ -95,8 +98,6 @@ class Zonos(nn.Module):
                 ws.append(state_dict.pop(f"{prefix}heads.{i}.weight"))
                 i += 1
             state_dict[f"{prefix}fused_heads.weight"] = torch.cat(ws, dim=0)
-        for k in [k for k in state_dict if k.startswith(f"{prefix}prefix_conditioner.")]:
-            state_dict.pop(k)     # conditioner weights are not consumed yet
         super()._load_from_state_dict(state_dict, prefix, *args)
 
     def _apply(self, fn, *a, **k):
@@ -136,9 +137,11 @@ class Zonos(nn.Module):
         eng.call("zn_op_linear", x.data_ptr(), None, None, self.fused_heads.weight.data_ptr(), out.data_ptr(), B * S, nq * 1025, d, _lib.stream_ptr())
         return out.view(B, S, nq, 1025).transpose(1, 2)
 
-    def prepare_conditioning(self, cond_dict: dict, uncond_dict: dict | None = None, use_cache: bool = False, cfg_scale: float = 1.0):
-        raise NotImplementedError("prefix conditioner (zonos/conditioning.py) is the next row after the hot path "
-                                  "(SURVEY.md §8f #1); pass precomputed prefix_conditioning [2B, L_c, d] to generate()")
+    @torch.inference_mode()
+    def prepare_conditioning(self, cond_dict: dict, uncond_dict: dict | None = None, use_cache: bool = False, cfg_scale: float = 1.0) -> torch.Tensor:
+        """model.py:237-265 -> conditioning_cache.py:139-193: [2B or B, L_c, d] bf16 ([cond ‖ uncond] when cfg_scale != 1)."""
+        return prepare_conditioning_with_cache(self.prefix_conditioner, cond_dict=cond_dict, uncond_dict=uncond_dict, use_cache=use_cache,
+                                               cfg_scale=cfg_scale, cache=self._conditioning_cache if use_cache else None)
 
     def setup_cache(self, batch_size: int, max_seqlen: int, dtype: torch.dtype = torch.bfloat16) -> InferenceParams:
         """model.py:305-338: length rounded to x8, bf16 KV per layer, lengths_per_sample int32 zeros."""

@@ -140,6 +140,52 @@ def conditioning(seed: int, name: str, rows: int, l_c: int, d: int, dtype=torch.
     return _t(normal(seed, name, (rows, l_c, d)), dtype)
 
 
+# ------------------------------------------------------------------ prefix conditioner
+# Conditioner list of Zonos-v0.1-transformer as documented in the reference's CONDITIONING_README.md:3-75
+TRANSFORMER_CONDITIONERS = [
+    {"type": "EspeakPhonemeConditioner", "name": "espeak"},
+    {"type": "PassthroughConditioner", "name": "speaker", "cond_dim": 128, "uncond_type": "learned", "projection": "linear"},
+    {"type": "FourierConditioner", "name": "emotion", "input_dim": 8, "uncond_type": "learned"},
+    {"type": "FourierConditioner", "name": "fmax", "min_val": 0, "max_val": 24000, "uncond_type": "learned"},
+    {"type": "FourierConditioner", "name": "pitch_std", "min_val": 0, "max_val": 400, "uncond_type": "learned"},
+    {"type": "FourierConditioner", "name": "speaking_rate", "min_val": 0, "max_val": 40, "uncond_type": "learned"},
+    {"type": "IntegerConditioner", "name": "language_id", "min_val": -1, "max_val": 126, "uncond_type": "learned"},
+]
+N_PHONEME_TOKENS = 4 + 185       # special tokens + symbol table (zonos/conditioning.py:225-240)
+
+
+def conditioner_state_dict(conditioners: list, d: int, seed: int = 1234, projection: str = "none", dtype=torch.bfloat16) -> dict:
+    """Synthetic weights of a PrefixConditioner under the reference's module names (zonos/conditioning.py:506-511)."""
+    sd = {}
+
+    def lin(prefix, cin, cout):
+        sd[prefix + "weight"] = _t(uniform(seed, "cond." + prefix + "weight", (cout, cin), 1.0 / np.sqrt(cin)), dtype)
+        sd[prefix + "bias"] = _t(uniform(seed, "cond." + prefix + "bias", (cout,), 1.0 / np.sqrt(cin)), dtype)
+
+    def proj(prefix, kind, cin):
+        if kind == "linear":
+            lin(prefix + "project.", cin, d)
+        elif kind == "mlp":
+            lin(prefix + "project.0.", cin, d)
+            lin(prefix + "project.2.", d, d)
+
+    for i, c in enumerate(conditioners):
+        p = f"conditioners.{i}."
+        if c["type"] == "EspeakPhonemeConditioner":
+            sd[p + "phoneme_embedder.weight"] = _t(normal(seed, "cond." + p + "phoneme_embedder", (N_PHONEME_TOKENS, d)), dtype)
+        elif c["type"] == "FourierConditioner":
+            sd[p + "weight"] = _t(normal(seed, "cond." + p + "weight", (d // 2, c.get("input_dim", 1)), c.get("std", 1.0)), dtype)
+        elif c["type"] == "IntegerConditioner":
+            sd[p + "int_embedder.weight"] = _t(normal(seed, "cond." + p + "int_embedder", (c.get("max_val", 512) - c.get("min_val", 0) + 1, d)), dtype)
+        proj(p, c.get("projection", "none"), c.get("cond_dim") or d)
+        if c.get("uncond_type") == "learned":
+            sd[p + "uncond_vector"] = _t(normal(seed, "cond." + p + "uncond_vector", (d,)), dtype)
+    proj("", projection, d)
+    sd["norm.weight"] = _t(1.0 + uniform(seed, "cond.norm.weight", (d,), 0.1), dtype)
+    sd["norm.bias"] = _t(uniform(seed, "cond.norm.bias", (d,), 0.1), dtype)
+    return sd
+
+
 # ------------------------------------------------------------------ DAC decoder weights
 
 def dac_decoder_spec(hidden=1024, dec_hidden=1536, ratios=(8, 8, 4, 2), n_codebooks=9,

@@ -9,18 +9,20 @@ from .config import BackboneConfig, PrefixConditionerConfig, ZonosConfig
 from .model import Zonos
 
 
-def zonos_config(cfg: dict) -> ZonosConfig:
+def zonos_config(cfg: dict, conditioners: list | None = None, projection: str = "none") -> ZonosConfig:
     return ZonosConfig(BackboneConfig(d_model=cfg["d_model"], n_layer=cfg["n_layer"], attn_mlp_d_intermediate=cfg["d_ff"],
                                       attn_layer_idx=list(range(cfg["n_layer"])),
                                       attn_cfg=dict(num_heads=cfg["num_heads"], num_heads_kv=cfg["num_heads_kv"])),
-                       PrefixConditionerConfig([], "none"))
+                       PrefixConditionerConfig(list(conditioners or []), projection))
 
 
-def build_model(cfg: dict, seed: int, device="cuda", dac: DACAutoencoder | None = None, peaky: bool = False):
+def build_model(cfg: dict, seed: int, device="cuda", dac: DACAutoencoder | None = None, peaky: bool = False, conditioners: list | None = None,
+                projection: str = "none"):
     """Returns (model on `device`, CPU state dict).  The state dict uses the reference's key contract."""
     sd = synth.zonos_state_dict(cfg, seed, peaky=peaky)
+    sd.update({"prefix_conditioner." + k: v for k, v in synth.conditioner_state_dict(conditioners or [], cfg["d_model"], seed, projection).items()})
     with torch.device("meta"):
-        model = Zonos(zonos_config(cfg), autoencoder=dac or DACAutoencoder())
+        model = Zonos(zonos_config(cfg, conditioners, projection), autoencoder=dac or DACAutoencoder())
     model.load_state_dict({k: v for k, v in sd.items()}, assign=True, strict=True)
     model = model.to(device)
     return model.eval(), sd
