@@ -183,13 +183,16 @@ def test_forced_eos_output_length_matches_reference(golden_dir, tiny):
         eng.lib.zn_debug_force_eos(eng.h, -1)
 
 
-def test_attention_decode_vs_cpu_sdpa(full):
+@pytest.mark.parametrize("fused_limit", [2048, 1], ids=["fused-launch", "two-pass"])
+def test_attention_decode_vs_cpu_sdpa(full, fused_limit):
     """zn_op_attn_decode vs torch CPU SDPA (the op the reference calls at _torch.py:415) on random bf16 q/K/V at
     L = 1..1500: bit-equal fraction must exceed 0.99 (the kernel reproduces the 512-key blocking, fexp_u20 /
-    libm exp split, bf16 P and reciprocal-multiply of the CPU flash kernel; residual = fp32 summation order)."""
+    libm exp split, bf16 P and reciprocal-multiply of the CPU flash kernel; residual = fp32 summation order).
+    Both launch shapes: the fused one (scores in LDS via MFMA, short KV capacities) and scores + P.V passes."""
     import torch.nn.functional as F
     model, _ = full
     eng = model.engine(1)
+    eng.call("zn_debug_tune", 5, fused_limit)
     st = _lib.stream_ptr()
     gen = torch.Generator().manual_seed(0)
     for L in (1, 5, 16, 17, 31, 300, 512, 513, 530, 900, 1500):
@@ -207,6 +210,7 @@ def test_attention_decode_vs_cpu_sdpa(full):
         eq = float((got.view(torch.int16) == r.contiguous().view(torch.int16)).float().mean())
         print(f"\n[attn L={L}] bit-equal {eq:.5f} max|d| {(got.float() - r.float()).abs().max().item():.3g}")
         assert eq > 0.99, (L, eq)
+    eng.call("zn_debug_tune", 5, 448)
 
 
 def test_layer0_decode_vs_reference_block(golden_dir, full):

@@ -44,13 +44,16 @@ struct zn_handle_s {
   int *lengths = nullptr, *codes = nullptr;
   int force_eos_step = -1;
   float eos_bias = 0.f;
-  int tune[8] = {512, 512, 512, 1024, 256, 0, 0, 0};   // target workgroups: in_proj, out_proj, fc1, fc2, heads
+  int tune[8] = {512, 512, 512, 1024, 256, 448, 0, 0};   // target workgroups: in_proj, out_proj, fc1, fc2, heads; [5] longest context of the fused attention launch
   const int* tok_override = nullptr;
   int tok_override_calls = 0;
   hipStream_t cap_stream = nullptr;
-  hipGraphExec_t graph_exec = nullptr;
-  hipGraph_t graph = nullptr;
-  bool graph_tried = false;
+  // one captured decode step per attention launch shape: [1] = fused single launch (short contexts), [0] = two passes
+  hipGraphExec_t graph_exec[2] = {nullptr, nullptr};
+  hipGraph_t graph[2] = {nullptr, nullptr};
+  bool graph_tried[2] = {false, false};
+  int len_hi = 0;            // host-side upper bound of the rows' KV lengths (keys already cached)
+  bool attn_fused = false;   // launch shape of the next run_attention
   std::string err;
 };
 
@@ -77,9 +80,11 @@ extern "C" size_t zn_kv_bytes_per_layer(const zn_config* c, int32_t rows, int32_
 }
 
 static void free_graph(zn_handle h) {
-  if (h->graph_exec) { (void)hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; }
-  if (h->graph) { (void)hipGraphDestroy(h->graph); h->graph = nullptr; }
-  h->graph_tried = false;
+  for (int k = 0; k < 2; ++k) {
+    if (h->graph_exec[k]) { (void)hipGraphExecDestroy(h->graph_exec[k]); h->graph_exec[k] = nullptr; }
+    if (h->graph[k]) { (void)hipGraphDestroy(h->graph[k]); h->graph[k] = nullptr; }
+    h->graph_tried[k] = false;
+  }
 }
 
 extern "C" int zn_destroy(zn_handle h) {
@@ -233,11 +238,19 @@ static int run_gemv(zn_handle h, GemvArgs a, int rows, int target_blocks, hipStr
   return ZN_OK;
 }
 
+// fused attention launch iff no row can hold more than tune[5] keys after this call (LDS score buffer: ZN_AFUSED_MAX)
+static bool attn_fused_for(zn_handle h, int keys_upper_bound) {
+  const int lim = h->tune[5] < ZN_AFUSED_MAX ? h->tune[5] : ZN_AFUSED_MAX;
+  return keys_upper_bound <= lim;
+}
+
 template <int HD>
-static int launch_attn_g(const AttnArgs& a, int G, dim3 grid, hipStream_t s) {
+static int launch_attn_g(const AttnArgs& a, int G, dim3 grid, bool fused, hipStream_t s) {
   switch (G) {
-#define ZN_ATTN_CASE(GG) case GG: hipLaunchKernelGGL((attn_scores_kernel<HD, GG>), grid, dim3(256), 0, s, a); \
-                                  hipLaunchKernelGGL((attn_pv_kernel<HD, GG>), dim3(HD / 32, grid.y, grid.z), dim3(512), 0, s, a); return 0;
+#define ZN_ATTN_CASE(GG) case GG: \
+    if (fused) { hipLaunchKernelGGL((attn_pv_kernel<HD, GG, true>), dim3((HD / 32) * grid.y * grid.z), dim3(512), 0, s, a); return 0; } \
+    hipLaunchKernelGGL((attn_scores_kernel<HD, GG>), grid, dim3(256), 0, s, a); \
+    hipLaunchKernelGGL((attn_pv_kernel<HD, GG, false>), dim3(HD / 32, grid.y, grid.z), dim3(512), 0, s, a); return 0;
     ZN_ATTN_CASE(1) ZN_ATTN_CASE(2) ZN_ATTN_CASE(4) ZN_ATTN_CASE(8)
 #undef ZN_ATTN_CASE
   }
@@ -264,10 +277,13 @@ static int run_attention(zn_handle h, const bf16_t* q, const bf16_t* kv, int max
   AttnArgs a{};
   a.q = q; a.kv = kv; a.lengths = lengths; a.ext = ext; a.ext_scalar = ext_scalar; a.max_len = max_len;
   a.n_heads = c.n_heads; a.n_heads_kv = c.n_heads_kv; a.lcap = h->lcap; a.scale = (float)(1.0 / std::sqrt((double)h->hd));
-  a.scores = h->scores; a.cmax = h->cmax; a.out = out;
+  a.scores = h->scores; a.cmax = h->cmax; a.out = out; a.rows = rows;
   const int hd = h->hd;
   dim3 grid((max_len + ZN_ACHUNK - 1) / ZN_ACHUNK, c.n_heads_kv, rows);
-  int r2 = hd == 128 ? launch_attn_g<128>(a, h->G, grid, s) : hd == 64 ? launch_attn_g<64>(a, h->G, grid, s) : launch_attn_g<32>(a, h->G, grid, s);
+  // one fused launch for short contexts (the caller bounds the context: h->attn_fused), two passes beyond
+  const bool fused = h->attn_fused;
+  int r2 = hd == 128 ? launch_attn_g<128>(a, h->G, grid, fused, s) : hd == 64 ? launch_attn_g<64>(a, h->G, grid, fused, s)
+                                                                             : launch_attn_g<32>(a, h->G, grid, fused, s);
   if (r2) ZN_FAIL(h, ZN_ERR_UNSUPPORTED, "attention: unsupported group %d", h->G);
   return ZN_OK;
 }
@@ -388,7 +404,11 @@ extern "C" int zn_gen_begin(zn_handle h, int32_t batch, const void* const* kv_la
   std::vector<int> rem(batch, t_total - offset0), stop(batch, 0);   // model.py:439-441
   HIPCHK(h, hipMemcpyAsync(h->remaining, rem.data(), batch * sizeof(int), hipMemcpyHostToDevice, s));
   HIPCHK(h, hipMemcpyAsync(h->stopping, stop.data(), batch * sizeof(int), hipMemcpyHostToDevice, s));
+  std::vector<int> len0(2 * batch, 0);
+  HIPCHK(h, hipMemcpyAsync(len0.data(), lengths_dev, 2 * batch * sizeof(int), hipMemcpyDeviceToHost, s));
   HIPCHK(h, hipStreamSynchronize(s));  // host vectors go out of scope
+  h->len_hi = 0;
+  for (int v : len0) if (v > h->len_hi) h->len_hi = v;
   h->gen_active = true;
   return ZN_OK;
 }
@@ -472,6 +492,7 @@ extern "C" int zn_prefill(zn_handle h, const void* hidden_dev, int32_t S, zn_str
   int rc;
   if (h->prefill_mode == 1 && S > 1 && c.d_model % 32 == 0 && c.d_ff % 32 == 0) {
     if ((rc = prefill_batched(h, (const bf16_t*)hidden_dev, S, s))) return rc;
+    h->len_hi += S;
   } else {
     // Position by position through the decode kernels.  Row-wise ops are independent of S; attention reproduces the
     // reference's causal flash-attention blocking through `ext` = keys spanned by the query block of this position.
@@ -479,6 +500,7 @@ extern "C" int zn_prefill(zn_handle h, const void* hidden_dev, int32_t S, zn_str
     for (int p = 0; p < S; ++p) {
       hipLaunchKernelGGL(gather_pos_kernel, dim3(h->rows), dim3(256), 0, s, (const bf16_t*)hidden_dev, h->x, S, p, c.d_model);
       int ext = (p / qb) * qb + qb; if (ext > S) ext = S;
+      h->attn_fused = attn_fused_for(h, ++h->len_hi);
       for (int li = 0; li < c.n_layer; ++li)
         if ((rc = layer_decode(h, li, h->x, (bf16_t*)h->kv_layers[li], h->max_len, h->lengths, nullptr, ext, h->rows, s))) return rc;
       hipLaunchKernelGGL(add_lengths_kernel, dim3(1), dim3(64 > h->rows ? 64 : h->rows), 0, s, h->lengths, h->rows, 1);
@@ -512,29 +534,31 @@ extern "C" int zn_decode_steps(zn_handle h, int32_t n, zn_stream stream) {
   if (!h->gen_active) ZN_FAIL(h, ZN_ERR_STATE, "zn_decode_steps before zn_gen_begin");
   if (n < 0) ZN_FAIL(h, ZN_ERR_ARG, "n < 0");
   hipStream_t s = (hipStream_t)stream;
-  if (!h->graph_exec && !h->graph_tried && n > 1) {
-    // capture one step; every step-varying quantity (column, positions) is read from device memory
-    h->graph_tried = true;
-    // capture on an internal stream: the caller's stream may be the legacy null stream, which cannot be captured
-    if (!h->cap_stream) (void)hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking);
-    hipStream_t cs = h->cap_stream;
-    if (cs && hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal) == hipSuccess) {
-      int rc = enqueue_step(h, cs);
-      hipGraph_t g = nullptr;
-      hipError_t e = hipStreamEndCapture(cs, &g);
-      if (rc == ZN_OK && e == hipSuccess && g && hipGraphInstantiate(&h->graph_exec, g, nullptr, nullptr, 0) == hipSuccess) h->graph = g;
-      else { if (g) (void)hipGraphDestroy(g); h->graph_exec = nullptr; (void)hipGetLastError(); }
-    } else (void)hipGetLastError();
-  }
   for (int i = 0; i < n; ++i) {
-    if (h->graph_exec) HIPCHK(h, hipGraphLaunch(h->graph_exec, s));
+    const int k = attn_fused_for(h, ++h->len_hi) ? 1 : 0;   // this step appends one key per row
+    h->attn_fused = k != 0;
+    if (!h->graph_exec[k] && !h->graph_tried[k] && n > 1) {
+      // capture one step; every step-varying quantity (column, positions) is read from device memory
+      h->graph_tried[k] = true;
+      // capture on an internal stream: the caller's stream may be the legacy null stream, which cannot be captured
+      if (!h->cap_stream) (void)hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking);
+      hipStream_t cs = h->cap_stream;
+      if (cs && hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+        int rc = enqueue_step(h, cs);
+        hipGraph_t g = nullptr;
+        hipError_t e = hipStreamEndCapture(cs, &g);
+        if (rc == ZN_OK && e == hipSuccess && g && hipGraphInstantiate(&h->graph_exec[k], g, nullptr, nullptr, 0) == hipSuccess) h->graph[k] = g;
+        else { if (g) (void)hipGraphDestroy(g); h->graph_exec[k] = nullptr; (void)hipGetLastError(); }
+      } else (void)hipGetLastError();
+    }
+    if (h->graph_exec[k]) HIPCHK(h, hipGraphLaunch(h->graph_exec[k], s));
     else { int rc = enqueue_step(h, s); if (rc) return rc; }
   }
   HIPCHK(h, hipGetLastError());
   return ZN_OK;
 }
 
-extern "C" int zn_graph_active(zn_handle h) { return (h && h->graph_exec) ? 1 : 0; }
+extern "C" int zn_graph_active(zn_handle h) { return (h && (h->graph_exec[0] || h->graph_exec[1])) ? 1 : 0; }
 
 extern "C" int zn_all_stopped(zn_handle h, int32_t* out, zn_stream stream) {
   if (!h || !out) return ZN_ERR_ARG;
@@ -699,6 +723,7 @@ extern "C" int zn_op_layer_decode(zn_handle h, int32_t layer, void* x, void* kv,
     ZN_FAIL(h, ZN_ERR_ARG, "zn_op_layer_decode: bad argument");
   int rc = ensure_attn_ws(h, max_len);
   if (rc) return rc;
+  h->attn_fused = attn_fused_for(h, max_len);   // lengths live on the device: bound the context by the capacity
   rc = layer_decode(h, layer, (bf16_t*)x, (bf16_t*)kv, max_len, lengths, ext, 0, rows, (hipStream_t)stream);
   if (rc) return rc;
   HIPCHK(h, hipGetLastError());
@@ -712,6 +737,7 @@ extern "C" int zn_op_attn_decode(zn_handle h, const void* q, const void* kv, int
   if (rows > h->max_rows) ZN_FAIL(h, ZN_ERR_ARG, "zn_op_attn_decode: rows > max_rows");
   int rc = ensure_attn_ws(h, max_len);
   if (rc) return rc;
+  h->attn_fused = attn_fused_for(h, max_len);
   rc = run_attention(h, (const bf16_t*)q, (const bf16_t*)kv, max_len, lengths, ext, 0, (bf16_t*)out, rows, (hipStream_t)stream);
   if (rc) return rc;
   HIPCHK(h, hipGetLastError());

@@ -352,6 +352,7 @@ struct AttnArgs {
   const int* ext;       // optional int32 [rows]: keys the reference's block loop spans (prefill emulation)
   int ext_scalar;       // used when ext == NULL and > 0
   int max_len, n_heads, n_heads_kv, lcap;   // lcap = scores row stride (multiple of 512)
+  int rows;             // activation rows (fused variant's 1-D grid decode)
   float scale;
   float* scores;        // [rows][Hq][lcap]
   float* cmax;          // [rows][Hq][lcap/64]   per-64-key-chunk maxima
@@ -367,8 +368,9 @@ __global__ __launch_bounds__(256) void attn_scores_kernel(AttnArgs a) {
   constexpr int PPW = 64 / LPP;    // keys per wave-wide load
   constexpr int NKL = 16 / PPW;    // loads per wave (16 keys per wave)
   const int chunk = blockIdx.x, kvh = blockIdx.y, r = blockIdx.z;
-  const int L = a.lengths[r] + 1;
-  if (chunk * ZN_ACHUNK >= L) return;
+  // The length is requested first and every other request is issued before it is needed (addresses clamped to the
+  // cache capacity, results masked at use): one memory round trip on the launch-bound chain instead of two.
+  const int Lraw = a.lengths[r];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int sub = lane % LPP, grp = lane / LPP;
   const size_t kvrow = (size_t)2 * a.n_heads_kv * HD;
@@ -377,12 +379,14 @@ __global__ __launch_bounds__(256) void attn_scores_kernel(AttnArgs a) {
 #pragma unroll
   for (int i = 0; i < NKL; ++i) {
     const int t = chunk * ZN_ACHUNK + wave * 16 + i * PPW + grp;
-    kk[i] = u32x4{0, 0, 0, 0};
-    if (t < L) kk[i] = ld16(kbase + (size_t)t * kvrow);
+    kk[i] = ld16(kbase + (size_t)min(t, a.max_len - 1) * kvrow);
   }
   u32x4 qv[G];
 #pragma unroll
   for (int g = 0; g < G; ++g) qv[g] = ld16(a.q + ((size_t)r * a.n_heads + kvh * G + g) * HD + sub * 8);
+  __builtin_amdgcn_sched_barrier(0);
+  const int L = Lraw + 1;
+  if (chunk * ZN_ACHUNK >= L) return;
   float mx[G];
 #pragma unroll
   for (int g = 0; g < G; ++g) mx[g] = -INFINITY;
@@ -413,21 +417,33 @@ __global__ __launch_bounds__(256) void attn_scores_kernel(AttnArgs a) {
 // running max taken from the chunk maxima of pass 1), forms e/P with the reference's rounding, accumulates P.V on its
 // value columns and writes the final bf16 output — no cross-workgroup partials, no combine launch.  V is read as
 // 64-B row pieces (L x 64 B per workgroup, ~58 KB at 10 s of context).
-template <int HD, int G>
+//
+// FUSED (contexts up to ZN_AFUSED_MAX keys, i.e. every step of a 10-20 s utterance): the same workgroup first computes
+// the scores of ALL keys of its kv head into LDS (identical arithmetic to attn_scores_kernel; the HD/32 slice
+// workgroups of one (row, kv head) repeat it, and the 1-D grid puts them on one XCD so that K comes from that XCD's
+// L2 after the first touch) and then runs pass 2 from LDS: one launch instead of two on the latency-bound chain.
+#define ZN_AFUSED_MAX 2048
+template <int HD, int G, bool FUSED>
 __global__ __launch_bounds__(512) void attn_pv_kernel(AttnArgs a) {
   constexpr int NW = 8;                                   // waves per workgroup; 16 keys per wave-load -> 128 keys per round
   constexpr int NR = 512 / (NW * 16);                     // rounds per 512-key block
   constexpr int GL = (G + 3) / 4;                         // heads a lane evaluates: g = vsub + 4*q
-  const int slice = blockIdx.x, kvh = blockIdx.y, r = blockIdx.z;
-  const int L = a.lengths[r] + 1;
-  int E = a.ext ? a.ext[r] : (a.ext_scalar > 0 ? a.ext_scalar : L);
-  if (E < L) E = L;
+  int slice, kvh, r;
+  if constexpr (FUSED) {
+    // blockIdx.x = pair + npairs * slice with pair = r * Hkv + kvh: with 8 (row, kv head) pairs the slices of a pair
+    // share blockIdx.x % 8, i.e. one XCD under round-robin placement (speed only, never correctness)
+    const int npairs = a.n_heads_kv * a.rows;
+    const int pair = blockIdx.x % npairs;
+    slice = blockIdx.x / npairs; kvh = pair % a.n_heads_kv; r = pair / a.n_heads_kv;
+  } else { slice = blockIdx.x; kvh = blockIdx.y; r = blockIdx.z; }
+  // length (and span) first; the first block's requests below do not wait for them (clamped addresses, masked use)
+  const int Lraw = a.lengths[r];
+  const int Eraw = a.ext ? a.ext[r] : a.ext_scalar;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int vsub = lane & 3, vkey = lane >> 2;           // 4 lanes x 16 B cover the 32-wide slice; 16 keys per wave-load
   const size_t kvrow = (size_t)2 * a.n_heads_kv * HD;
   const bf16_t* vbase = a.kv + (size_t)r * a.max_len * kvrow + (size_t)(a.n_heads_kv + kvh) * HD + slice * 32 + vsub * 8;
   const int cstride = a.lcap / ZN_ACHUNK;
-  const int nchunks = (L + ZN_ACHUNK - 1) / ZN_ACHUNK, nb = (L + 511) >> 9;
   // this lane evaluates e only for heads vsub, vsub+4, ... and quad-broadcasts them (DPP); P.V needs all G heads
   const float* srow[GL];
   const float* crow[GL];
@@ -437,6 +453,21 @@ __global__ __launch_bounds__(512) void attn_pv_kernel(AttnArgs a) {
     srow[q] = a.scores + ((size_t)r * a.n_heads + kvh * G + g) * a.lcap;
     crow[q] = a.cmax + ((size_t)r * a.n_heads + kvh * G + g) * cstride;
   }
+  u32x4 vnext[NR];
+  float scn[FUSED ? 1 : NR][GL], cmn[GL];
+#pragma unroll
+  for (int i = 0; i < NR; ++i) {
+    const int idx = i * (NW * 16) + wave * 16 + vkey;
+    vnext[i] = ld16(vbase + (size_t)min(idx, a.max_len - 1) * kvrow);
+    if constexpr (!FUSED) {
+#pragma unroll
+      for (int q = 0; q < GL; ++q) scn[i][q] = srow[q][idx];          // idx < 512 <= lcap
+    }
+  }
+  if constexpr (!FUSED) {
+#pragma unroll
+    for (int q = 0; q < GL; ++q) cmn[q] = crow[q][lane >> 3];         // chunk < 8 <= lcap / 64
+  }
   float acc[G][8], lsum[GL], m_run[GL];
 #pragma unroll
   for (int g = 0; g < G; ++g)
@@ -444,23 +475,117 @@ __global__ __launch_bounds__(512) void attn_pv_kernel(AttnArgs a) {
     for (int e = 0; e < 8; ++e) acc[g][e] = 0.f;
 #pragma unroll
   for (int q = 0; q < GL; ++q) { lsum[q] = 0.f; m_run[q] = -INFINITY; }
+  int L, nb;
+  __shared__ float s_sc[FUSED ? G : 1][FUSED ? ZN_AFUSED_MAX : 1];
+  __shared__ float s_bm[FUSED ? ZN_AFUSED_MAX / 512 : 1][NW][FUSED ? G : 1];
+  if constexpr (FUSED) {
+    // ---- pass 1 in LDS: scores of all keys on the matrix cores, S[head][key] = Q K^T as 16x16x32 tiles (A = the G
+    // query heads padded to 16 rows, B = 16 keys; lane = (row/col l&15, k-group l>>4); D: col = key l&15, row = head
+    // 4*(l>>4)+reg), fp32 accumulate, then the reference's fp32 scale; per-wave maxima of each 512-key block.
+    static_assert(HD % 32 == 0 && G <= 16, "fused attention tile shape");
+    constexpr int KST = HD / 32;                                  // MFMA steps over the head dimension
+    constexpr int TPW = 512 / 16 / NW;                            // 16-key tiles per wave per 512-key block
+    const int kn = lane & 15, kg = lane >> 4;
+    zn_bf16x8 qa[KST];
+#pragma unroll
+    for (int st = 0; st < KST; ++st) {
+      u32x4 v = u32x4{0, 0, 0, 0};
+      if (kn < G) v = ld16(a.q + ((size_t)r * a.n_heads + kvh * G + kn) * HD + 32 * st + 8 * kg);
+      qa[st] = __builtin_bit_cast(zn_bf16x8, v);
+    }
+    const bf16_t* kbase = a.kv + (size_t)r * a.max_len * kvrow + (size_t)kvh * HD + 8 * kg;
+    typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+    u32x4 kk[TPW][KST];
+#pragma unroll
+    for (int tl = 0; tl < TPW; ++tl) {                               // block 0, before the length is known
+      const bf16_t* kp = kbase + (size_t)min((tl * NW + wave) * 16 + kn, a.max_len - 1) * kvrow;
+#pragma unroll
+      for (int st = 0; st < KST; ++st) kk[tl][st] = ld16(kp + 32 * st);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    L = Lraw + 1; nb = (L + 511) >> 9;
+    for (int j = 0; j < nb; ++j) {
+      float mx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+      const int tb = j * 512, tend = min(L, tb + 512);
+      if (j > 0) {
+#pragma unroll
+        for (int tl = 0; tl < TPW; ++tl) {
+          const int t = tb + (tl * NW + wave) * 16 + kn;
+          const bf16_t* kp = kbase + (size_t)min(t, L - 1) * kvrow;   // clamped, not masked: no exec branch between the loads
+#pragma unroll
+          for (int st = 0; st < KST; ++st) kk[tl][st] = ld16(kp + 32 * st);
+        }
+      }
+#pragma unroll
+      for (int tl = 0; tl < TPW; ++tl) {
+        const int tt = tb + (tl * NW + wave) * 16;
+        if (tt < tend) {                                          // wave-uniform
+          f32x4_t c = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int st = 0; st < KST; ++st) c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa[st], __builtin_bit_cast(zn_bf16x8, kk[tl][st]), c, 0, 0, 0);
+          const int t = tt + kn;
+#pragma unroll
+          for (int reg = 0; reg < 4; ++reg) {
+            const int head = 4 * kg + reg;
+            if (head < G && t < tend) {
+              const float sv = __fmul_rn(c[reg], a.scale);
+              mx[reg] = fmaxf(mx[reg], sv);
+              s_sc[head][t] = sv;
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        const float m = wave_max(kg == g / 4 ? mx[g % 4] : -INFINITY);
+        if (lane == 0) s_bm[j][wave][g] = m;
+      }
+    }
+    __syncthreads();
+  } else {
+    __builtin_amdgcn_sched_barrier(0);
+    L = Lraw + 1; nb = (L + 511) >> 9;
+  }
+  int E = Eraw > 0 ? Eraw : L;
+  if (E < L) E = L;
+  const int nchunks = (L + ZN_ACHUNK - 1) / ZN_ACHUNK;
   for (int j = 0; j < nb; ++j) {
     const int t0 = j * 512;
     const int nkeys = min(512, L - t0);
-    // requests of this block: chunk maxima, 4 value pieces and 4*GL scores per lane
+    // this block's chunk maxima, 4 value pieces and 4*GL scores per lane were requested one block ahead
     float cm[GL];
-#pragma unroll
-    for (int q = 0; q < GL; ++q) { const int c = 8 * j + (lane >> 3); cm[q] = (c < nchunks && (lane >> 3) < 8) ? crow[q][c] : -INFINITY; }
     u32x4 vv[NR];
     float sc[NR][GL];
+#pragma unroll
+    for (int q = 0; q < GL; ++q) {
+      if constexpr (FUSED) cm[q] = s_bm[j][lane >> 3][min(vsub + 4 * q, G - 1)];
+      else cm[q] = (8 * j + (lane >> 3) < nchunks) ? cmn[q] : -INFINITY;
+    }
 #pragma unroll
     for (int i = 0; i < NR; ++i) {
       const int idx = i * (NW * 16) + wave * 16 + vkey;
       const bool ok = idx < nkeys;
-      vv[i] = u32x4{0, 0, 0, 0};
-      if (ok) vv[i] = ld16(vbase + (size_t)(t0 + idx) * kvrow);
+      vv[i] = ok ? vnext[i] : u32x4{0, 0, 0, 0};
 #pragma unroll
-      for (int q = 0; q < GL; ++q) sc[i][q] = ok ? srow[q][t0 + idx] : 0.f;
+      for (int q = 0; q < GL; ++q) {
+        if constexpr (FUSED) sc[i][q] = ok ? s_sc[min(vsub + 4 * q, G - 1)][t0 + idx] : 0.f;
+        else sc[i][q] = ok ? scn[i][q] : 0.f;
+      }
+    }
+    if (j + 1 < nb) {                                     // next block's requests fly during this block's arithmetic
+#pragma unroll
+      for (int i = 0; i < NR; ++i) {
+        const int nidx = t0 + 512 + i * (NW * 16) + wave * 16 + vkey;
+        vnext[i] = ld16(vbase + (size_t)min(nidx, L - 1) * kvrow);
+        if constexpr (!FUSED) {
+#pragma unroll
+          for (int q = 0; q < GL; ++q) scn[i][q] = srow[q][min(nidx, a.lcap - 1)];
+        }
+      }
+      if constexpr (!FUSED) {
+#pragma unroll
+        for (int q = 0; q < GL; ++q) cmn[q] = crow[q][min(8 * (j + 1) + (lane >> 3), cstride - 1)];
+      }
     }
     // running max of the block (max over its <= 8 chunk maxima: lanes 8c..8c+7 hold chunk c), rescale factors
     float f[GL], mnew[GL];
