@@ -13,6 +13,7 @@
 #include <vector>
 
 static thread_local std::string g_create_err;
+#define ZN_GRAPH_STEPS 8
 
 struct zn_handle_s {
   zn_config cfg;
@@ -44,14 +45,15 @@ struct zn_handle_s {
   int *lengths = nullptr, *codes = nullptr;
   int force_eos_step = -1;
   float eos_bias = 0.f;
-  int tune[8] = {512, 512, 512, 1024, 256, 448, 0, 0};   // target workgroups: in_proj, out_proj, fc1, fc2, heads; [5] longest context of the fused attention launch
+  int tune[8] = {512, 512, 512, 1024, 256, 448, 2, 0};   // target workgroups: in_proj, out_proj, fc1, fc2, heads; [5] longest context of the fused attention launch; [6] > 1: multi-step graphs
   const int* tok_override = nullptr;
   int tok_override_calls = 0;
   hipStream_t cap_stream = nullptr;
-  // one captured decode step per attention launch shape: [1] = fused single launch (short contexts), [0] = two passes
-  hipGraphExec_t graph_exec[2] = {nullptr, nullptr};
-  hipGraph_t graph[2] = {nullptr, nullptr};
-  bool graph_tried[2] = {false, false};
+  // captured decode steps per attention launch shape (k & 1: 1 = fused single launch, 0 = two passes) and per length
+  // (k >> 1: 0 = one step, 1 = ZN_GRAPH_STEPS consecutive steps: fewer graph launches on the chain)
+  hipGraphExec_t graph_exec[4] = {nullptr, nullptr, nullptr, nullptr};
+  hipGraph_t graph[4] = {nullptr, nullptr, nullptr, nullptr};
+  bool graph_tried[4] = {false, false, false, false};
   int len_hi = 0;            // host-side upper bound of the rows' KV lengths (keys already cached)
   bool attn_fused = false;   // launch shape of the next run_attention
   std::string err;
@@ -80,7 +82,7 @@ extern "C" size_t zn_kv_bytes_per_layer(const zn_config* c, int32_t rows, int32_
 }
 
 static void free_graph(zn_handle h) {
-  for (int k = 0; k < 2; ++k) {
+  for (int k = 0; k < 4; ++k) {
     if (h->graph_exec[k]) { (void)hipGraphExecDestroy(h->graph_exec[k]); h->graph_exec[k] = nullptr; }
     if (h->graph[k]) { (void)hipGraphDestroy(h->graph[k]); h->graph[k] = nullptr; }
     h->graph_tried[k] = false;
@@ -534,17 +536,21 @@ extern "C" int zn_decode_steps(zn_handle h, int32_t n, zn_stream stream) {
   if (!h->gen_active) ZN_FAIL(h, ZN_ERR_STATE, "zn_decode_steps before zn_gen_begin");
   if (n < 0) ZN_FAIL(h, ZN_ERR_ARG, "n < 0");
   hipStream_t s = (hipStream_t)stream;
-  for (int i = 0; i < n; ++i) {
-    const int k = attn_fused_for(h, ++h->len_hi) ? 1 : 0;   // this step appends one key per row
-    h->attn_fused = k != 0;
+  for (int i = 0; i < n;) {
+    // this step appends one key per row; a run of ZN_GRAPH_STEPS steps with one launch shape replays the long graph
+    const bool fused = attn_fused_for(h, h->len_hi + 1);
+    const int run = (n - i >= ZN_GRAPH_STEPS && h->tune[6] > 1 && attn_fused_for(h, h->len_hi + ZN_GRAPH_STEPS) == fused) ? ZN_GRAPH_STEPS : 1;
+    const int k = (fused ? 1 : 0) | (run > 1 ? 2 : 0);
+    h->attn_fused = fused;
     if (!h->graph_exec[k] && !h->graph_tried[k] && n > 1) {
-      // capture one step; every step-varying quantity (column, positions) is read from device memory
+      // capture; every step-varying quantity (column, positions) is read from device memory
       h->graph_tried[k] = true;
       // capture on an internal stream: the caller's stream may be the legacy null stream, which cannot be captured
       if (!h->cap_stream) (void)hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking);
       hipStream_t cs = h->cap_stream;
       if (cs && hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal) == hipSuccess) {
-        int rc = enqueue_step(h, cs);
+        int rc = ZN_OK;
+        for (int j = 0; j < run && rc == ZN_OK; ++j) rc = enqueue_step(h, cs);
         hipGraph_t g = nullptr;
         hipError_t e = hipStreamEndCapture(cs, &g);
         if (rc == ZN_OK && e == hipSuccess && g && hipGraphInstantiate(&h->graph_exec[k], g, nullptr, nullptr, 0) == hipSuccess) h->graph[k] = g;
@@ -552,13 +558,14 @@ extern "C" int zn_decode_steps(zn_handle h, int32_t n, zn_stream stream) {
       } else (void)hipGetLastError();
     }
     if (h->graph_exec[k]) HIPCHK(h, hipGraphLaunch(h->graph_exec[k], s));
-    else { int rc = enqueue_step(h, s); if (rc) return rc; }
+    else for (int j = 0; j < run; ++j) { int rc = enqueue_step(h, s); if (rc) return rc; }
+    i += run; h->len_hi += run;
   }
   HIPCHK(h, hipGetLastError());
   return ZN_OK;
 }
 
-extern "C" int zn_graph_active(zn_handle h) { return (h && (h->graph_exec[0] || h->graph_exec[1])) ? 1 : 0; }
+extern "C" int zn_graph_active(zn_handle h) { return (h && (h->graph_exec[0] || h->graph_exec[1] || h->graph_exec[2] || h->graph_exec[3])) ? 1 : 0; }
 
 extern "C" int zn_all_stopped(zn_handle h, int32_t* out, zn_stream stream) {
   if (!h || !out) return ZN_ERR_ARG;
