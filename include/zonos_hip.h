@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define ZN_ABI_VERSION 1
+#define ZN_ABI_VERSION 2
 
 enum zn_status {
   ZN_OK = 0,
@@ -48,6 +48,16 @@ typedef struct zn_config {
   int32_t rope_positions;  /* rows of the RoPE table, 16384 (_torch.py:206) */
   int32_t double_out_proj; /* 1 = reproduce _torch.py:419-420 (out_proj applied twice), 0 = upstream behaviour */
   float norm_eps;          /* 1e-5 */
+  /* ABI 2 — hybrid backbone (zonos/backbone/_mamba_ssm.py:8-119; BackboneConfig.ssm_cfg, zonos/config.py:79).
+   * arch 0: every layer is a _torch.py TransformerBlock (fields below ignored).  arch 1: mamba_ssm Block semantics
+   * (fused residual-add + LayerNorm with the sum kept in fp32 for the norm, single out_proj, deferred residual),
+   * layer i is a Mamba2 mixer unless zn_layer_weights.kind says attention. */
+  int32_t arch;
+  int32_t m_d_inner;       /* expand * d_model */
+  int32_t m_headdim;       /* 64 */
+  int32_t m_d_state;       /* 64 or 128 */
+  int32_t m_ngroups;       /* 1 */
+  int32_t m_d_conv;        /* 4 */
 } zn_config;
 
 typedef struct zn_layer_weights { /* bf16; names = _torch.py:278-281,373-374,453-454 */
@@ -57,6 +67,14 @@ typedef struct zn_layer_weights { /* bf16; names = _torch.py:278-281,373-374,453
   const void *norm2_w, *norm2_b;   /* [d] */
   const void *fc1;                 /* [2*d_ff, d]  rows [0,d_ff) = value, [d_ff,2d_ff) = gate */
   const void *fc2;                 /* [d, d_ff] */
+  /* ABI 2: kind 0 = attention + gated MLP (fields above), 1 = Mamba2 mixer (fields below + norm_w/norm_b);
+   * names = mamba_ssm Mamba2 parameters under layers.{i}.mixer. */
+  int32_t kind;
+  const void *m_in_proj;           /* [2*d_inner + 2*ngroups*d_state + nheads, d] */
+  const void *m_conv_w, *m_conv_b; /* conv1d.weight [conv_dim, 1, d_conv], conv1d.bias [conv_dim]; conv_dim = d_inner + 2*ngroups*d_state */
+  const void *m_dt_bias, *m_A_log, *m_D;   /* [nheads], nheads = d_inner / headdim */
+  const void *m_norm_w;            /* mixer.norm.weight [d_inner] (RMSNormGated) */
+  const void *m_out_proj;          /* [d, d_inner] */
 } zn_layer_weights;
 
 typedef struct zn_weights {
@@ -86,6 +104,11 @@ int zn_destroy(zn_handle h);
 const char* zn_last_error(zn_handle h); /* h may be NULL: last creation error */
 /* Bytes of one layer's KV cache [rows, max_len, 2, Hkv, hd] bf16 (_torch.py:305). */
 size_t zn_kv_bytes_per_layer(const zn_config* cfg, int32_t rows, int32_t max_len);
+/* Bytes of one Mamba2 layer's decode state (_mamba_ssm.py:65-86 -> Mamba2.allocate_inference_cache): conv_state
+ * bf16 [rows, conv_dim, d_conv] followed by ssm_state bf16 [rows, nheads, headdim, d_state], one contiguous buffer
+ * whose device pointer takes the layer's slot in zn_gen_begin's kv_layers_dev.  *conv_bytes (optional) receives the
+ * offset of ssm_state. */
+size_t zn_mamba_state_bytes_per_layer(const zn_config* cfg, int32_t rows, size_t* conv_bytes);
 
 /* ---------------------------------------------------------------- generation (Zonos.generate, model.py:354-548) */
 /* Binds the per-call state that zonos/model.py:410-463 builds: KV caches (one device pointer per layer, layout
@@ -161,6 +184,13 @@ int zn_op_layer_decode(zn_handle h, int32_t layer, void* x_dev, void* kv_dev, in
 int zn_op_attn_decode(zn_handle h, const void* q_dev, const void* kv_dev, int32_t max_len, const int32_t* lengths_dev,
                       const int32_t* ext_dev, void* out_dev, int32_t rows, zn_stream stream);
 /* embed_codes_static (codec_utils.py:37): codes int32 [B, n_codebooks] -> bf16 [B, d], sequential bf16 adds. */
+/* mamba_ssm layer_norm_fn(prenorm=True) of the hybrid Block: s = h + res (fp32), res <- bf16(s) in place (res NULL:
+ * s = h), out = bf16(LayerNorm(s)).  h/res/out bf16 [rows, d]. */
+int zn_op_add_layernorm(zn_handle h, const void* hidden, void* res, const void* w, const void* b, void* out, int32_t rows,
+                        int32_t d, float eps, zn_stream stream);
+/* One token through the Mamba2 mixer of hybrid layer `layer` (mamba_ssm Mamba2.step): x bf16 [rows, d] (already
+ * normalised), state = the layer's zn_mamba_state_bytes_per_layer buffer (updated), out bf16 [rows, d]. */
+int zn_op_mamba_step(zn_handle h, int32_t layer, const void* x, void* state, void* out, int32_t rows, zn_stream stream);
 int zn_op_embed(zn_handle h, const int32_t* codes_dev, void* out_dev, int32_t batch, zn_stream stream);
 /* sample_from_logits (sampling.py:166-231) on fp32 logits [B, n_codebooks, vocab_head]; recent int32
  * [B, n_codebooks, window] or NULL; tokens int32 [B, n_codebooks]; probs_out (optional) receives the filtered

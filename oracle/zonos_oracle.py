@@ -121,12 +121,125 @@ def layer_forward(w: dict, li: int, x: torch.Tensor, cache: Cache, cs: torch.Ten
 
 def backbone_forward(w: dict, x: torch.Tensor, cache: Cache, cfg: dict, double_out_proj: bool = True) -> torch.Tensor:
     """zonos/backbone/_torch.py:232-238 — positions = arange(S) + lengths_per_sample, 26 blocks, final LN."""
+    if cfg.get("ssm_cfg"):
+        return hybrid_backbone_forward(w, x, cache, cfg)
     pos = torch.arange(x.shape[1])[None, :] + cache.lengths[:x.shape[0], None].long()
     cs = cache.rope[pos]
     for li in range(cfg["n_layer"]):
         x = layer_forward(w, li, x, cache, cs, cfg, double_out_proj)
     d = cfg["d_model"]
     return F.layer_norm(x, (d,), w["backbone.norm_f.weight"], w["backbone.norm_f.bias"], 1e-5)
+
+
+# --------------------------------------------------------------------------- hybrid backbone (PARITY UNPINNED)
+# zonos/backbone/_mamba_ssm.py:8-119 builds its blocks with the third-party mamba_ssm==2.2.5 (requirements.txt:18;
+# source not under /root/reference, not installed): `create_block(..., fused_add_norm=True)` -> Block(norm, mixer =
+# Mamba2 | MHA, norm2 + GatedMLP on attention layers), Triton layer_norm_fn for the fused residual-add + norm,
+# causal_conv1d_update + selective_state_update for the single-token Mamba2 step.  What follows restates the
+# PUBLISHED algorithm of those pieces (Mamba-2 paper, arXiv:2405.21060, sec. 7 / mamba_ssm Mamba2.step) with the
+# rounding points of the kernels the reference would run: fp32 inside a kernel, one rounding to bf16 at its output,
+# bf16 conv/SSM state (Mamba2.allocate_inference_cache with the dtype generate() passes).  No reference output exists
+# to pin it (SURVEY.md 8c): every result that rests on it says "parity unpinned".
+def mamba2_dims(cfg: dict) -> dict:
+    sc = cfg["ssm_cfg"]
+    d_inner = int(sc.get("expand", 2)) * cfg["d_model"]
+    headdim, d_state, ngroups = int(sc.get("headdim", 64)), int(sc.get("d_state", 128)), int(sc.get("ngroups", 1))
+    return dict(d_inner=d_inner, headdim=headdim, nheads=d_inner // headdim, d_state=d_state, ngroups=ngroups,
+                d_conv=int(sc.get("d_conv", 4)), conv_dim=d_inner + 2 * ngroups * d_state,
+                d_in_proj=2 * d_inner + 2 * ngroups * d_state + d_inner // headdim)
+
+
+def hybrid_setup_cache(cfg: dict, rows: int, max_len: int) -> Cache:
+    """_mamba_ssm.py:65-86: attention layers get a KV cache, Mamba2 layers (conv_state [R, conv_dim, d_conv],
+    ssm_state [R, nheads, headdim, d_state]) in the dtype generate() passes (bf16)."""
+    max_len = find_multiple(max_len, 8)
+    hd = cfg["d_model"] // cfg["num_heads"]
+    m = mamba2_dims(cfg)
+    kv = [torch.zeros(rows, max_len, 2, cfg["num_heads_kv"], hd, dtype=torch.bfloat16) if i in cfg["attn_layer_idx"] else
+          (torch.zeros(rows, m["conv_dim"], m["d_conv"], dtype=torch.bfloat16),
+           torch.zeros(rows, m["nheads"], m["headdim"], m["d_state"], dtype=torch.bfloat16)) for i in range(cfg["n_layer"])]
+    return Cache(kv, max_len, 0, torch.zeros(rows, dtype=torch.int32), rope_table(16384, hd))
+
+
+def add_norm(h: torch.Tensor, res, wgt: torch.Tensor, bias: torch.Tensor, eps: float):
+    """Fused residual-add + LayerNorm (mamba_ssm layer_norm_fn, prenorm=True, residual_in_fp32=False): the sum is
+    formed and normalised in fp32; the residual stream keeps its bf16 rounding, the norm sees the unrounded sum."""
+    s = h.float() if res is None else h.float() + res.float()
+    return F.layer_norm(s, (s.shape[-1],), wgt.float(), bias.float(), eps).to(h.dtype), s.to(h.dtype)
+
+
+def mamba2_step(w: dict, p: str, n: torch.Tensor, conv_state: torch.Tensor, ssm_state: torch.Tensor, m: dict, eps: float = 1e-5):
+    """One token through a Mamba2 mixer (mamba_ssm Mamba2.step; Mamba-2 paper eq. for the SSD recurrence
+    h_t = exp(dt A) h_{t-1} + dt B x_t, y_t = C h_t + D x_t).  n [R, d] bf16; states updated in place."""
+    R = n.shape[0]
+    di, H, P, N, G = m["d_inner"], m["nheads"], m["headdim"], m["d_state"], m["ngroups"]
+    zxbcdt = F.linear(n, w[p + "in_proj.weight"])                                   # bf16 [R, 2*di + 2*G*N + H]
+    z, xBC, dt = zxbcdt.split([di, di + 2 * G * N, H], dim=-1)
+    # causal_conv1d_update: shift the window, fp32 dot with the taps + bias, SiLU, one rounding
+    conv_state.copy_(torch.roll(conv_state, shifts=-1, dims=-1))
+    conv_state[:, :, -1] = xBC
+    wf = w[p + "conv1d.weight"].float().view(-1, m["d_conv"])
+    acc = w[p + "conv1d.bias"].float()[None, :].expand(R, -1)
+    for i in range(m["d_conv"]):                                                     # out = bias; out += w[i] * win[i], tap order
+        acc = acc + wf[None, :, i] * conv_state[:, :, i].float()
+    xBC = (acc / (1.0 + torch.exp(-acc))).to(n.dtype)
+    x, Bm, Cm = xBC.split([di, G * N, G * N], dim=-1)
+    # selective_state_update (fp32 inside; state stored bf16, y from the unrounded new state)
+    A = -torch.exp(w[p + "A_log"].float())                                           # [H]
+    dtv = dt.float() + w[p + "dt_bias"].float()
+    dtv = torch.where(dtv <= 20.0, torch.log1p(torch.exp(dtv)), dtv)                 # softplus
+    dA = torch.exp(dtv * A)                                                          # [R, H]
+    xh = x.float().view(R, H, P)
+    Bg = Bm.float().view(R, G, N).repeat_interleave(H // G, dim=1)                   # [R, H, N]
+    Cg = Cm.float().view(R, G, N).repeat_interleave(H // G, dim=1)
+    new_state = ssm_state.float() * dA[:, :, None, None] + (Bg * dtv[:, :, None])[:, :, None, :] * xh[:, :, :, None]
+    ssm_state.copy_(new_state.to(ssm_state.dtype))
+    y = (new_state * Cg[:, :, None, :]).sum(-1) + xh * w[p + "D"].float()[None, :, None]
+    y = y.reshape(R, di).to(n.dtype)
+    # RMSNormGated(norm_before_gate=False): rmsnorm(y * silu(z)) * weight, per group of d_inner / ngroups
+    v = y.float() * (z.float() * torch.sigmoid(z.float()))
+    vg = v.view(R, G, di // G)
+    vg = vg * torch.rsqrt(vg.pow(2).mean(-1, keepdim=True) + eps)
+    o = (vg.reshape(R, di) * w[p + "norm.weight"].float()).to(n.dtype)
+    return F.linear(o, w[p + "out_proj.weight"])
+
+
+def hybrid_backbone_forward(w: dict, x: torch.Tensor, cache: Cache, cfg: dict) -> torch.Tensor:
+    """_mamba_ssm.py:106-119: position by position (the chunked-scan prefill of the library is the same recurrence)."""
+    d, H, Hkv, eps = cfg["d_model"], cfg["num_heads"], cfg["num_heads_kv"], 1e-5
+    hd = d // H
+    R, S, _ = x.shape
+    m = mamba2_dims(cfg)
+    outs = []
+    for s_i in range(S):
+        h, res = x[:, s_i], None
+        pos = cache.lengths[:R].long() + s_i
+        cs = cache.rope[pos][:, None]                                               # [R, 1, hd/2, 2]
+        t0 = cache.seqlen_offset + s_i
+        for li in range(cfg["n_layer"]):
+            p = f"backbone.layers.{li}."
+            n, res = add_norm(h, res, w[p + "norm.weight"], w[p + "norm.bias"], eps)
+            if li in cfg["attn_layer_idx"]:
+                # mamba_ssm MHA with interleaved rotary (the convention _torch.py:57-68 shares), single out_proj
+                qkv = F.linear(n, w[p + "mixer.in_proj.weight"])
+                q, k, v = qkv.split([H * hd, Hkv * hd, Hkv * hd], dim=-1)
+                q = rope_apply(q.view(R, 1, H, hd), cs)
+                k = rope_apply(k.view(R, 1, Hkv, hd), cs)
+                kvc = cache.kv[li]
+                kvc[:R, t0, 0] = k[:, 0]
+                kvc[:R, t0, 1] = v.view(R, Hkv, hd)
+                kk, vv = kvc[:R, :t0 + 1].unbind(dim=-3)
+                a = F.scaled_dot_product_attention(q.transpose(1, 2), kk.transpose(1, 2), vv.transpose(1, 2), enable_gqa=True)
+                h = F.linear(a.transpose(1, 2).reshape(R, H * hd), w[p + "mixer.out_proj.weight"])
+                n2, res = add_norm(h, res, w[p + "norm2.weight"], w[p + "norm2.bias"], eps)
+                val, gate = F.linear(n2, w[p + "mlp.fc1.weight"]).chunk(2, dim=-1)
+                h = F.linear(val * F.silu(gate), w[p + "mlp.fc2.weight"])
+            else:
+                conv_state, ssm_state = cache.kv[li]
+                h = mamba2_step(w, p + "mixer.", n, conv_state[:R], ssm_state[:R], m, eps)
+        out, _ = add_norm(h, res, w["backbone.norm_f.weight"], w["backbone.norm_f.bias"], eps)
+        outs.append(out)
+    return torch.stack(outs, dim=1)
 
 
 def embed_codes(w: dict, codes: torch.Tensor) -> torch.Tensor:
@@ -221,6 +334,7 @@ class GenTrace:
     """Optional per-step record for teacher-forced comparisons."""
     logits: list = field(default_factory=list)      # fp32 [B,9,1025] fed to the sampler (after bias), per step
     tokens: list = field(default_factory=list)      # sampled [B,9] per step (before EOS masking)
+    inputs: list = field(default_factory=list)      # delayed column [B,9] fed to loop step j (after MASK / prefix / EOS fill)
     final_offset: int = 0
     steps_run: int = 0
 
@@ -244,7 +358,7 @@ def generate(w: dict, cfg: dict, prefix_conditioning: torch.Tensor, audio_prefix
     P = 0 if audio_prefix_codes is None else audio_prefix_codes.shape[2]
     L_c = prefix_conditioning.shape[1]
     audio_len = P + max_new_tokens
-    cache = setup_cache(cfg, 2 * B, L_c + audio_len + N_Q)                      # model.py:410-413
+    cache = (hybrid_setup_cache if cfg.get("ssm_cfg") else setup_cache)(cfg, 2 * B, L_c + audio_len + N_Q)   # model.py:410-413
     codes = torch.full((B, N_Q, audio_len), -1, dtype=torch.int64)
     if audio_prefix_codes is not None:
         codes[..., :P] = audio_prefix_codes
@@ -281,6 +395,8 @@ def generate(w: dict, cfg: dict, prefix_conditioning: torch.Tensor, audio_prefix
         if offset >= delayed.shape[2]:
             break
         ids = delayed[..., offset - 1:offset]
+        if trace is not None:
+            trace.inputs.append(ids[..., 0].clone())
         hid = embed_codes(w, ids).repeat(2, 1, 1)                               # generation_utils.py:191-192
         logits = compute_logits(w, hid, cache, cfg, cfg_scale, double_out_proj)
         logits = logits + bias

@@ -29,7 +29,7 @@ def _write_checkpoint(tmp_path, cfg, seed):
     ck["prefix_conditioner.norm.weight"] = torch.ones(cfg["d_model"], dtype=torch.bfloat16)   # ignored until the conditioner row lands
     save_file(ck, str(tmp_path / "model.safetensors"))
     conf = {"backbone": {"d_model": cfg["d_model"], "n_layer": cfg["n_layer"], "attn_mlp_d_intermediate": cfg["d_ff"], "d_intermediate": 0,
-                         "ssm_cfg": {}, "attn_layer_idx": list(range(cfg["n_layer"])),
+                         "ssm_cfg": dict(cfg.get("ssm_cfg") or {}), "attn_layer_idx": list(cfg.get("attn_layer_idx", range(cfg["n_layer"]))),
                          "attn_cfg": {"num_heads": cfg["num_heads"], "num_heads_kv": cfg["num_heads_kv"], "causal": True, "rotary_emb_dim": 32},
                          "rms_norm": False, "residual_in_fp32": False, "norm_epsilon": 1e-5},
             "prefix_conditioner": {"conditioners": [], "projection": "none"},
@@ -54,11 +54,27 @@ def test_from_local_key_contract_cpu(tmp_path):
     for k, v in sd.items():
         if k.startswith("backbone."):
             assert torch.equal(got[k], v), k
-    hybrid = json.load(open(tmp_path / "config.json"))
-    hybrid["backbone"]["ssm_cfg"] = {"layer": "Mamba2"}
-    (tmp_path / "hybrid.json").write_text(json.dumps(hybrid))
-    with pytest.raises(Exception, match="hybrid"):
-        Zonos.from_local(str(tmp_path / "hybrid.json"), str(tmp_path / "model.safetensors"), device="cpu")
+    other = json.load(open(tmp_path / "config.json"))
+    other["backbone"]["ssm_cfg"] = {"layer": "Mamba1"}
+    (tmp_path / "mamba1.json").write_text(json.dumps(other))
+    with pytest.raises(Exception, match="Mamba2"):
+        Zonos.from_local(str(tmp_path / "mamba1.json"), str(tmp_path / "model.safetensors"), device="cpu")
+
+
+def test_from_local_hybrid_key_contract_cpu(tmp_path):
+    """A hybrid checkpoint (mamba_ssm parameter names under layers.{i}.mixer, _mamba_ssm.py:43-60) loads key for key."""
+    cfg = synth.HYBRID_TINY_CFG
+    sd = _write_checkpoint(tmp_path, cfg, 78)
+    model = Zonos.from_local(str(tmp_path / "config.json"), str(tmp_path / "model.safetensors"), device="cpu")
+    got = model.state_dict()
+    n_backbone = 0
+    for k, v in sd.items():
+        if k.startswith("backbone."):
+            assert k in got and got[k].shape == v.shape and torch.equal(got[k], v), k
+            n_backbone += 1
+    assert n_backbone == sum(k.startswith("backbone.") for k in got)      # no parameter of the module tree is left unset
+    assert got["backbone.layers.0.mixer.conv1d.weight"].shape == (256 + 2 * 64, 1, 4)
+    assert "backbone.layers.2.mlp.fc1.weight" in got and "backbone.layers.0.mlp.fc1.weight" not in got
 
 
 @pytest.mark.gpu

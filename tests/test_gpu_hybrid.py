@@ -1,0 +1,154 @@
+"""GPU tests of the hybrid (Mamba2 + attention) backbone, SURVEY.md 8a row S / BASELINE config 4: HIP path through the
+C ABI vs the CPU restatement in oracle/zonos_oracle.py.
+
+PARITY UNPINNED against the reference: its hybrid arithmetic is third-party mamba_ssm / causal_conv1d / flash_attn code
+that is neither in the reference tree nor installed, and the reference holds no fixture for it.  These
+tests pin the HIP kernels to the restatement (itself checked against the published recurrence in
+tests/test_hybrid_oracle.py); tolerances are stated per test."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import zonos_oracle as zo
+from zonos_amd import _lib, synth
+from zonos_amd.backbone._hip import mamba2_dims
+from zonos_amd.testing import build_model
+
+pytestmark = pytest.mark.gpu
+GREEDY = {"temperature": 0.0}
+WIDE_CFG = dict(synth.HYBRID_FULL_CFG, n_layer=2, attn_layer_idx=[1])      # full widths (d 2048, d_inner 4096, N 128), 2 layers
+
+
+def _bits(t):
+    return t.contiguous().view(torch.int16)
+
+
+def test_add_layernorm_vs_oracle():
+    model, _ = build_model(synth.HYBRID_TINY_CFG, 3, "cuda:0")
+    eng = model.engine(1)
+    st = _lib.stream_ptr()
+    for d in (128, 2048):
+        h = torch.from_numpy(synth.normal(3, f"aln.h.{d}", (4, d))).to(torch.bfloat16)
+        res = torch.from_numpy(synth.normal(3, f"aln.r.{d}", (4, d), 3.0)).to(torch.bfloat16)
+        w = (1.0 + torch.from_numpy(synth.uniform(3, f"aln.w.{d}", (d,), 0.1))).to(torch.bfloat16)
+        b = torch.from_numpy(synth.uniform(3, f"aln.b.{d}", (d,), 0.1)).to(torch.bfloat16)
+        for use_res in (True, False):
+            ref_n, ref_res = zo.add_norm(h, res if use_res else None, w, b, 1e-5)
+            hd, rd, wd, bd = h.cuda(), res.clone().cuda(), w.cuda(), b.cuda()
+            out = torch.empty_like(hd)
+            eng.call("zn_op_add_layernorm", hd.data_ptr(), rd.data_ptr() if use_res else None, wd.data_ptr(), bd.data_ptr(), out.data_ptr(), 4, d, 1e-5, st)
+            torch.cuda.synchronize()
+            eq = float((_bits(out.cpu()) == _bits(ref_n)).float().mean())
+            print(f"\n[add+LN d={d} res={use_res}] normalised bit-equal {eq:.5f}")
+            assert eq > 0.995
+            if use_res:
+                assert torch.equal(_bits(rd.cpu()), _bits(ref_res))          # the residual stream is exact (one fp32 add, one rounding)
+
+
+@pytest.mark.parametrize("cfg_name", ["tiny", "wide"])
+def test_mamba2_step_vs_oracle(cfg_name):
+    """Six consecutive tokens through the Mamba2 mixer of layer 0 from random states.  The conv window holds in_proj
+    outputs (bf16 GEMV results: fp32 summation order may flip a last bit), SSM state and outputs additionally see libm
+    ulp differences in exp/log1p before one bf16 rounding: bit-equal fractions > 0.98 (window, state) / > 0.8 (output),
+    max |diff| <= 2^-6 of the output scale."""
+    cfg = synth.HYBRID_TINY_CFG if cfg_name == "tiny" else WIDE_CFG
+    model, sd = build_model(cfg, 11, "cuda:0")
+    eng = model.engine(1)
+    st = _lib.stream_ptr()
+    m = mamba2_dims(model.config.backbone)
+    R, d = 2, cfg["d_model"]
+    conv = torch.from_numpy(synth.normal(11, "conv0", (R, m["conv_dim"], m["d_conv"]))).to(torch.bfloat16)
+    ssm = torch.from_numpy(synth.normal(11, "ssm0", (R, m["nheads"], m["headdim"], m["d_state"]))).to(torch.bfloat16)
+    n_conv = conv.numel()
+    buf = torch.cat([conv.flatten(), ssm.flatten()]).cuda()
+    assert buf.numel() * 2 == eng.lib.zn_mamba_state_bytes_per_layer(C.byref(eng.zc), R, None)
+    om = zo.mamba2_dims(dict(cfg))
+    for t in range(6):
+        x = torch.from_numpy(synth.normal(11, f"x{t}", (R, d))).to(torch.bfloat16)
+        ref = zo.mamba2_step(sd, "backbone.layers.0.mixer.", x, conv, ssm, om)
+        xd = x.cuda()
+        out = torch.empty_like(xd)
+        eng.call("zn_op_mamba_step", 0, xd.data_ptr(), buf.data_ptr(), out.data_ptr(), R, st)
+        torch.cuda.synchronize()
+        got, gconv, gssm = out.cpu(), buf[:n_conv].cpu().view_as(conv), buf[n_conv:].cpu().view_as(ssm)
+        eq = float((_bits(got) == _bits(ref)).float().mean())
+        seq = float((_bits(gssm) == _bits(ssm)).float().mean())
+        md = (got.float() - ref.float()).abs().max().item()
+        print(f"\n[mamba2 {cfg_name} t={t}] out bit-equal {eq:.4f} max|d| {md:.3g} (|ref| max {ref.float().abs().max():.3g}); state bit-equal {seq:.5f}")
+        ceq = float((_bits(gconv) == _bits(conv)).float().mean())
+        assert ceq > 0.98 and seq > 0.98 and eq > 0.8, (ceq, seq, eq)    # one flipped input of the gated RMS norm moves rstd for the whole row
+        assert md <= 2.0 ** -6 * max(1.0, ref.float().abs().max().item())
+        buf.copy_(torch.cat([conv.flatten(), ssm.flatten()]))     # continue from the oracle's state: errors do not compound
+
+
+def _trace_run(model, cond, max_new, inputs):
+    tr = {"logits": []}
+    inp = torch.from_numpy(inputs.astype(np.int32)).to("cuda:0")
+
+    def hook(step_idx, delayed, col):
+        k = step_idx + 1
+        if k < inp.shape[0]:
+            delayed[:, :, col] = inp[k]
+    tr["after_step"] = hook
+    model.generate(cond.to("cuda:0"), max_new_tokens=max_new, sampling_params=GREEDY, _trace=tr)
+    return torch.stack(tr["logits"]).cpu()
+
+
+@pytest.mark.parametrize("peaky", [False, True])
+def test_hybrid_generate_vs_oracle(peaky):
+    """Whole hybrid stack through Zonos.generate (prefill position by position, hipGraph decode steps, Mamba2 state and
+    KV caches) teacher-forced on the oracle's inputs: logits within 0.06 (Gaussian heads; with the heavy-tailed 'peaky'
+    heads 2^-5 of the largest |logit|: bf16 hidden ulp flips times head weights up to 20), greedy indices equal wherever
+    the oracle's top-2 margin exceeds twice that; the free-running agreement is reported."""
+    cfg = synth.HYBRID_TINY_CFG
+    model, sd = build_model(cfg, 21, "cuda:0", peaky=peaky)
+    cond = synth.conditioning(21, "cond", 2, 7, cfg["d_model"])
+    max_new = 40
+    tr = zo.GenTrace()
+    ref_codes = zo.generate(sd, dict(cfg), cond, max_new_tokens=max_new, cfg_scale=2.0, sampling_params=GREEDY, trace=tr)
+    ref_logits = torch.stack(tr.logits).numpy()
+    got = _trace_run(model, cond, max_new, torch.stack(tr.inputs).numpy()).numpy()
+    fin = np.isfinite(ref_logits)
+    assert np.array_equal(np.isfinite(got), fin)
+    diff = np.abs(np.where(fin, got - ref_logits, 0.0))
+    srt = np.sort(np.where(fin, ref_logits, -np.inf), axis=-1)
+    margin = srt[..., -1] - srt[..., -2]
+    ga, ra = np.where(fin, got, -np.inf).argmax(-1), np.where(fin, ref_logits, -np.inf).argmax(-1)
+    print(f"\n[hybrid tiny peaky={peaky}] {len(got)} calls: exact logits {float((diff == 0).mean()):.4f}, max|diff| {diff.max():.4g}; "
+          f"argmax equal {float((ga == ra).mean()):.4f}")
+    maxabs = float(np.abs(np.where(fin, ref_logits, 0)).max())
+    tol = 0.06 if not peaky else max(0.06, 2.0 ** -5 * maxabs)        # peaky heads: |logit| up to ~100, one bf16 ulp of a hidden value x 20
+    print(f"  max|logit| {maxabs:.1f}, tolerance {tol:.3g}, decisive pairs {float((margin > 2 * tol).mean()):.3f}")
+    assert diff.max() <= tol
+    assert np.array_equal(ga[margin > 2 * tol], ra[margin > 2 * tol])
+    if peaky:
+        out = model.generate(cond.to("cuda:0"), max_new_tokens=max_new, sampling_params=GREEDY)
+        same = (out.cpu() == ref_codes).all(dim=1)[0]
+        first = int((~same).nonzero()[0]) if not bool(same.all()) else max_new
+        print(f"  free-running greedy: identical frames up to {first} of {max_new} (a near-tie flipped by libm ulp differences in the Mamba2 "
+              "step redirects the rest; the teacher-forced bar above is the parity statement)")
+        assert out.shape == ref_codes.shape
+
+
+@pytest.mark.parametrize("B", [2, 3])
+def test_hybrid_batch_rows_match_single_runs(B):
+    """B utterances in one call vs B single-utterance calls.  B = 2 shares the GEMV kernels with the solo runs (4 rows:
+    bit-identical per row); B = 3 runs the projections on the small-M MFMA path (6 rows), whose fp32 summation order
+    differs: near-ties may flip, so the first frames and most tokens must agree (same bar as the transformer's test)."""
+    cfg = synth.HYBRID_TINY_CFG
+    model, _ = build_model(cfg, 23, "cuda:0", peaky=True)
+    conds = [synth.conditioning(23, f"cond{i}", 2, 6, cfg["d_model"]) for i in range(B)]
+    singles = [model.generate(c.to("cuda:0"), max_new_tokens=24, sampling_params=GREEDY).cpu() for c in conds]
+    batch = torch.cat([torch.stack([c[0] for c in conds]), torch.stack([c[1] for c in conds])]).to("cuda:0")
+    out = model.generate(batch, max_new_tokens=24, batch_size=B, sampling_params=GREEDY).cpu()
+    for i in range(B):
+        n = min(out.shape[-1], singles[i].shape[-1])      # lengths differ only through the EOS trim of the batch / solo run
+        same = (out[i, :, :n] == singles[i][0, :, :n]).float().mean().item()
+        print(f"\n[hybrid batch {B} utterance {i}] tokens equal to the solo run on the common {n} frames: {same:.3f}")
+        assert n >= 4
+        if B <= 2:
+            assert same == 1.0
+        else:
+            assert torch.equal(out[i, :, :3], singles[i][0, :, :3]) and same > 0.5

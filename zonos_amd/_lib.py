@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libzonos_hip.so")
 
-ZN_ABI_VERSION = 1
+ZN_ABI_VERSION = 2
 
 
 class ZonosHipError(RuntimeError):
@@ -20,11 +20,13 @@ class ZonosHipError(RuntimeError):
 
 class zn_config(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("d_model", "n_layer", "n_heads", "n_heads_kv", "d_ff", "n_codebooks", "vocab_head",
-                                          "vocab_embed", "eos_id", "mask_id", "rope_positions", "double_out_proj")] + [("norm_eps", C.c_float)]
+                                          "vocab_embed", "eos_id", "mask_id", "rope_positions", "double_out_proj")] + [("norm_eps", C.c_float)] + \
+               [(n, C.c_int32) for n in ("arch", "m_d_inner", "m_headdim", "m_d_state", "m_ngroups", "m_d_conv")]
 
 
 class zn_layer_weights(C.Structure):
-    _fields_ = [(n, C.c_void_p) for n in ("norm_w", "norm_b", "in_proj", "out_proj", "norm2_w", "norm2_b", "fc1", "fc2")]
+    _fields_ = [(n, C.c_void_p) for n in ("norm_w", "norm_b", "in_proj", "out_proj", "norm2_w", "norm2_b", "fc1", "fc2")] + [("kind", C.c_int32)] + \
+               [(n, C.c_void_p) for n in ("m_in_proj", "m_conv_w", "m_conv_b", "m_dt_bias", "m_A_log", "m_D", "m_norm_w", "m_out_proj")]
 
 
 class zn_weights(C.Structure):
@@ -54,6 +56,7 @@ SIGNATURES = {
     "zn_destroy": (C.c_int, [C.c_void_p]),
     "zn_last_error": (C.c_char_p, [C.c_void_p]),
     "zn_kv_bytes_per_layer": (C.c_size_t, [C.POINTER(zn_config), C.c_int32, C.c_int32]),
+    "zn_mamba_state_bytes_per_layer": (C.c_size_t, [C.POINTER(zn_config), C.c_int32, C.POINTER(C.c_size_t)]),
     "zn_gen_begin": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_void_p), C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
                                C.c_int32, C.c_float, C.POINTER(zn_sampling), C.c_void_p]),
     "zn_prefill": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
@@ -77,6 +80,8 @@ SIGNATURES = {
     "zn_op_layer_decode": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
     "zn_op_attn_decode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
     "zn_op_embed": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
+    "zn_op_add_layernorm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_void_p]),
+    "zn_op_mamba_step": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
     "zn_op_sample": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(zn_sampling), C.c_uint64, C.c_void_p, C.c_void_p,
                                C.c_int32, C.c_void_p]),
     "zn_dac_create": (C.c_int, [C.POINTER(zn_dac_config), C.POINTER(zn_dac_tensor), C.c_int32, C.POINTER(C.c_void_p)]),

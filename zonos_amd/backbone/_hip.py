@@ -1,4 +1,4 @@
-"""HIP transformer backbone behind the reference's backbone plugin contract.
+"""HIP transformer / hybrid backbone behind the reference's backbone plugin contract.
 
 Contract (zonos/backbone/__init__.py:24-36, _torch.py:130,157,213): a class with `supported_architectures`,
 `__init__(config: BackboneConfig)`, `allocate_inference_cache(batch_size, max_seqlen, dtype) -> {layer: (kv, None)}`
@@ -43,14 +43,50 @@ class _Mlp(nn.Module):
         self.fc2 = nn.Linear(cfg.attn_mlp_d_intermediate, cfg.d_model, bias=False)
 
 
-class _Block(nn.Module):
-    """Parameter container only (names = _torch.py:278-281); the math is the HIP kernels'."""
+def mamba2_dims(cfg: BackboneConfig) -> dict:
+    """Mamba2 hyper-parameters from BackboneConfig.ssm_cfg with the library's defaults (mamba_ssm 2.2.5 Mamba2.__init__,
+    the class _mamba_ssm.py:45-58 instantiates through create_block)."""
+    sc = cfg.ssm_cfg
+    d_inner = int(sc.get("expand", 2)) * cfg.d_model
+    headdim, d_state, ngroups, d_conv = int(sc.get("headdim", 64)), int(sc.get("d_state", 128)), int(sc.get("ngroups", 1)), int(sc.get("d_conv", 4))
+    return dict(d_inner=d_inner, headdim=headdim, nheads=d_inner // headdim, d_state=d_state, ngroups=ngroups, d_conv=d_conv,
+                conv_dim=d_inner + 2 * ngroups * d_state, d_in_proj=2 * d_inner + 2 * ngroups * d_state + d_inner // headdim)
+
+
+class _RmsWeight(nn.Module):
+    def __init__(self, n: int):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(n))
+
+
+class _Mamba2Mixer(nn.Module):
+    """Parameter container with mamba_ssm Mamba2's names: in_proj, conv1d, dt_bias, A_log, D, norm, out_proj."""
     def __init__(self, cfg: BackboneConfig):
         super().__init__()
+        m = mamba2_dims(cfg)
+        self.in_proj = nn.Linear(cfg.d_model, m["d_in_proj"], bias=False)
+        self.conv1d = nn.Conv1d(m["conv_dim"], m["conv_dim"], m["d_conv"], groups=m["conv_dim"], padding=m["d_conv"] - 1, bias=True)
+        self.dt_bias = nn.Parameter(torch.zeros(m["nheads"]))
+        self.A_log = nn.Parameter(torch.zeros(m["nheads"]))
+        self.D = nn.Parameter(torch.ones(m["nheads"]))
+        self.norm = _RmsWeight(m["d_inner"])
+        self.out_proj = nn.Linear(m["d_inner"], cfg.d_model, bias=False)
+
+
+class _Block(nn.Module):
+    """Parameter container only (names = _torch.py:278-281 / mamba_ssm Block); the math is the HIP kernels'."""
+    def __init__(self, cfg: BackboneConfig, layer_idx: int = 0):
+        super().__init__()
         self.norm = nn.LayerNorm(cfg.d_model, eps=cfg.norm_epsilon)
-        self.mixer = _Mixer(cfg)
-        self.norm2 = nn.LayerNorm(cfg.d_model, eps=cfg.norm_epsilon)
-        self.mlp = _Mlp(cfg)
+        self.is_mamba = bool(cfg.ssm_cfg) and layer_idx not in cfg.attn_layer_idx
+        if self.is_mamba:
+            self.mixer = _Mamba2Mixer(cfg)
+            if cfg.d_intermediate:
+                raise _lib.ZonosHipError("Mamba2 layers with an MLP (d_intermediate > 0) are not supported")
+        else:
+            self.mixer = _Mixer(cfg)
+            self.norm2 = nn.LayerNorm(cfg.d_model, eps=cfg.norm_epsilon)
+            self.mlp = _Mlp(cfg)
 
 
 class HipEngine:
@@ -73,10 +109,25 @@ class HipEngine:
         zc = _lib.zn_config(d_model=cfg.d_model, n_layer=cfg.n_layer, n_heads=h, n_heads_kv=hkv, d_ff=cfg.attn_mlp_d_intermediate,
                             n_codebooks=n_codebooks, vocab_head=vocab_head, vocab_embed=vocab_embed, eos_id=eos_id, mask_id=mask_id,
                             rope_positions=ROPE_POSITIONS, double_out_proj=int(double_out_proj), norm_eps=cfg.norm_epsilon)
+        if cfg.ssm_cfg:   # hybrid: mamba_ssm Block semantics, Mamba2 mixers outside attn_layer_idx
+            m = mamba2_dims(cfg)
+            zc.arch, zc.double_out_proj = 1, 0
+            zc.m_d_inner, zc.m_headdim, zc.m_d_state, zc.m_ngroups, zc.m_d_conv = m["d_inner"], m["headdim"], m["d_state"], m["ngroups"], m["d_conv"]
         self.zc = zc
         self._keep = [self.rope]
         lw = (_lib.zn_layer_weights * cfg.n_layer)()
         for i, blk in enumerate(backbone.layers):
+            if blk.is_mamba:
+                mx = blk.mixer
+                ts = [blk.norm.weight, blk.norm.bias, mx.in_proj.weight, mx.conv1d.weight, mx.conv1d.bias, mx.dt_bias, mx.A_log, mx.D, mx.norm.weight,
+                      mx.out_proj.weight]
+                for t in ts:
+                    assert t.is_contiguous()
+                lw[i].kind = 1
+                (lw[i].norm_w, lw[i].norm_b, lw[i].m_in_proj, lw[i].m_conv_w, lw[i].m_conv_b, lw[i].m_dt_bias, lw[i].m_A_log, lw[i].m_D, lw[i].m_norm_w,
+                 lw[i].m_out_proj) = [t.data_ptr() for t in ts]
+                self._keep += ts
+                continue
             ts = [blk.norm.weight, blk.norm.bias, blk.mixer.in_proj.weight, blk.mixer.out_proj.weight, blk.norm2.weight, blk.norm2.bias,
                   blk.mlp.fc1.weight, blk.mlp.fc2.weight]
             for t in ts:
@@ -112,13 +163,16 @@ class HipEngine:
 
 
 class HipZonosBackbone(nn.Module):
-    supported_architectures = ["transformer"]
+    supported_architectures = ["transformer", "hybrid"]      # _mamba_ssm.py:25
 
     def __init__(self, config: BackboneConfig):
-        assert not config.ssm_cfg, "This backbone implementation only supports the Transformer model."
+        if config.ssm_cfg and config.ssm_cfg.get("layer", "Mamba1") != "Mamba2":
+            raise _lib.ZonosHipError("only ssm_cfg layer = 'Mamba2' is supported (the Zonos hybrid checkpoints' mixer)")
+        if config.rms_norm or config.residual_in_fp32:
+            raise _lib.ZonosHipError("rms_norm / residual_in_fp32 backbones are not supported (Zonos checkpoints use neither)")
         super().__init__()
         self.config = config
-        self.layers = nn.ModuleList(_Block(config) for _ in range(config.n_layer))
+        self.layers = nn.ModuleList(_Block(config, i) for i in range(config.n_layer))
         self.norm_f = nn.LayerNorm(config.d_model, eps=config.norm_epsilon)
         self.ref_double_out_proj = True   # reproduce zonos/backbone/_torch.py:419-420
         self._engine: HipEngine | None = None
@@ -130,19 +184,32 @@ class HipZonosBackbone(nn.Module):
         return e
 
     def allocate_inference_cache(self, batch_size: int, max_seqlen: int, dtype: torch.dtype = torch.bfloat16):
-        """_torch.py:157-211: per layer (kv [R, maxL, 2, Hkv, hd], None)."""
+        """_torch.py:157-211: per attention layer (kv [R, maxL, 2, Hkv, hd], None); _mamba_ssm.py:65-86: per Mamba2
+        layer (conv_state [R, conv_dim, d_conv], ssm_state [R, nheads, headdim, d_state]), zero-initialised, both views
+        of one contiguous buffer (the layout zn_mamba_state_bytes_per_layer describes)."""
         if dtype != torch.bfloat16:
             raise _lib.ZonosHipError("the KV cache is bfloat16 (zonos/model.py:305)")
         cfg = self.config
         hd = cfg.d_model // cfg.attn_cfg["num_heads"]
         dev = self.norm_f.weight.device
-        return {i: (torch.empty(batch_size, max_seqlen, 2, cfg.attn_cfg["num_heads_kv"], hd, dtype=dtype, device=dev), None)
-                for i in range(cfg.n_layer)}
+        out = {}
+        for i, blk in enumerate(self.layers):
+            if blk.is_mamba:
+                m = mamba2_dims(cfg)
+                n_conv = batch_size * m["conv_dim"] * m["d_conv"]
+                buf = torch.zeros(n_conv + batch_size * m["d_inner"] * m["d_state"], dtype=dtype, device=dev)
+                out[i] = (buf[:n_conv].view(batch_size, m["conv_dim"], m["d_conv"]),
+                          buf[n_conv:].view(batch_size, m["nheads"], m["headdim"], m["d_state"]))
+            else:
+                out[i] = (torch.empty(batch_size, max_seqlen, 2, cfg.attn_cfg["num_heads_kv"], hd, dtype=dtype, device=dev), None)
+        return out
 
     @torch.inference_mode()
     def forward(self, hidden_states: torch.Tensor, inference_params: InferenceParams) -> torch.Tensor:
         """_torch.py:213-238.  Position by position through the decode kernels; KV is appended at
         lengths_per_sample + s (== seqlen_offset + s in every reference call site)."""
+        if self.config.ssm_cfg:
+            raise _lib.ZonosHipError("HipZonosBackbone.forward: the hybrid stack runs through Zonos.generate (device-resident loop) only")
         R, S, d = hidden_states.shape
         eng = self.engine(R + (R & 1))
         st = _lib.stream_ptr()

@@ -4,6 +4,7 @@
 #include "zn_decode_kernels.h"
 #include "zn_prefill_kernels.h"
 #include "zn_cond_kernels.h"
+#include "zn_mamba_kernels.h"
 
 #include <cmath>
 #include <cstdio>
@@ -26,6 +27,9 @@ struct zn_handle_s {
   bool has_io = false;  // embeddings + heads bound (false: backbone-only handle)
   // workspace (device)
   bf16_t *x = nullptr, *q = nullptr, *o1 = nullptr, *mbuf = nullptr, *nbuf = nullptr;
+  // hybrid backbone (arch 1): residual stream, normalised activations, Mamba2 intermediates
+  bf16_t *res = nullptr, *hn = nullptr, *m_zx = nullptr, *m_xbc = nullptr, *m_y = nullptr, *m_g = nullptr;
+  int m_nheads = 0, m_conv_dim = 0, m_d_in_proj = 0;
   float *logits_raw = nullptr, *last_logits = nullptr;
   int* tok_raw = nullptr;
   float *scores = nullptr, *cmax = nullptr;
@@ -81,6 +85,15 @@ extern "C" size_t zn_kv_bytes_per_layer(const zn_config* c, int32_t rows, int32_
   return (size_t)rows * max_len * 2 * c->n_heads_kv * hd * 2;
 }
 
+extern "C" size_t zn_mamba_state_bytes_per_layer(const zn_config* c, int32_t rows, size_t* conv_bytes) {
+  if (conv_bytes) *conv_bytes = 0;
+  if (!c || c->arch != 1 || c->m_headdim <= 0 || rows < 0) return 0;
+  const size_t conv_dim = (size_t)c->m_d_inner + 2 * (size_t)c->m_ngroups * c->m_d_state;
+  const size_t cb = (size_t)rows * conv_dim * c->m_d_conv * 2;
+  if (conv_bytes) *conv_bytes = cb;
+  return cb + (size_t)rows * c->m_d_inner * c->m_d_state * 2;   // nheads * headdim = d_inner
+}
+
 static void free_graph(zn_handle h) {
   for (int k = 0; k < 4; ++k) {
     if (h->graph_exec[k]) { (void)hipGraphExecDestroy(h->graph_exec[k]); h->graph_exec[k] = nullptr; }
@@ -92,7 +105,7 @@ static void free_graph(zn_handle h) {
 extern "C" int zn_destroy(zn_handle h) {
   if (!h) return ZN_OK;
   free_graph(h);
-  void* ptrs[] = {h->emb_tables_dev, h->x, h->q, h->o1, h->mbuf, h->nbuf, h->logits_raw, h->last_logits, h->tok_raw, h->scores, h->cmax, h->pf_x, h->pf_n, h->pf_qkv, h->pf_a, h->pf_u, h->pf_m, h->st, h->remaining, h->stopping};
+  void* ptrs[] = {h->emb_tables_dev, h->x, h->q, h->o1, h->mbuf, h->nbuf, h->logits_raw, h->last_logits, h->tok_raw, h->scores, h->cmax, h->pf_x, h->pf_n, h->pf_qkv, h->pf_a, h->pf_u, h->pf_m, h->st, h->remaining, h->stopping, h->res, h->hn, h->m_zx, h->m_xbc, h->m_y, h->m_g};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (h->done_host) (void)hipHostFree(h->done_host);
   if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
@@ -113,9 +126,23 @@ extern "C" int zn_create(const zn_config* cfg, const zn_weights* w, int32_t max_
   if (c.d_model % 8 || c.d_ff % 8 || c.d_model > 4096) ZN_FAIL((zn_handle) nullptr, ZN_ERR_UNSUPPORTED, "d_model/d_ff must be multiples of 8, d_model <= 4096");
   if (c.vocab_head > ZN_SAMPLE_MAXV) ZN_FAIL((zn_handle) nullptr, ZN_ERR_UNSUPPORTED, "vocab_head > %d", ZN_SAMPLE_MAXV);
   if (max_rows < 2 || max_rows % 2) ZN_FAIL((zn_handle) nullptr, ZN_ERR_ARG, "max_rows must be even and >= 2");
+  if (c.arch != 0 && c.arch != 1) ZN_FAIL((zn_handle) nullptr, ZN_ERR_ARG, "zn_create: arch must be 0 (transformer) or 1 (hybrid)");
+  if (c.arch == 1) {
+    if (c.m_headdim != 64 || (c.m_d_state != 64 && c.m_d_state != 128) || c.m_d_conv != 4)
+      ZN_FAIL((zn_handle) nullptr, ZN_ERR_UNSUPPORTED, "Mamba2: headdim %d / d_state %d / d_conv %d not in {64} x {64,128} x {4}", c.m_headdim, c.m_d_state, c.m_d_conv);
+    if (c.m_d_inner <= 0 || c.m_d_inner % 64 || c.m_ngroups < 1 || (c.m_d_inner / 64) % c.m_ngroups || (c.m_d_inner / c.m_ngroups) % 8 ||
+        c.m_d_inner / c.m_ngroups > 8192)
+      ZN_FAIL((zn_handle) nullptr, ZN_ERR_UNSUPPORTED, "Mamba2: d_inner %d / ngroups %d not supported", c.m_d_inner, c.m_ngroups);
+  }
   zn_handle h = new zn_handle_s();
   h->cfg = c; h->max_rows = max_rows; h->hd = hd; h->G = G;
-  if (const char* e = getenv("ZN_PREFILL_MODE")) h->prefill_mode = atoi(e);
+  if (c.arch == 1) {
+    h->m_nheads = c.m_d_inner / c.m_headdim;
+    h->m_conv_dim = c.m_d_inner + 2 * c.m_ngroups * c.m_d_state;
+    h->m_d_in_proj = 2 * c.m_d_inner + 2 * c.m_ngroups * c.m_d_state + h->m_nheads;
+    h->prefill_mode = 0;   // hybrid: position by position (the library's chunked scan is the same recurrence)
+  }
+  if (const char* e = getenv("ZN_PREFILL_MODE")) if (c.arch == 0) h->prefill_mode = atoi(e);
   h->layers.assign(w->layers, w->layers + c.n_layer);
   h->heads = w->heads; h->norm_f_w = w->norm_f_w; h->norm_f_b = w->norm_f_b; h->rope = w->rope_table;
 #define ZC(call) do { hipError_t _e = (call); if (_e != hipSuccess) { g_create_err = std::string(#call) + ": " + hipGetErrorString(_e); zn_destroy(h); return ZN_ERR_HIP; } } while (0)
@@ -136,6 +163,14 @@ extern "C" int zn_create(const zn_config* cfg, const zn_weights* w, int32_t max_
   ZC(hipMalloc(&h->remaining, (R / 2) * sizeof(int)));
   ZC(hipMalloc(&h->stopping, (R / 2) * sizeof(int)));
   ZC(hipHostMalloc(&h->done_host, sizeof(int) * 4));
+  if (c.arch == 1) {
+    ZC(hipMalloc(&h->res, R * c.d_model * 2));
+    ZC(hipMalloc(&h->hn, R * c.d_model * 2));
+    ZC(hipMalloc(&h->m_zx, R * h->m_d_in_proj * 2));
+    ZC(hipMalloc(&h->m_xbc, R * h->m_conv_dim * 2));
+    ZC(hipMalloc(&h->m_y, R * c.m_d_inner * 2));
+    ZC(hipMalloc(&h->m_g, R * c.m_d_inner * 2));
+  }
 #undef ZC
   *out = h;
   return ZN_OK;
@@ -343,6 +378,94 @@ static int heads_logits(zn_handle h, const bf16_t* x, int rows, hipStream_t s) {
   return run_gemv<PRO_LN, EPI_F32>(h, a, rows, h->tune[4], s);
 }
 
+// ------------------------------------------------------------------------------------------------ hybrid backbone
+static void launch_add_ln(const bf16_t* hid, bf16_t* res, int has_res, int write_res, const void* w, const void* b, bf16_t* out, int rows,
+                          int d, float eps, hipStream_t s) {
+  AddLnArgs a{};
+  a.h = hid; a.res = res; a.w = (const bf16_t*)w; a.b = (const bf16_t*)b; a.out = out; a.d = d; a.has_res = has_res; a.write_res = write_res;
+  a.eps = eps;
+  hipLaunchKernelGGL(add_ln_kernel, dim3(rows), dim3(256), 0, s, a);
+}
+
+// One token through the Mamba2 mixer of layer li (mamba_ssm Mamba2.step): n [rows][d] normalised -> out [rows][d]
+static int mamba_mixer(zn_handle h, int li, const bf16_t* n, void* state, bf16_t* out, int rows, hipStream_t s) {
+  const zn_config& c = h->cfg;
+  const zn_layer_weights& lw = h->layers[li];
+  int rc;
+  {
+    GemvArgs a{};
+    a.W = (const bf16_t*)lw.m_in_proj; a.N = h->m_d_in_proj; a.K = c.d_model; a.x = n; a.out = h->m_zx;
+    if ((rc = run_gemv<PRO_NONE, EPI_STORE>(h, a, rows, (h->m_d_in_proj / 2 + 3) / 4, s))) return rc;
+  }
+  size_t conv_bytes = 0;   // the state buffer is laid out for exactly `rows` rows (zn_mamba_state_bytes_per_layer)
+  (void)zn_mamba_state_bytes_per_layer(&c, rows, &conv_bytes);
+  MambaArgs m{};
+  m.zx = h->m_zx; m.conv_state = (bf16_t*)state; m.ssm_state = (bf16_t*)((char*)state + conv_bytes);
+  m.conv_w = (const bf16_t*)lw.m_conv_w; m.conv_b = (const bf16_t*)lw.m_conv_b;
+  m.dt_bias = (const bf16_t*)lw.m_dt_bias; m.A_log = (const bf16_t*)lw.m_A_log; m.D = (const bf16_t*)lw.m_D;
+  m.norm_w = (const bf16_t*)lw.m_norm_w; m.xbc = h->m_xbc; m.y = h->m_y; m.g = h->m_g;
+  m.d_inner = c.m_d_inner; m.conv_dim = h->m_conv_dim; m.nheads = h->m_nheads; m.d_state = c.m_d_state; m.ngroups = c.m_ngroups;
+  m.d_in_proj = h->m_d_in_proj; m.eps = c.norm_eps;
+  hipLaunchKernelGGL(mamba_conv_kernel, dim3((h->m_conv_dim + 255) / 256, rows), dim3(256), 0, s, m);
+  if (c.m_d_state == 128) hipLaunchKernelGGL((mamba_ssm_kernel<128>), dim3(h->m_nheads, rows), dim3(256), 0, s, m);
+  else hipLaunchKernelGGL((mamba_ssm_kernel<64>), dim3(h->m_nheads, rows), dim3(256), 0, s, m);
+  hipLaunchKernelGGL(mamba_gated_norm_kernel, dim3(c.m_ngroups, rows), dim3(256), 0, s, m);
+  {
+    GemvArgs a{};
+    a.W = (const bf16_t*)lw.m_out_proj; a.N = c.d_model; a.K = c.m_d_inner; a.x = h->m_g; a.out = out;
+    if ((rc = run_gemv<PRO_NONE, EPI_STORE>(h, a, rows, h->tune[3], s))) return rc;
+  }
+  return ZN_OK;
+}
+
+// One token through hybrid layer li (mamba_ssm Block, fused_add_norm): hidden h->x / residual h->res in, same out.
+static int hybrid_layer(zn_handle h, int li, void* cache, int max_len, const int* lengths, int rows, hipStream_t s) {
+  const zn_config& c = h->cfg;
+  const zn_layer_weights& lw = h->layers[li];
+  const int d = c.d_model, hd = h->hd, nq = c.n_heads * hd, nkv = c.n_heads_kv * hd;
+  int rc;
+  launch_add_ln(h->x, h->res, li > 0, 1, lw.norm_w, lw.norm_b, h->hn, rows, d, c.norm_eps, s);
+  if (lw.kind == 1) return mamba_mixer(h, li, h->hn, cache, h->x, rows, s);
+  {  // MHA: in_proj -> split -> interleaved RoPE(q,k) -> KV append
+    GemvArgs a{};
+    a.W = (const bf16_t*)lw.in_proj; a.N = nq + 2 * nkv; a.K = d; a.x = h->hn;
+    a.lengths = lengths; a.hd = hd; a.n_heads = c.n_heads; a.n_heads_kv = c.n_heads_kv;
+    a.q_out = h->q; a.kv = (bf16_t*)cache; a.rope = h->rope; a.max_len = max_len; a.rope_positions = c.rope_positions;
+    if ((rc = run_gemv<PRO_NONE, EPI_ROPE_KV>(h, a, rows, h->tune[0], s))) return rc;
+  }
+  if ((rc = run_attention(h, h->q, (const bf16_t*)cache, max_len, lengths, nullptr, 0, h->o1, rows, s))) return rc;
+  {
+    GemvArgs a{};
+    a.W = (const bf16_t*)lw.out_proj; a.N = d; a.K = nq; a.x = h->o1; a.out = h->x;
+    if ((rc = run_gemv<PRO_NONE, EPI_STORE>(h, a, rows, h->tune[1], s))) return rc;
+  }
+  launch_add_ln(h->x, h->res, 1, 1, lw.norm2_w, lw.norm2_b, h->hn, rows, d, c.norm_eps, s);
+  {
+    GemvArgs a{};
+    a.W = (const bf16_t*)lw.fc1; a.N = 2 * c.d_ff; a.K = d; a.x = h->hn; a.out = h->mbuf;
+    if ((rc = run_gemv<PRO_NONE, EPI_SILU>(h, a, rows, h->tune[2], s))) return rc;
+  }
+  {
+    GemvArgs a{};
+    a.W = (const bf16_t*)lw.fc2; a.N = d; a.K = c.d_ff; a.x = h->mbuf; a.out = h->x;
+    if ((rc = run_gemv<PRO_NONE, EPI_STORE>(h, a, rows, h->tune[3], s))) return rc;
+  }
+  return ZN_OK;
+}
+
+// All layers for the token in h->x, then the final add + LayerNorm (_mamba_ssm.py:111-119) and the heads.
+static int hybrid_token(zn_handle h, bool want_logits, hipStream_t s) {
+  const zn_config& c = h->cfg;
+  int rc;
+  for (int li = 0; li < c.n_layer; ++li)
+    if ((rc = hybrid_layer(h, li, (void*)h->kv_layers[li], h->max_len, h->lengths, h->rows, s))) return rc;
+  if (!want_logits) return ZN_OK;
+  launch_add_ln(h->x, h->res, 1, 0, h->norm_f_w, h->norm_f_b, h->hn, h->rows, c.d_model, c.norm_eps, s);
+  GemvArgs a{};
+  a.W = (const bf16_t*)h->heads; a.N = c.n_codebooks * c.vocab_head; a.K = c.d_model; a.x = h->hn; a.out_f32 = h->logits_raw;
+  return run_gemv<PRO_NONE, EPI_F32>(h, a, h->rows, h->tune[4], s);
+}
+
 static SampleArgs make_sample_args(zn_handle h, const zn_sampling& sp) {
   SampleArgs a{};
   const zn_config& c = h->cfg;
@@ -362,9 +485,13 @@ static int enqueue_step(zn_handle h, hipStream_t s) {
   e.tables = h->emb_tables_dev; e.codes = h->codes; e.col_dev = &h->st->offset; e.sb = c.n_codebooks * h->t_total; e.si = h->t_total;
   e.col = 0; e.n_q = c.n_codebooks; e.d = c.d_model; e.batch = h->batch; e.vocab_embed = c.vocab_embed; e.out = h->x; e.dup = 1;
   hipLaunchKernelGGL(embed_kernel, dim3(h->batch), dim3(256), 0, s, e);
-  for (int li = 0; li < c.n_layer; ++li)
-    if ((rc = layer_decode(h, li, h->x, (bf16_t*)h->kv_layers[li], h->max_len, h->lengths, nullptr, 0, h->rows, s))) return rc;
-  if ((rc = heads_logits(h, h->x, h->rows, s))) return rc;
+  if (c.arch == 1) {
+    if ((rc = hybrid_token(h, true, s))) return rc;
+  } else {
+    for (int li = 0; li < c.n_layer; ++li)
+      if ((rc = layer_decode(h, li, h->x, (bf16_t*)h->kv_layers[li], h->max_len, h->lengths, nullptr, 0, h->rows, s))) return rc;
+    if ((rc = heads_logits(h, h->x, h->rows, s))) return rc;
+  }
   SampleArgs a = make_sample_args(h, h->sp);
   a.raw = h->logits_raw; a.mix = 1; a.cfg_scale = h->cfg_scale; a.apply_bias = 1; a.batch = h->batch;
   a.codes = h->codes; a.t_total = h->t_total; a.ctx = h->max_new < 100 ? h->max_new : 100;
@@ -503,12 +630,16 @@ extern "C" int zn_prefill(zn_handle h, const void* hidden_dev, int32_t S, zn_str
       hipLaunchKernelGGL(gather_pos_kernel, dim3(h->rows), dim3(256), 0, s, (const bf16_t*)hidden_dev, h->x, S, p, c.d_model);
       int ext = (p / qb) * qb + qb; if (ext > S) ext = S;
       h->attn_fused = attn_fused_for(h, ++h->len_hi);
-      for (int li = 0; li < c.n_layer; ++li)
-        if ((rc = layer_decode(h, li, h->x, (bf16_t*)h->kv_layers[li], h->max_len, h->lengths, nullptr, ext, h->rows, s))) return rc;
+      if (c.arch == 1) {
+        if ((rc = hybrid_token(h, p == S - 1, s))) return rc;
+      } else {
+        for (int li = 0; li < c.n_layer; ++li)
+          if ((rc = layer_decode(h, li, h->x, (bf16_t*)h->kv_layers[li], h->max_len, h->lengths, nullptr, ext, h->rows, s))) return rc;
+      }
       hipLaunchKernelGGL(add_lengths_kernel, dim3(1), dim3(64 > h->rows ? 64 : h->rows), 0, s, h->lengths, h->rows, 1);
     }
   }
-  if ((rc = heads_logits(h, h->x, h->rows, s))) return rc;
+  if (c.arch == 0 && (rc = heads_logits(h, h->x, h->rows, s))) return rc;
   HIPCHK(h, hipGetLastError());
   return ZN_OK;
 }
@@ -732,6 +863,26 @@ extern "C" int zn_op_layer_decode(zn_handle h, int32_t layer, void* x, void* kv,
   if (rc) return rc;
   h->attn_fused = attn_fused_for(h, max_len);   // lengths live on the device: bound the context by the capacity
   rc = layer_decode(h, layer, (bf16_t*)x, (bf16_t*)kv, max_len, lengths, ext, 0, rows, (hipStream_t)stream);
+  if (rc) return rc;
+  HIPCHK(h, hipGetLastError());
+  return ZN_OK;
+}
+
+extern "C" int zn_op_add_layernorm(zn_handle h, const void* hidden, void* res, const void* w, const void* b, void* out, int32_t rows,
+                                   int32_t d, float eps, zn_stream stream) {
+  if (!h) return ZN_ERR_ARG;
+  if (!hidden || !w || !b || !out || rows < 1 || d < 8 || d % 8 || d > 4096) ZN_FAIL(h, ZN_ERR_ARG, "zn_op_add_layernorm: bad argument");
+  launch_add_ln((const bf16_t*)hidden, (bf16_t*)res, res != nullptr, res != nullptr, w, b, (bf16_t*)out, rows, d, eps, (hipStream_t)stream);
+  HIPCHK(h, hipGetLastError());
+  return ZN_OK;
+}
+
+extern "C" int zn_op_mamba_step(zn_handle h, int32_t layer, const void* x, void* state, void* out, int32_t rows, zn_stream stream) {
+  if (!h) return ZN_ERR_ARG;
+  if (h->cfg.arch != 1) ZN_FAIL(h, ZN_ERR_STATE, "zn_op_mamba_step: the handle is not a hybrid backbone");
+  if (!x || !state || !out || layer < 0 || layer >= h->cfg.n_layer || rows < 1 || rows > h->max_rows) ZN_FAIL(h, ZN_ERR_ARG, "zn_op_mamba_step: bad argument");
+  if (h->layers[layer].kind != 1) ZN_FAIL(h, ZN_ERR_ARG, "zn_op_mamba_step: layer %d is an attention layer", layer);
+  int rc = mamba_mixer(h, layer, (const bf16_t*)x, state, (bf16_t*)out, rows, (hipStream_t)stream);
   if (rc) return rc;
   HIPCHK(h, hipGetLastError());
   return ZN_OK;

@@ -1,0 +1,219 @@
+// Hybrid backbone (zonos/backbone/_mamba_ssm.py:8-119) decode-step kernels: fused residual-add + LayerNorm of the
+// mamba_ssm Block, and the single-token Mamba2 mixer pieces (causal conv window update + SiLU, SSD state update,
+// gated RMSNorm).  The arithmetic of these pieces lives in third-party mamba_ssm 2.2.5 / causal_conv1d 1.5.2, absent
+// from the reference tree: the kernels follow the published recurrence (Mamba-2, arXiv:2405.21060) with one bf16
+// rounding per kernel output and bf16 conv/SSM state; the CPU restatement they are tested against is
+// oracle/zonos_oracle.py (mamba2_step, add_norm) — parity with the reference itself is unpinned.
+// All of it is HBM-bound byte moving: the SSM state (H x P x N bf16 per row and layer) is read and written once per
+// step with 16-B accesses, reductions are wavefront shuffles.
+#pragma once
+#include "zn_common.h"
+
+// ------------------------------------------------------------------------------------------------ add + LayerNorm
+struct AddLnArgs {
+  const bf16_t* h;      // [rows][d] mixer / MLP output of the previous sub-block
+  bf16_t* res;          // [rows][d] residual stream, updated in place (has_res = 0: written only)
+  const bf16_t *w, *b;  // [d]
+  bf16_t* out;          // [rows][d] normalised
+  int d, has_res, write_res;
+  float eps;
+};
+// s = h + res in fp32; res <- bf16(s); out <- bf16(LayerNorm_fp32(s)) (biased variance, two passes over registers).
+// One workgroup per row, 8 elements per thread per sweep (d <= 4096).
+__global__ __launch_bounds__(256) void add_ln_kernel(AddLnArgs a) {
+  const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int d = a.d;
+  constexpr int MAXV = 2;                      // sweeps of 256 threads x 8 elements
+  float v[MAXV][8];
+  int nv = 0;
+  float sum = 0.f;
+#pragma unroll
+  for (int it = 0; it < MAXV; ++it) {
+    const int k = (it * 256 + tid) * 8;
+    if (k < d) {
+      const u32x4 hv = ld16(a.h + (size_t)r * d + k);
+      float f[8] = {lo_f(hv.x), hi_f(hv.x), lo_f(hv.y), hi_f(hv.y), lo_f(hv.z), hi_f(hv.z), lo_f(hv.w), hi_f(hv.w)};
+      if (a.has_res) {
+        const u32x4 rv = ld16(a.res + (size_t)r * d + k);
+        const float g[8] = {lo_f(rv.x), hi_f(rv.x), lo_f(rv.y), hi_f(rv.y), lo_f(rv.z), hi_f(rv.z), lo_f(rv.w), hi_f(rv.w)};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] = __fadd_rn(f[e], g[e]);
+      }
+      if (a.write_res) {
+        u32x4 o;
+        o.x = pack2(f[0], f[1]); o.y = pack2(f[2], f[3]); o.z = pack2(f[4], f[5]); o.w = pack2(f[6], f[7]);
+        *(u32x4*)(a.res + (size_t)r * d + k) = o;
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { v[it][e] = f[e]; sum += f[e]; }
+      nv = it + 1;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[it][e] = 0.f;
+    }
+  }
+  __shared__ float red[2][4];
+  sum = wave_sum(sum);
+  if (lane == 0) red[0][wave] = sum;
+  __syncthreads();
+  const float mean = ((red[0][0] + red[0][1]) + (red[0][2] + red[0][3])) / (float)d;
+  float ss = 0.f;
+#pragma unroll
+  for (int it = 0; it < MAXV; ++it)
+    if (it < nv) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { const float c = v[it][e] - mean; ss += c * c; }
+    }
+  ss = wave_sum(ss);
+  if (lane == 0) red[1][wave] = ss;
+  __syncthreads();
+  const float rstd = 1.0f / sqrtf(((red[1][0] + red[1][1]) + (red[1][2] + red[1][3])) / (float)d + a.eps);
+#pragma unroll
+  for (int it = 0; it < MAXV; ++it) {
+    const int k = (it * 256 + tid) * 8;
+    if (it < nv) {
+      const u32x4 wv = ld16(a.w + k), bv = ld16(a.b + k);
+      const float wf[8] = {lo_f(wv.x), hi_f(wv.x), lo_f(wv.y), hi_f(wv.y), lo_f(wv.z), hi_f(wv.z), lo_f(wv.w), hi_f(wv.w)};
+      const float bf[8] = {lo_f(bv.x), hi_f(bv.x), lo_f(bv.y), hi_f(bv.y), lo_f(bv.z), hi_f(bv.z), lo_f(bv.w), hi_f(bv.w)};
+      float o[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = (v[it][e] - mean) * rstd * wf[e] + bf[e];
+      u32x4 ov;
+      ov.x = pack2(o[0], o[1]); ov.y = pack2(o[2], o[3]); ov.z = pack2(o[4], o[5]); ov.w = pack2(o[6], o[7]);
+      *(u32x4*)(a.out + (size_t)r * d + k) = ov;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ Mamba2 step
+struct MambaArgs {
+  const bf16_t* zx;       // [rows][d_in_proj] = [z (d_inner) | xBC (conv_dim) | dt (nheads)]  (in_proj output)
+  bf16_t* conv_state;     // [rows][conv_dim][4]
+  bf16_t* ssm_state;      // [rows][nheads][headdim][d_state]
+  const bf16_t *conv_w;   // [conv_dim][4]  (conv1d.weight [conv_dim,1,4])
+  const bf16_t *conv_b;   // [conv_dim]
+  const bf16_t *dt_bias, *A_log, *D;   // [nheads]
+  const bf16_t* norm_w;   // [d_inner]
+  bf16_t* xbc;            // [rows][conv_dim] activated conv output
+  bf16_t* y;              // [rows][d_inner]
+  bf16_t* g;              // [rows][d_inner] gated-normalised
+  int d_inner, conv_dim, nheads, d_state, ngroups, d_in_proj;
+  float eps;
+};
+
+// causal_conv1d_update (width 4): shift the window, append the new sample, out = silu(bias + sum_i w[i] * win[i]) with
+// separately rounded fp32 multiplies and adds in tap order, one rounding to bf16.  One thread per channel.
+__global__ __launch_bounds__(256) void mamba_conv_kernel(MambaArgs a) {
+  const int c = blockIdx.x * 256 + threadIdx.x, r = blockIdx.y;
+  if (c >= a.conv_dim) return;
+  typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
+  bf16_t* sp = a.conv_state + ((size_t)r * a.conv_dim + c) * 4;
+  const u32x2_t st = *(const u32x2_t*)sp;
+  const u32x2_t wv = *(const u32x2_t*)(a.conv_w + (size_t)c * 4);
+  const bf16_t xn = a.zx[(size_t)r * a.d_in_proj + a.d_inner + c];
+  const float s0 = hi_f(st.x), s1 = lo_f(st.y), s2 = hi_f(st.y), s3 = bf2f(xn);
+  u32x2_t ns;
+  ns.x = (st.x >> 16) | (st.y << 16);
+  ns.y = (st.y >> 16) | ((unsigned)xn << 16);
+  *(u32x2_t*)sp = ns;
+  float acc = bf2f(a.conv_b[c]);
+  acc = __fadd_rn(acc, __fmul_rn(lo_f(wv.x), s0));
+  acc = __fadd_rn(acc, __fmul_rn(hi_f(wv.x), s1));
+  acc = __fadd_rn(acc, __fmul_rn(lo_f(wv.y), s2));
+  acc = __fadd_rn(acc, __fmul_rn(hi_f(wv.y), s3));
+  a.xbc[(size_t)r * a.conv_dim + c] = f2bf(acc / (1.0f + expf(-acc)));
+}
+
+// selective_state_update for one (row, head): h <- h * exp(dt A) + (B dt) x (each product and the sum rounded in fp32,
+// state stored bf16), y = C . h_new + D x from the unrounded new state.  headdim 64; 256 threads: thread = (p = tid / 4,
+// quarter of the state row); the state tile (64 x N bf16, 16 KB at N = 128) is read and written once, 16 B per access.
+template <int N>
+__global__ __launch_bounds__(256) void mamba_ssm_kernel(MambaArgs a) {
+  constexpr int P = 64, NT = N / 4, NV = NT / 8;     // state elements per thread, 16-B vectors per thread
+  const int h = blockIdx.x, r = blockIdx.y, tid = threadIdx.x;
+  const int p = tid >> 2, q = tid & 3;
+  bf16_t* sp = a.ssm_state + (((size_t)r * a.nheads + h) * P + p) * N + q * NT;
+  u32x4 sv[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) sv[i] = ld16(sp + i * 8);
+  const int grp = h / (a.nheads / a.ngroups);
+  const bf16_t* xb = a.xbc + (size_t)r * a.conv_dim;
+  const bf16_t* Bp = xb + a.d_inner + grp * N + q * NT;
+  const bf16_t* Cp = Bp + a.ngroups * N;
+  u32x4 bv[NV], cv[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) { bv[i] = ld16(Bp + i * 8); cv[i] = ld16(Cp + i * 8); }
+  const float x = bf2f(xb[h * P + p]);
+  float dt = __fadd_rn(bf2f(a.zx[(size_t)r * a.d_in_proj + a.d_inner + a.conv_dim + h]), bf2f(a.dt_bias[h]));
+  if (dt <= 20.0f) dt = log1pf(expf(dt));
+  const float A = -expf(bf2f(a.A_log[h]));
+  const float dA = expf(__fmul_rn(dt, A));
+  float y = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const unsigned sw[4] = {sv[i].x, sv[i].y, sv[i].z, sv[i].w};
+    const unsigned bw[4] = {bv[i].x, bv[i].y, bv[i].z, bv[i].w};
+    const unsigned cw[4] = {cv[i].x, cv[i].y, cv[i].z, cv[i].w};
+    unsigned ow[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float n0 = __fadd_rn(__fmul_rn(lo_f(sw[e]), dA), __fmul_rn(__fmul_rn(lo_f(bw[e]), dt), x));
+      const float n1 = __fadd_rn(__fmul_rn(hi_f(sw[e]), dA), __fmul_rn(__fmul_rn(hi_f(bw[e]), dt), x));
+      y = fmaf(n0, lo_f(cw[e]), y);
+      y = fmaf(n1, hi_f(cw[e]), y);
+      ow[e] = pack2(n0, n1);
+    }
+    *(u32x4*)(sp + i * 8) = u32x4{ow[0], ow[1], ow[2], ow[3]};
+  }
+  // the 4 quarter-row partials of p sit in one quad
+  y += dpp_mov<ZN_DPP_XOR1>(y);
+  y += dpp_mov<ZN_DPP_XOR2>(y);
+  if (q == 0) a.y[(size_t)r * a.d_inner + h * P + p] = f2bf(__fadd_rn(y, __fmul_rn(x, bf2f(a.D[h]))));
+}
+
+// RMSNormGated(norm_before_gate=False): v = y * silu(z); g = bf16(v * rsqrt(mean_group(v^2) + eps) * w).
+// One workgroup per (row, group), 8 elements per thread per sweep (group size <= 8192).
+__global__ __launch_bounds__(256) void mamba_gated_norm_kernel(MambaArgs a) {
+  const int r = blockIdx.y, grp = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int gs = a.d_inner / a.ngroups;
+  constexpr int MAXV = 4;
+  float v[MAXV][8];
+  float ss = 0.f;
+#pragma unroll
+  for (int it = 0; it < MAXV; ++it) {
+    const int k = (it * 256 + tid) * 8;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[it][e] = 0.f;
+    if (k < gs) {
+      const u32x4 yv = ld16(a.y + (size_t)r * a.d_inner + grp * gs + k);
+      const u32x4 zv = ld16(a.zx + (size_t)r * a.d_in_proj + grp * gs + k);
+      const float yf[8] = {lo_f(yv.x), hi_f(yv.x), lo_f(yv.y), hi_f(yv.y), lo_f(yv.z), hi_f(yv.z), lo_f(yv.w), hi_f(yv.w)};
+      const float zf[8] = {lo_f(zv.x), hi_f(zv.x), lo_f(zv.y), hi_f(zv.y), lo_f(zv.z), hi_f(zv.z), lo_f(zv.w), hi_f(zv.w)};
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float sg = 1.0f / (1.0f + expf(-zf[e]));
+        v[it][e] = __fmul_rn(yf[e], __fmul_rn(zf[e], sg));
+        ss += v[it][e] * v[it][e];
+      }
+    }
+  }
+  __shared__ float red[4];
+  ss = wave_sum(ss);
+  if (lane == 0) red[wave] = ss;
+  __syncthreads();
+  const float rstd = 1.0f / sqrtf(((red[0] + red[1]) + (red[2] + red[3])) / (float)gs + a.eps);
+#pragma unroll
+  for (int it = 0; it < MAXV; ++it) {
+    const int k = (it * 256 + tid) * 8;
+    if (k < gs) {
+      const u32x4 wv = ld16(a.norm_w + grp * gs + k);
+      const float wf[8] = {lo_f(wv.x), hi_f(wv.x), lo_f(wv.y), hi_f(wv.y), lo_f(wv.z), hi_f(wv.z), lo_f(wv.w), hi_f(wv.w)};
+      float o[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = __fmul_rn(__fmul_rn(v[it][e], rstd), wf[e]);
+      u32x4 ov;
+      ov.x = pack2(o[0], o[1]); ov.y = pack2(o[2], o[3]); ov.z = pack2(o[4], o[5]); ov.w = pack2(o[6], o[7]);
+      *(u32x4*)(a.g + (size_t)r * a.d_inner + grp * gs + k) = ov;
+    }
+  }
+}

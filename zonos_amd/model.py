@@ -74,8 +74,6 @@ class Zonos(nn.Module):
         """model.py:128-176: bf16 model, embeddings zero-padded to the 1032-row tables, heads.{i} fused."""
         import safetensors
         config = ZonosConfig.from_dict(json.load(open(config_path)))
-        if config.backbone.ssm_cfg:
-            raise _lib.ZonosHipError("hybrid (Mamba2) checkpoints are not supported yet (SURVEY.md §8a row S)")
         backbone_cls = BACKBONES[backbone] if backbone else DEFAULT_BACKBONE_CLS
         model = cls(config, backbone_cls).to(device, torch.bfloat16)
         sd = model.state_dict()

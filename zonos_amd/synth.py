@@ -117,8 +117,12 @@ def zonos_state_dict(cfg: dict, seed: int = 1234, dtype=torch.bfloat16, peaky: b
     else:
         sd["fused_heads.weight"] = torch.cat(
             [_t(uniform(seed, f"heads.{i}.weight", (vh, d), 1.0 / np.sqrt(d)), dtype) for i in range(nq)], 0)
+    ssm = cfg.get("ssm_cfg") or {}
     for l in range(L):
         p = f"backbone.layers.{l}."
+        if ssm and l not in cfg["attn_layer_idx"]:
+            sd.update(mamba2_layer_state_dict(cfg, seed, p, dtype))
+            continue
         for nm in ("norm", "norm2"):
             sd[p + nm + ".weight"] = _t(1.0 + uniform(seed, p + nm + ".weight", (d,), 0.1), dtype)
             sd[p + nm + ".bias"] = _t(uniform(seed, p + nm + ".bias", (d,), 0.1), dtype)
@@ -131,6 +135,39 @@ def zonos_state_dict(cfg: dict, seed: int = 1234, dtype=torch.bfloat16, peaky: b
     return sd
 
 
+def mamba2_layer_state_dict(cfg: dict, seed: int, p: str, dtype=torch.bfloat16) -> dict:
+    """Synthetic Mamba2 block under mamba_ssm's parameter names (norm + mixer.{in_proj, conv1d, dt_bias, A_log, D, norm,
+    out_proj}) with the library's init distributions: dt = exp(U(log 1e-3, log 1e-1)) -> dt_bias = softplus^-1(dt),
+    A = U(1, 16) -> A_log, D = 1 (perturbed), conv/Linear U(+-1/sqrt(fan_in))."""
+    d = cfg["d_model"]
+    sc = cfg["ssm_cfg"]
+    d_inner = int(sc.get("expand", 2)) * d
+    headdim, d_state, ngroups, d_conv = int(sc.get("headdim", 64)), int(sc.get("d_state", 128)), int(sc.get("ngroups", 1)), int(sc.get("d_conv", 4))
+    H = d_inner // headdim
+    conv_dim = d_inner + 2 * ngroups * d_state
+    sd = {}
+    sd[p + "norm.weight"] = _t(1.0 + uniform(seed, p + "norm.weight", (d,), 0.1), dtype)
+    sd[p + "norm.bias"] = _t(uniform(seed, p + "norm.bias", (d,), 0.1), dtype)
+    sd[p + "mixer.in_proj.weight"] = _t(uniform(seed, p + "mixer.in_proj.weight", (2 * d_inner + 2 * ngroups * d_state + H, d), 1.0 / np.sqrt(d)), dtype)
+    sd[p + "mixer.conv1d.weight"] = _t(uniform(seed, p + "mixer.conv1d.weight", (conv_dim, 1, d_conv), 1.0 / np.sqrt(d_conv)), dtype)
+    sd[p + "mixer.conv1d.bias"] = _t(uniform(seed, p + "mixer.conv1d.bias", (conv_dim,), 1.0 / np.sqrt(d_conv)), dtype)
+    u = (uniform(seed, p + "mixer.dt", (H,), 1.0).astype(np.float64) + 1.0) / 2.0
+    dt = np.exp(u * (np.log(0.1) - np.log(0.001)) + np.log(0.001))
+    sd[p + "mixer.dt_bias"] = _t((dt + np.log(-np.expm1(-dt))).astype(np.float32), dtype)
+    a = 1.0 + 15.0 * (uniform(seed, p + "mixer.A", (H,), 1.0).astype(np.float64) + 1.0) / 2.0
+    sd[p + "mixer.A_log"] = _t(np.log(a).astype(np.float32), dtype)
+    sd[p + "mixer.D"] = _t(1.0 + uniform(seed, p + "mixer.D", (H,), 0.1), dtype)
+    sd[p + "mixer.norm.weight"] = _t(1.0 + uniform(seed, p + "mixer.norm.weight", (d_inner,), 0.1), dtype)
+    sd[p + "mixer.out_proj.weight"] = _t(uniform(seed, p + "mixer.out_proj.weight", (d, d_inner), 1.0 / np.sqrt(d_inner)), dtype)
+    return sd
+
+
+# Hybrid configurations: tiny for parity tests; full = the recalled Zonos-v0.1-hybrid dimensions (SURVEY.md 0.8,
+# "lower confidence": the loader reads the real ones from config.json).
+HYBRID_TINY_CFG = dict(d_model=128, n_layer=4, num_heads=4, num_heads_kv=2, d_ff=256, ssm_cfg={"layer": "Mamba2", "d_state": 64},
+                       attn_layer_idx=[2])
+HYBRID_FULL_CFG = dict(d_model=2048, n_layer=46, num_heads=16, num_heads_kv=4, d_ff=8192, ssm_cfg={"layer": "Mamba2"},
+                       attn_layer_idx=[9, 19, 29, 39])
 TINY_CFG = dict(d_model=128, n_layer=2, num_heads=4, num_heads_kv=2, d_ff=256)
 FULL_CFG = dict(d_model=2048, n_layer=26, num_heads=16, num_heads_kv=4, d_ff=8192)
 

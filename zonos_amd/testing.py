@@ -11,7 +11,7 @@ from .model import Zonos
 
 def zonos_config(cfg: dict, conditioners: list | None = None, projection: str = "none") -> ZonosConfig:
     return ZonosConfig(BackboneConfig(d_model=cfg["d_model"], n_layer=cfg["n_layer"], attn_mlp_d_intermediate=cfg["d_ff"],
-                                      attn_layer_idx=list(range(cfg["n_layer"])),
+                                      attn_layer_idx=list(cfg.get("attn_layer_idx", range(cfg["n_layer"]))), ssm_cfg=dict(cfg.get("ssm_cfg") or {}),
                                       attn_cfg=dict(num_heads=cfg["num_heads"], num_heads_kv=cfg["num_heads_kv"])),
                        PrefixConditionerConfig(list(conditioners or []), projection))
 
