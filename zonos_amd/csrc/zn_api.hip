@@ -235,6 +235,15 @@ static int run_gemm16(zn_handle h, GemvArgs a, int rows, hipStream_t s) {
     if (g.lengths) g.lengths += r0;
     if (g.q_out) g.q_out += (size_t)r0 * a.n_heads * a.hd;
     if (g.kv) g.kv += (size_t)r0 * a.max_len * 2 * a.n_heads_kv * a.hd;
+    if constexpr (EPI != EPI_SILU) {
+      if (tiles <= 192 && a.N % 8 == 0) {   // N = d_model: 8-row tiles so that every CU gets a workgroup
+        const int t8 = a.N / 8;
+        if (nw == 16) hipLaunchKernelGGL((gemm16_kernel<16, EPI, 8>), dim3(t8), dim3(1024), 0, s, g);
+        else if (nw == 8) hipLaunchKernelGGL((gemm16_kernel<8, EPI, 8>), dim3(t8), dim3(512), 0, s, g);
+        else hipLaunchKernelGGL((gemm16_kernel<4, EPI, 8>), dim3(t8), dim3(256), 0, s, g);
+        continue;
+      }
+    }
     if (nw == 16) hipLaunchKernelGGL((gemm16_kernel<16, EPI>), dim3(tiles), dim3(1024), 0, s, g);
     else if (nw == 8) hipLaunchKernelGGL((gemm16_kernel<8, EPI>), dim3(tiles), dim3(512), 0, s, g);
     else hipLaunchKernelGGL((gemm16_kernel<4, EPI>), dim3(tiles), dim3(256), 0, s, g);

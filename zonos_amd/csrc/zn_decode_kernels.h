@@ -263,16 +263,18 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs a) {
 // 16 B per lane per 32-deep step) with the activation fragment fetched from L2; the partial 16x16 tiles meet in LDS
 // and the shared epilogues finish them.  HBM-bound like the GEMV; MFMA only replaces 16 rows x dot2 on the VALU.
 typedef __attribute__((ext_vector_type(8))) __bf16 zn_bf16x8;
-template <int NW, int EPI>
+// TR = weight rows per workgroup: 16, or 8 (lanes n >= 8 idle) when N / 16 tiles would leave CUs without a workgroup
+// (N = d_model = 2048: 128 tiles on 256 CUs) — twice the workgroups at half the rows each.
+template <int NW, int EPI, int TR = 16>
 __global__ __launch_bounds__(NW * 64) void gemm16_kernel(GemvArgs a) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int n = lane & 15, g = lane >> 4;
-  const int u = blockIdx.x;                       // tile of 16 weight rows
+  const int u = blockIdx.x;                       // tile of TR weight rows
   const int F = a.N >> 1;
-  const int rowbaseA = (EPI == EPI_SILU) ? 16 * u : 16 * u;
-  const int rowbaseB = F + 16 * u;                // EPI_SILU only
+  const int rowbaseA = TR * u;
+  const int rowbaseB = F + TR * u;                // EPI_SILU only
   const int K = a.K, kw = K / NW, kbase = wave * kw;
-  const bool n_ok = rowbaseA + n < ((EPI == EPI_SILU) ? F : a.N);
+  const bool n_ok = n < TR && rowbaseA + n < ((EPI == EPI_SILU) ? F : a.N);
   const bf16_t* wa = a.W + (size_t)(rowbaseA + (n_ok ? n : 0)) * K + kbase + 8 * g;
   const bf16_t* wb = a.W + (size_t)(rowbaseB + (n_ok ? n : 0)) * K + kbase + 8 * g;
   const bool m_ok = n < a.nrows;                  // A fragment: lane's activation row is (lane & 15)
@@ -308,16 +310,16 @@ __global__ __launch_bounds__(NW * 64) void gemm16_kernel(GemvArgs a) {
   if constexpr (EPI == EPI_SILU) {
     if (t >= 256) return;
     const int m = t >> 4, nn = t & 15;
-    if (m >= a.nrows || 16 * u + nn >= F) return;
+    if (m >= a.nrows || nn >= TR || TR * u + nn >= F) return;
     float vA = 0.f, vB = 0.f;
 #pragma unroll
     for (int w = 0; w < NW; ++w) { vA += s_t[w][0][m][nn]; vB += s_t[w][1][m][nn]; }
-    gemv_epilogue<EPI>(a, m, 16 * u + nn, F + 16 * u + nn, true, 16 * u + nn, vA, vB, 0u, 1.f, 0.f, 0);
+    gemv_epilogue<EPI>(a, m, TR * u + nn, F + TR * u + nn, true, TR * u + nn, vA, vB, 0u, 1.f, 0.f, 0);
   } else {
     if (t >= 128) return;
     const int m = t >> 3, np = t & 7;
-    const int rowA = 16 * u + 2 * np, rowB = rowA + 1;
-    if (m >= a.nrows || rowA >= a.N) return;
+    const int rowA = TR * u + 2 * np, rowB = rowA + 1;
+    if (m >= a.nrows || 2 * np >= TR || rowA >= a.N) return;
     const bool b_ok = rowB < a.N;
     float vA = 0.f, vB = 0.f;
 #pragma unroll
