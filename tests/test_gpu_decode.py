@@ -482,3 +482,33 @@ def test_errors_are_reported_not_crashes(tiny):
         model.generate(cond.to("cuda:0"), max_new_tokens=4, sampling_params=dict(bogus=1))
     with pytest.raises(_lib.ZonosHipError):                                              # beyond the 16384-row RoPE table (_torch.py:206)
         model.generate(cond.to("cuda:0"), max_new_tokens=16400, sampling_params=GREEDY)
+
+
+def test_small_m_projections_match_the_gemv_path(full):
+    """16 activation rows through one block (LDS-staged MFMA projections, K split over workgroups, ticketed combine) vs
+    the same rows two at a time (weight-streaming GEMV kernels): same rounding points, different fp32 summation order.
+    New K/V bit-equal > 0.995, block output bit-equal > 0.9 and within 2^-5 of the output scale (the bar of the
+    single-utterance block test)."""
+    model, _ = full
+    eng = model.engine(8)
+    st = _lib.stream_ptr()
+    L, max_len, R = 40, 64, 16
+    x0 = synth.conditioning(99, "m16.x", R, 1, 2048)[:, 0].contiguous()
+    kv0 = torch.from_numpy(synth.normal(99, "m16.kv", (R, max_len, 2, 4, 128))).to(torch.bfloat16)
+    lengths = torch.full((R,), L - 1, dtype=torch.int32, device="cuda:0")
+    for layer in (0, 7):
+        xa, kva = x0.clone().to("cuda:0"), kv0.clone().to("cuda:0")
+        eng.call("zn_op_layer_decode", layer, xa.data_ptr(), kva.data_ptr(), max_len, lengths.data_ptr(), None, R, st)
+        xb, kvb = x0.clone().to("cuda:0"), kv0.clone().to("cuda:0")
+        for r in range(0, R, 2):
+            xs, ks = xb[r:r + 2].contiguous(), kvb[r:r + 2].contiguous()
+            eng.call("zn_op_layer_decode", layer, xs.data_ptr(), ks.data_ptr(), max_len, lengths[r:r + 2].data_ptr(), None, 2, st)
+            xb[r:r + 2], kvb[r:r + 2] = xs, ks
+        torch.cuda.synchronize()
+        ya, yb = xa.cpu(), xb.cpu()
+        eq = float((ya.view(torch.int16) == yb.view(torch.int16)).float().mean())
+        keq = float((kva[:, L - 1].cpu().view(torch.int16) == kvb[:, L - 1].cpu().view(torch.int16)).float().mean())
+        md = (ya.float() - yb.float()).abs().max().item()
+        print(f"\n[16 rows vs 8 x 2 rows, layer {layer}] new K/V bit-equal {keq:.5f}; output bit-equal {eq:.5f}, max|diff| {md:.4g}")
+        assert keq > 0.995 and eq > 0.9
+        assert md <= 2.0 ** -5 * max(1.0, yb.float().abs().max().item())

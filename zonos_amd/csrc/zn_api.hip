@@ -15,6 +15,8 @@
 
 static thread_local std::string g_create_err;
 #define ZN_GRAPH_STEPS 8
+#define ZN_G16_PART_BYTES ((size_t)8 << 20)
+#define ZN_G16_MAX_GROUPS 1024
 
 struct zn_handle_s {
   zn_config cfg;
@@ -30,6 +32,9 @@ struct zn_handle_s {
   // hybrid backbone (arch 1): residual stream, normalised activations, Mamba2 intermediates
   bf16_t *res = nullptr, *hn = nullptr, *m_zx = nullptr, *m_xbc = nullptr, *m_y = nullptr, *m_g = nullptr;
   int m_nheads = 0, m_conv_dim = 0, m_d_in_proj = 0;
+  float* g16_part = nullptr;   // gemm16s_kernel: split-K partial tiles
+  int* g16_tickets = nullptr;
+  size_t g16_part_bytes = 0;
   float *logits_raw = nullptr, *last_logits = nullptr;
   int* tok_raw = nullptr;
   float *scores = nullptr, *cmax = nullptr;
@@ -49,7 +54,7 @@ struct zn_handle_s {
   int *lengths = nullptr, *codes = nullptr;
   int force_eos_step = -1;
   float eos_bias = 0.f;
-  int tune[8] = {512, 512, 512, 1024, 256, 448, 2, 0};   // target workgroups: in_proj, out_proj, fc1, fc2, heads; [5] longest context of the fused attention launch; [6] > 1: multi-step graphs
+  int tune[8] = {512, 512, 512, 1024, 256, 448, 2, 2};   // target workgroups: in_proj, out_proj, fc1, fc2, heads; [5] longest context of the fused attention launch; [6] > 1: multi-step graphs; [7] > 1: LDS-staged small-M projections
   const int* tok_override = nullptr;
   int tok_override_calls = 0;
   hipStream_t cap_stream = nullptr;
@@ -105,7 +110,7 @@ static void free_graph(zn_handle h) {
 extern "C" int zn_destroy(zn_handle h) {
   if (!h) return ZN_OK;
   free_graph(h);
-  void* ptrs[] = {h->emb_tables_dev, h->x, h->q, h->o1, h->mbuf, h->nbuf, h->logits_raw, h->last_logits, h->tok_raw, h->scores, h->cmax, h->pf_x, h->pf_n, h->pf_qkv, h->pf_a, h->pf_u, h->pf_m, h->st, h->remaining, h->stopping, h->res, h->hn, h->m_zx, h->m_xbc, h->m_y, h->m_g};
+  void* ptrs[] = {h->emb_tables_dev, h->x, h->q, h->o1, h->mbuf, h->nbuf, h->logits_raw, h->last_logits, h->tok_raw, h->scores, h->cmax, h->pf_x, h->pf_n, h->pf_qkv, h->pf_a, h->pf_u, h->pf_m, h->st, h->remaining, h->stopping, h->res, h->hn, h->m_zx, h->m_xbc, h->m_y, h->m_g, h->g16_part, h->g16_tickets};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (h->done_host) (void)hipHostFree(h->done_host);
   if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
@@ -163,6 +168,12 @@ extern "C" int zn_create(const zn_config* cfg, const zn_weights* w, int32_t max_
   ZC(hipMalloc(&h->remaining, (R / 2) * sizeof(int)));
   ZC(hipMalloc(&h->stopping, (R / 2) * sizeof(int)));
   ZC(hipHostMalloc(&h->done_host, sizeof(int) * 4));
+  if (max_rows > 4) {
+    ZC(hipMalloc(&h->g16_part, ZN_G16_PART_BYTES));
+    ZC(hipMalloc(&h->g16_tickets, ZN_G16_MAX_GROUPS * sizeof(int)));
+    ZC(hipMemset(h->g16_tickets, 0, ZN_G16_MAX_GROUPS * sizeof(int)));
+    h->g16_part_bytes = ZN_G16_PART_BYTES;
+  }
   if (c.arch == 1) {
     ZC(hipMalloc(&h->res, R * c.d_model * 2));
     ZC(hipMalloc(&h->hn, R * c.d_model * 2));
@@ -209,6 +220,28 @@ static int launch_gemv_rows(const GemvArgs& a, int rgroup, int ks, int nch, int 
 // group, so batches beyond 2 utterances pay extra HBM traffic until the MFMA small-M path lands).
 // rows in (4, 16]: one weight pass on the matrix cores (gemm16_kernel); LayerNorm, when fused in the GEMV, is a row-wise
 // launch here (amortised over the batch).
+// rows in (4, 16], K a multiple of 256: the LDS-staged kernel (coalesced weight stream); K is split over workgroups until
+// the grid has >= 512 of them, the partial tiles meet in a scratch buffer (allocated by zn_create when max_rows > 4).
+template <int EPI>
+static bool run_gemm16s(zn_handle h, GemvArgs g, hipStream_t s) {
+  const int K = g.K;
+  if (K % ZN_G16_KC || !h->g16_part) return false;
+  const int nrows_w = (EPI == EPI_SILU) ? g.N / 2 : g.N;          // weight rows that define the grid
+  const int per64 = (EPI == EPI_SILU) ? 32 : 64;
+  // 64-row workgroups when that already gives >= 512 of them, else 32-row ones, else split K as well
+  int nwv = 4, groups = (nrows_w + per64 - 1) / per64;
+  if (groups < 512) { nwv = 2; groups = (nrows_w + per64 / 2 - 1) / (per64 / 2); }
+  if (groups > ZN_G16_MAX_GROUPS) return false;
+  int ks = 1;
+  while (groups * ks < 448 && ks < 16 && K % (2 * ks * ZN_G16_KC) == 0) ks *= 2;
+  if (ks > 1 && K / ks < 512) return false;   // short slices: the combine costs more than the direct-fragment kernel's access pattern
+  if ((size_t)ks * 16 * groups * nwv * 16 * sizeof(float) > h->g16_part_bytes) return false;
+  g.part = h->g16_part; g.tickets = h->g16_tickets; g.ksplit = ks;
+  if (nwv == 4) hipLaunchKernelGGL((gemm16s_kernel<EPI, 4>), dim3(groups, ks), dim3(256), 0, s, g);
+  else hipLaunchKernelGGL((gemm16s_kernel<EPI, 2>), dim3(groups, ks), dim3(128), 0, s, g);
+  return true;
+}
+
 template <int PRO, int EPI>
 static int run_gemm16(zn_handle h, GemvArgs a, int rows, hipStream_t s) {
   const int K = a.K;
@@ -235,6 +268,7 @@ static int run_gemm16(zn_handle h, GemvArgs a, int rows, hipStream_t s) {
     if (g.lengths) g.lengths += r0;
     if (g.q_out) g.q_out += (size_t)r0 * a.n_heads * a.hd;
     if (g.kv) g.kv += (size_t)r0 * a.max_len * 2 * a.n_heads_kv * a.hd;
+    if (h->tune[7] > 1 && run_gemm16s<EPI>(h, g, s)) continue;
     if constexpr (EPI != EPI_SILU) {
       if (tiles <= 192 && a.N % 8 == 0) {   // N = d_model: 8-row tiles so that every CU gets a workgroup
         const int t8 = a.N / 8;

@@ -30,6 +30,10 @@ struct GemvArgs {
   bf16_t* kv;            // [rows][max_len][2][Hkv][hd]
   const float* rope;     // [positions][hd/2][2]
   int max_len, n_heads_kv, rope_positions;
+  // gemm16s_kernel (K split over workgroups): fp32 partial tiles [ksplit][16][N] and one arrival ticket per row group
+  float* part;
+  int* tickets;
+  int ksplit;
 };
 
 // Fused epilogues shared by the GEMV (rows <= 4) and the small-M MFMA kernel (rows <= 16): finishes activation row r
@@ -339,6 +343,159 @@ __global__ __launch_bounds__(NW * 64) void gemm16_kernel(GemvArgs a) {
       }
     }
     gemv_epilogue<EPI>(a, m, rowA, rowB, b_ok, rowA >> 1, vA, vB, resid, cs, sn, pos);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ small-M MFMA, LDS-staged
+// gemm16_kernel feeds MFMA fragments straight from global memory: every 16-lane phase of its weight loads touches 16
+// different rows (16 cache lines for 256 bytes), and the vector-memory pipe, not HBM, bounds it (2-3.7 TB/s at 16 rows).
+// Here the weight stream is read the way the GEMV reads it (each 16-lane phase = 256 contiguous bytes of one row), staged
+// in LDS (row stride KC + 8 elements: conflict-free 16-B fragment reads) together with the activation chunk, and the
+// fragments come from LDS.  A workgroup owns 64 weight rows (EPI_SILU: 32 value rows + their 32 gate rows), one 16-row
+// MFMA tile per wave, and walks its K slice in chunks of KC = 256 with the next chunk's global loads in flight during
+// the MFMAs.  Small N (d_model rows) splits K over gridDim.y workgroups: fp32 partial tiles go to a scratch buffer and
+// the last workgroup to arrive (ticket, no waiting) adds them in slice order and runs the epilogue — deterministic.
+#define ZN_G16_KC 256
+ZN_DEVINL void st_wt(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }   // write-through
+ZN_DEVINL float ld_wt(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }   // L2-bypassing
+// NWV = waves (16-row tiles) per workgroup: 4 (64 rows) or 2 (32 rows; more, smaller workgroups for mid-size N).
+template <int EPI, int NWV>
+__global__ __launch_bounds__(NWV * 64) void gemm16s_kernel(GemvArgs a) {
+  constexpr int KC = ZN_G16_KC, LDW = KC + 8, NT = NWV * 64, TN = NWV * 16, HALF = TN / 2;
+  constexpr int XP = 512 / NT;                        // activation pieces per thread (16 rows x 32 pieces)
+  __shared__ __attribute__((aligned(16))) bf16_t Ws[TN * LDW];
+  __shared__ __attribute__((aligned(16))) bf16_t Xs[16 * LDW];
+  __shared__ float Ct[TN][17];
+  __shared__ int s_last;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n = lane & 15, g = lane >> 4;
+  const int grp = blockIdx.x, ys = blockIdx.y;
+  const int K = a.K, F = a.N >> 1;
+  // LDS row j of this workgroup <-> weight row (clamped: never out of bounds; masked in the epilogue)
+  auto wrow = [&](int j) -> int {
+    if constexpr (EPI == EPI_SILU) {
+      const int r = (j < HALF) ? grp * HALF + j : F + grp * HALF + (j - HALF);
+      const int lim = (j < HALF) ? F : a.N;
+      return r < lim ? r : lim - 1;
+    } else {
+      const int r = grp * TN + j;
+      return r < a.N ? r : a.N - 1;
+    }
+  };
+  const int kslice = K / a.ksplit, kbeg = ys * kslice, nchunks = kslice / KC;
+  u32x4 wr[8], xr[XP];
+  const bf16_t* wp[8];
+  int wl[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int idx = j * NT + tid, row = idx >> 5, c16 = idx & 31;      // 32 x 16 B per row chunk
+    wp[j] = a.W + (size_t)wrow(row) * K + kbeg + c16 * 8;
+    wl[j] = row * LDW + c16 * 8;
+  }
+  const bf16_t* xp[XP];
+  int xl[XP];
+#pragma unroll
+  for (int j = 0; j < XP; ++j) {
+    const int idx = j * NT + tid, row = idx >> 5, c16 = idx & 31;
+    xp[j] = a.x + (size_t)(row < a.nrows ? row : a.nrows - 1) * K + kbeg + c16 * 8;
+    xl[j] = row * LDW + c16 * 8;
+  }
+#pragma unroll
+  for (int j = 0; j < XP; ++j) xr[j] = ld16(xp[j]);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) wr[j] = ld_nt16(wp[j]);
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (int c = 0; c < nchunks; ++c) {
+    __syncthreads();                                   // the previous chunk's fragment reads are done
+#pragma unroll
+    for (int j = 0; j < XP; ++j) *(u32x4*)&Xs[xl[j]] = xr[j];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) *(u32x4*)&Ws[wl[j]] = wr[j];
+    __syncthreads();
+    if (c + 1 < nchunks) {
+#pragma unroll
+      for (int j = 0; j < XP; ++j) xr[j] = ld16(xp[j] + (size_t)(c + 1) * KC);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) wr[j] = ld_nt16(wp[j] + (size_t)(c + 1) * KC);
+    }
+    const bf16_t* wf = &Ws[(wave * 16 + n) * LDW + 8 * g];
+    const bf16_t* xf = &Xs[n * LDW + 8 * g];
+#pragma unroll
+    for (int st = 0; st < KC / 32; ++st) {
+      const u32x4 bw = *(const u32x4*)(wf + 32 * st);
+      const u32x4 ax = *(const u32x4*)(xf + 32 * st);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(zn_bf16x8, ax), __builtin_bit_cast(zn_bf16x8, bw), acc, 0, 0, 0);
+    }
+  }
+  // D layout: col (LDS row wave*16 + n) = lane & 15, row (activation row) = 4*(lane>>4) + reg
+  if (a.ksplit > 1) {
+    // partial tiles leave by write-through stores, the ticket follows once they are acknowledged (no cache-wide fence);
+    // the last workgroup to arrive reads every slice past L2 and adds them in slice order
+    const size_t ld = (size_t)gridDim.x * TN;
+    float* pp = a.part + ((size_t)ys * 16) * ld + (size_t)grp * TN + wave * 16 + n;
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) st_wt(pp + (size_t)(4 * g + reg) * ld, acc[reg]);
+    __builtin_amdgcn_s_waitcnt(0);                     // vmcnt(0): stores acknowledged
+    __syncthreads();
+    if (tid == 0) {
+      const int t = __hip_atomic_fetch_add(a.tickets + grp, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      s_last = (t == a.ksplit - 1);
+      if (s_last) __hip_atomic_store(a.tickets + grp, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+    }
+    __syncthreads();
+    if (!s_last) return;
+    // 16 * TN / NT = 4 tile elements per thread, every slice of all four requested before the first add
+    constexpr int IPT = 16 * TN / NT;
+    float v[IPT][16];
+#pragma unroll
+    for (int i = 0; i < IPT; ++i) {
+      const int item = i * NT + tid, m = item / TN, col = item % TN;
+      const float* q = a.part + (size_t)m * ld + (size_t)grp * TN + col;
+#pragma unroll
+      for (int y = 0; y < 16; ++y) v[i][y] = (y < a.ksplit) ? ld_wt(q + (size_t)y * 16 * ld) : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < IPT; ++i) {
+      const int item = i * NT + tid, m = item / TN, col = item % TN;
+      float sum = 0.f;
+#pragma unroll
+      for (int y = 0; y < 16; ++y) sum += v[i][y];
+      Ct[col][m] = sum;
+    }
+  } else {
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) Ct[wave * 16 + n][4 * g + reg] = acc[reg];
+  }
+  __syncthreads();
+  // ---- epilogue: TN/2 row pairs x 16 activation rows, 2 items per thread
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int item = it * NT + tid, m = item & 15, pj = item >> 4;       // pj in [0, TN/2)
+    if (m >= a.nrows) continue;
+    if constexpr (EPI == EPI_SILU) {
+      const int u = grp * HALF + pj;
+      if (u >= F) continue;
+      gemv_epilogue<EPI>(a, m, u, F + u, true, u, Ct[pj][m], Ct[HALF + pj][m], 0u, 1.f, 0.f, 0);
+    } else {
+      const int rowA = grp * TN + 2 * pj, rowB = rowA + 1;
+      if (rowA >= a.N) continue;
+      const bool b_ok = rowB < a.N;
+      unsigned resid = 0; float cs = 1.f, sn = 0.f; int pos = 0;
+      if constexpr (EPI == EPI_RESID) {
+        const size_t o = (size_t)m * a.N + rowA;
+        resid = b_ok ? *(const unsigned*)(a.resid + o) : (unsigned)a.resid[o];
+      }
+      if constexpr (EPI == EPI_ROPE_KV) {
+        pos = a.lengths[m];
+        if (rowA < (a.n_heads + a.n_heads_kv) * a.hd) {
+          const int i = (rowA % a.hd) >> 1;
+          const int p = pos < a.rope_positions ? pos : a.rope_positions - 1;
+          const float2 c2 = *(const float2*)(a.rope + ((size_t)p * (a.hd >> 1) + i) * 2);
+          cs = c2.x; sn = c2.y;
+        }
+      }
+      gemv_epilogue<EPI>(a, m, rowA, rowB, b_ok, rowA >> 1, Ct[2 * pj][m], b_ok ? Ct[2 * pj + 1][m] : 0.f, resid, cs, sn, pos);
+    }
   }
 }
 
