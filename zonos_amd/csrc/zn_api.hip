@@ -450,8 +450,9 @@ static int mamba_mixer(zn_handle h, int li, const bf16_t* n, void* state, bf16_t
   m.d_inner = c.m_d_inner; m.conv_dim = h->m_conv_dim; m.nheads = h->m_nheads; m.d_state = c.m_d_state; m.ngroups = c.m_ngroups;
   m.d_in_proj = h->m_d_in_proj; m.eps = c.norm_eps;
   hipLaunchKernelGGL(mamba_conv_kernel, dim3((h->m_conv_dim + 255) / 256, rows), dim3(256), 0, s, m);
-  if (c.m_d_state == 128) hipLaunchKernelGGL((mamba_ssm_kernel<128>), dim3(h->m_nheads, rows), dim3(256), 0, s, m);
-  else hipLaunchKernelGGL((mamba_ssm_kernel<64>), dim3(h->m_nheads, rows), dim3(256), 0, s, m);
+  m.rows = rows;
+  if (c.m_d_state == 128) hipLaunchKernelGGL((mamba_ssm_kernel<128, 2>), dim3(h->m_nheads, (rows + 1) / 2), dim3(256), 0, s, m);
+  else hipLaunchKernelGGL((mamba_ssm_kernel<64, 2>), dim3(h->m_nheads, (rows + 1) / 2), dim3(256), 0, s, m);
   hipLaunchKernelGGL(mamba_gated_norm_kernel, dim3(c.m_ngroups, rows), dim3(256), 0, s, m);
   {
     GemvArgs a{};
