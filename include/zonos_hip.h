@@ -200,9 +200,10 @@ int zn_op_sample(zn_handle h, const float* logits_dev, const int32_t* recent_dev
                  int32_t batch, zn_stream stream);
 
 /* ---------------------------------------------------------------- DAC decode (autoencoder.py:119-170) */
-typedef struct zn_dac_config { /* transformers DacConfig fields used by decode */
+typedef struct zn_dac_config { /* transformers DacConfig fields used by decode / encode */
   int32_t n_codebooks, codebook_size, codebook_dim, hidden_size, decoder_hidden_size;
-  int32_t n_ratios; int32_t ratios[8]; /* upsampling_ratios, e.g. 8,8,4,2 */
+  int32_t n_ratios; int32_t ratios[8]; /* upsampling_ratios, e.g. 8,8,4,2 (downsampling_ratios = reversed) */
+  int32_t encoder_hidden_size;         /* 64; 0 = no encoder */
 } zn_dac_config;
 typedef struct zn_dac_tensor { const char* name; const float* data_dev; int64_t numel; } zn_dac_tensor;
 /* Weights by their transformers state-dict names (fp32, device).  The library re-lays them out once. */
@@ -211,6 +212,10 @@ int zn_dac_destroy(zn_dac d);
 const char* zn_dac_last_error(zn_dac d);
 /* DACAutoencoder.decode: codes int32 [B, n_codebooks, T] -> wav fp32 [B, 1, hop*T]. */
 int zn_dac_decode(zn_dac d, const int32_t* codes_dev, int32_t batch, int32_t T, float* wav_dev, zn_stream stream);
+/* DACAutoencoder.encode (zonos/autoencoder.py:103-117 -> DacModel.encode): wav fp32 [B, T] at the codec rate, T a
+ * positive multiple of the hop (preprocess pads) -> codes int32 [B, n_codebooks, T / hop].  Needs the encoder.* and
+ * quantizer.quantizers.{i}.in_proj tensors at zn_dac_create. */
+int zn_dac_encode(zn_dac d, const float* wav_dev, int32_t batch, int32_t T, int32_t* codes_dev, zn_stream stream);
 
 #ifdef __cplusplus
 }

@@ -539,3 +539,41 @@ def dac_decode_to_int16(dw: dict, codes: torch.Tensor) -> torch.Tensor:
     """zonos/autoencoder.py:165-170 — clamp(wav*32767, +-32767) -> int16, shape [512T, 1] (batch 1)."""
     wav = dac_decode(dw, codes).squeeze(1)
     return torch.clamp(wav * 32767.0, -32767.0, 32767.0).to(torch.int16).squeeze(0).unsqueeze(1)
+
+
+# --------------------------------------------------------------------------- DAC encode
+def dac_vq_nearest(dw: dict, q: str, lat: torch.Tensor):
+    """modeling_dac.py:156-172 decode_latents — nearest code on L2-normalised vectors; lat [B, dim, T]."""
+    B, D, T = lat.shape
+    enc = F.normalize(lat.permute(0, 2, 1).reshape(B * T, D))
+    cb = F.normalize(dw[q + "codebook.weight"])
+    l2 = enc.pow(2).sum(1, keepdim=True)
+    dist = -(l2 - 2 * enc @ cb.t()) + cb.pow(2).sum(1, keepdim=True).t()
+    idx = dist.max(1)[1].reshape(B, T)
+    return F.embedding(idx, dw[q + "codebook.weight"]).transpose(1, 2), idx
+
+
+def dac_encode(dw: dict, wav: torch.Tensor, ratios=(8, 8, 4, 2), collect: dict | None = None) -> torch.Tensor:
+    """zonos/autoencoder.py:117 -> modeling_dac.py:599-602: DacEncoder (:464-473; blocks :227-233 with
+    downsampling_ratios = reversed(ratios), strided conv k = 2s, pad ceil(s/2)) then the residual VQ (:310-340):
+    wav fp32 [B, 1, T] -> codes int64 [B, 9, T / prod(ratios)]."""
+    h = F.conv1d(wav, dw["encoder.conv1.weight"], dw["encoder.conv1.bias"], padding=3)
+    for bi, s in enumerate(reversed(ratios)):
+        b = f"encoder.block.{bi}."
+        for u, dil in ((1, 1), (2, 3), (3, 9)):
+            h = dac_residual_unit(dw, b + f"res_unit{u}.", h, dil)
+        h = F.conv1d(snake(h, dw[b + "snake1.alpha"]), dw[b + "conv1.weight"], dw[b + "conv1.bias"], stride=s, padding=math.ceil(s / 2))
+        if collect is not None:
+            collect[f"block{bi}"] = h
+    z = F.conv1d(snake(h, dw["encoder.snake1.alpha"]), dw["encoder.conv2.weight"], dw["encoder.conv2.bias"], padding=1)
+    if collect is not None:
+        collect["z"] = z
+    residual, codes = z, []
+    n_q = sum(1 for k in dw if k.endswith(".in_proj.weight"))
+    for i in range(n_q):
+        q = f"quantizer.quantizers.{i}."
+        lat = F.conv1d(residual, dw[q + "in_proj.weight"], dw[q + "in_proj.bias"])
+        quant, idx = dac_vq_nearest(dw, q, lat)
+        residual = residual - F.conv1d(quant, dw[q + "out_proj.weight"], dw[q + "out_proj.bias"])
+        codes.append(idx)
+    return torch.stack(codes, dim=1)

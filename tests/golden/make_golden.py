@@ -7,7 +7,7 @@ builds `zonos.model.Zonos` around `TorchZonosBackbone` with the build's syntheti
 real `Zonos.generate()`, of `zonos.sampling`, `zonos.codebook_pattern`, `zonos.backbone._torch` and of
 `transformers.models.dac.DacModel.decode`.  Only data (inputs' seeds + expected outputs) is written.
 
-    python tests/golden/make_golden.py [--only tiny,full,ops,sampling,eos,dac]
+    python tests/golden/make_golden.py [--only tiny,full,ops,sampling,eos,dac,dacenc]
 """
 import argparse
 import importlib.machinery
@@ -282,6 +282,28 @@ def main():
                 out[f"rms_block{bi}"] = np.float32(h.pow(2).mean().sqrt())
         np.savez_compressed(f"{HERE}/dac.npz", **out)
         print("dac done")
+
+    if "dacenc" in only:
+        # DacModel.encode (the call zonos/autoencoder.py:117 makes) on synthetic waveforms: codes + encoder latents
+        from transformers.models.dac import DacConfig, DacModel
+        seed = 4321
+        dm = DacModel(DacConfig(sampling_rate=44100)).eval()
+        dsd = synth.dac_state_dict(seed)
+        full = dm.state_dict()
+        missing = [k for k in dsd if k not in full]
+        assert not missing, missing
+        full.update(dsd)
+        dm.load_state_dict(full)
+        out = dict(seed=seed)
+        for T in (512 * 6, 512 * 23):
+            wav = synth.test_waveform(seed, f"encwav{T}", T)
+            with torch.no_grad():
+                enc = dm.encode(wav)
+                z = dm.encoder(wav)
+            out[f"codes_{T}"] = enc.audio_codes.numpy().astype(np.int16)
+            out[f"z_{T}"] = z.numpy().astype(np.float32)
+        np.savez_compressed(f"{HERE}/dac_encode.npz", **out)
+        print("dacenc done")
 
 
 if __name__ == "__main__":

@@ -167,3 +167,18 @@ def test_dac_decode_matches_transformers(golden_dir):
             assert abs(float(col["conv1"].pow(2).mean().sqrt()) - float(g["rms_conv1"])) < 1e-5
             for bi in range(4):
                 assert abs(float(col[f"block{bi}"].pow(2).mean().sqrt()) - float(g[f"rms_block{bi}"])) < 1e-4 * max(1.0, float(g[f"rms_block{bi}"]))
+
+
+def test_dac_encode_matches_transformers(golden_dir):
+    """oracle dac_encode vs transformers DacModel.encode (the call at zonos/autoencoder.py:117) on synthetic weights and
+    waveforms: codes bit-exact, encoder latents equal."""
+    g = _load(golden_dir, "dac_encode")
+    seed = int(g["seed"])
+    dw = synth.dac_state_dict(seed)
+    for T in (512 * 6, 512 * 23):
+        wav = synth.test_waveform(seed, f"encwav{T}", T)
+        col = {}
+        codes = zo.dac_encode(dw, wav, collect=col)
+        assert codes.shape == (1, 9, T // 512)
+        assert np.array_equal(codes.numpy(), g[f"codes_{T}"].astype(np.int64))
+        assert np.abs(col["z"].numpy() - g[f"z_{T}"]).max() <= 1e-6

@@ -42,7 +42,7 @@ class zn_sampling(C.Structure):
 
 class zn_dac_config(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("n_codebooks", "codebook_size", "codebook_dim", "hidden_size", "decoder_hidden_size", "n_ratios")] + \
-               [("ratios", C.c_int32 * 8)]
+               [("ratios", C.c_int32 * 8), ("encoder_hidden_size", C.c_int32)]
 
 
 class zn_dac_tensor(C.Structure):
@@ -88,6 +88,7 @@ SIGNATURES = {
     "zn_dac_destroy": (C.c_int, [C.c_void_p]),
     "zn_dac_last_error": (C.c_char_p, [C.c_void_p]),
     "zn_dac_decode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+    "zn_dac_encode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
 }
 
 _lib = None

@@ -1,13 +1,16 @@
-"""`DACAutoencoder` — zonos/autoencoder.py:50-170 surface over the HIP DAC decoder.
+"""`DACAutoencoder` — zonos/autoencoder.py:50-170 surface over the HIP DAC codec.
 
-`decode(codes) -> float32 [B, 1, 512*T]` and `decode_to_int16` run in libzonos_hip.so (fp32 arithmetic: the
-reference's CPU path disables autocast, autoencoder.py:139).  Weights use the transformers `DacModel`
-state-dict names (the reference loads `descript/dac_44khz`, autoencoder.py:74 — a network fetch, so here they
-come from a local safetensors file or a state dict).  `preprocess`/`encode` are the "next" row.
+`decode(codes) -> float32 [B, 1, 512*T]`, `decode_to_int16` and `encode(wav) -> int64 [B, 9, T/512]` run in
+libzonos_hip.so (fp32 arithmetic: the reference's CPU path disables autocast, autoencoder.py:139).  Weights use the
+transformers `DacModel` state-dict names (the reference loads `descript/dac_44khz`, autoencoder.py:74 — a network
+fetch, so here they come from a local safetensors file or a state dict).  `preprocess` pads on the left to a multiple
+of 512 like the reference; its resampler restates torchaudio's `sinc_interp_hann` (torchaudio is not installed here:
+that step is unpinned, identity at 44.1 kHz input).
 """
 from __future__ import annotations
 
 import ctypes as C
+import math
 
 import numpy as np
 import torch
@@ -16,7 +19,34 @@ from . import _lib
 
 # transformers DacConfig defaults = descript/dac_44khz (configuration_dac.py:55-70)
 DAC_44KHZ = dict(n_codebooks=9, codebook_size=1024, codebook_dim=8, hidden_size=1024, decoder_hidden_size=1536,
-                 upsampling_ratios=(8, 8, 4, 2), sampling_rate=44100)
+                 encoder_hidden_size=64, upsampling_ratios=(8, 8, 4, 2), sampling_rate=44100)
+
+
+def sinc_resample(wav: torch.Tensor, orig_freq: int, new_freq: int, lowpass_filter_width: int = 6, rolloff: float = 0.99) -> torch.Tensor:
+    """torchaudio.functional.resample(..., resampling_method="sinc_interp_hann") as published (the call the reference
+    makes at zonos/autoencoder.py:98 with the defaults): windowed-sinc polyphase filter applied as a strided conv1d.
+    torchaudio is not installed in this environment, so this restatement is unpinned; equal rates return the input."""
+    orig_freq, new_freq = int(orig_freq), int(new_freq)
+    if orig_freq == new_freq:
+        return wav
+    g = math.gcd(orig_freq, new_freq)
+    o, n = orig_freq // g, new_freq // g
+    base = min(o, n) * rolloff
+    width = math.ceil(lowpass_filter_width * o / base)
+    idx = torch.arange(-width, width + o, dtype=torch.float64, device=wav.device)[None, None] / o
+    t = torch.arange(0, -n, -1, dtype=torch.float64, device=wav.device)[:, None, None] / n + idx
+    t = (t * base).clamp_(-lowpass_filter_width, lowpass_filter_width)
+    window = torch.cos(t * math.pi / lowpass_filter_width / 2) ** 2
+    t = t * math.pi
+    kernels = torch.where(t == 0, torch.ones_like(t), t.sin() / t) * window * (base / o)
+    kernels = kernels.to(torch.float32)
+    shape = wav.shape
+    x = wav.reshape(-1, shape[-1]).to(torch.float32)
+    length = x.shape[-1]
+    x = torch.nn.functional.pad(x, (width, width + o))
+    y = torch.nn.functional.conv1d(x[:, None], kernels, stride=o).transpose(1, 2).reshape(x.shape[0], -1)
+    y = y[..., : math.ceil(n * length / o)]
+    return y.reshape(shape[:-1] + y.shape[-1:])
 
 
 class DACAutoencoder:
@@ -41,7 +71,7 @@ class DACAutoencoder:
     def load_state_dict(self, sd: dict, device=None):
         dev = torch.device(device if device is not None else (self.device or "cuda"))
         keep = {k: v.detach().to(device=dev, dtype=torch.float32).contiguous() for k, v in sd.items()
-                if k.startswith("quantizer.") and (".codebook.weight" in k or ".out_proj." in k) or k.startswith("decoder.")}
+                if k.startswith(("quantizer.quantizers.", "decoder.", "encoder."))}
         self._weights, self.device = keep, dev
         self._destroy()
 
@@ -74,7 +104,8 @@ class DACAutoencoder:
         lib = _lib.load()
         c = self.cfg
         zc = _lib.zn_dac_config(n_codebooks=c["n_codebooks"], codebook_size=c["codebook_size"], codebook_dim=c["codebook_dim"],
-                                hidden_size=c["hidden_size"], decoder_hidden_size=c["decoder_hidden_size"], n_ratios=len(c["upsampling_ratios"]))
+                                hidden_size=c["hidden_size"], decoder_hidden_size=c["decoder_hidden_size"], n_ratios=len(c["upsampling_ratios"]),
+                                encoder_hidden_size=c["encoder_hidden_size"] if "encoder.conv1.weight" in self._weights else 0)
         for i, r in enumerate(c["upsampling_ratios"]):
             zc.ratios[i] = r
         names = sorted(self._weights)
@@ -88,10 +119,29 @@ class DACAutoencoder:
         return h
 
     def preprocess(self, wav: torch.Tensor, sr: int) -> torch.Tensor:
-        raise NotImplementedError("DAC preprocess/encode is the next row after the hot path (SURVEY.md §8f #2)")
+        """autoencoder.py:80-101: resample to 44.1 kHz, zero-pad on the LEFT to a multiple of 512 samples."""
+        wav = sinc_resample(wav, sr, self.sampling_rate)
+        left_pad = math.ceil(wav.shape[-1] / self.hop) * self.hop - wav.shape[-1]
+        return torch.nn.functional.pad(wav, (left_pad, 0), value=0)
 
+    @torch.inference_mode()
     def encode(self, wav: torch.Tensor) -> torch.Tensor:
-        raise NotImplementedError("DAC preprocess/encode is the next row after the hot path (SURVEY.md §8f #2)")
+        """autoencoder.py:103-117: preprocessed audio [B, 1, T] (or [B, T]) -> int64 codes [B, 9, T / 512]."""
+        h = self._handle()
+        if "encoder.conv1.weight" not in self._weights:
+            raise _lib.ZonosHipError("this DACAutoencoder was built from decoder-only weights: encode() needs encoder.* and in_proj tensors")
+        if wav.dim() == 3:
+            if wav.shape[1] != 1:
+                raise ValueError(f"expected mono audio [B, 1, T], got {tuple(wav.shape)}")
+            wav = wav[:, 0]
+        B, T = wav.shape
+        if T < self.hop or T % self.hop:
+            raise ValueError(f"audio length {T} is not a positive multiple of {self.hop}: call preprocess() first (autoencoder.py:99-100)")
+        x = wav.to(device=self.device, dtype=torch.float32).contiguous()
+        codes = torch.empty(B, self.num_codebooks, T // self.hop, dtype=torch.int32, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check_dac(_lib.load().zn_dac_encode(h, x.data_ptr(), B, T, codes.data_ptr(), _lib.stream_ptr()), h, "zn_dac_encode")
+        return codes.to(torch.int64)
 
     @torch.inference_mode()
     def decode(self, codes: torch.Tensor) -> torch.Tensor:

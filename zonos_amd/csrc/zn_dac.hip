@@ -6,6 +6,13 @@
 // (NT*32)-channel output tile, the input rows it needs (with the dilation halo) are staged once per 16-channel chunk in
 // LDS with the Snake activation applied on the way in, and all taps of the chunk's weights sit next to them.
 // ConvTranspose1d(k = 2s, stride s) is s independent 2-tap GEMMs (one per output phase).
+//
+// DAC encode (zonos/autoencoder.py:103-117 -> modeling_dac.py:583-608 DacModel.encode, :444-473 DacEncoder, :212-233
+// DacEncoderBlock, :283-345 residual VQ, :123-172 DacVectorQuantize).  The strided Conv1d(k = 2s, stride s, pad
+// ceil(s/2)) of an encoder block reads the channels-last input as rows of s time steps ([T/s][s*C], the same memory):
+// out[t] touches rows t-1, t, t+1, i.e. it is a 3-tap stride-1 GEMM with K = s*C whose re-laid-out weight is zero where
+// the 2s-tap window does not reach (1.5x the MACs of the minimum on layers that hold ~10 % of the encoder's work, no
+// gather, and the zero padding is the kernel's ordinary row-range check).  The residual VQ runs one workgroup per frame.
 #include "../../include/zonos_hip.h"
 #include "zn_common.h"
 
@@ -186,6 +193,130 @@ __global__ __launch_bounds__(DAC_FIN_T) void dac_final_kernel(const float* in, c
   out[(size_t)b * T + t] = tanhf(acc + bias[0]);
 }
 
+// ------------------------------------------------------------------------------------------------ encoder pieces
+// strided conv weight [Cout][C][2s] -> [3 row taps][s*C][CoutPad]: row tap j (input row t-1+j), element e of the row,
+// channel ci <-> conv tap (j-1)*s + e + pad, zero where that tap does not exist (modeling_dac.py:222-224)
+__global__ void dac_wstride_kernel(const float* w, float* o, int Cout, int C, int s, int pad, int CoutPad) {
+  const size_t n = (size_t)3 * s * C * CoutPad;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const int co = i % CoutPad, ci = (i / CoutPad) % C, e = (i / ((size_t)CoutPad * C)) % s, j = i / ((size_t)CoutPad * C * s);
+    const int tap = (j - 1) * s + e + pad;
+    o[i] = (co < Cout && tap >= 0 && tap < 2 * s) ? w[((size_t)co * C + ci) * (2 * s) + tap] : 0.f;
+  }
+}
+__global__ void dac_tile_kernel(const float* a, float* o, int C, int reps) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < C * reps; i += gridDim.x * blockDim.x) o[i] = a[i % C];
+}
+// encoder.conv1: Conv1d(1 -> C, k = 7, pad 3) on the waveform (modeling_dac.py:451,465); out channels-last [B][T][C]
+__global__ __launch_bounds__(256) void dac_enc_conv1_kernel(const float* wav, const float* w /*[C][1][7]*/, const float* bias, float* out, int T, int C) {
+  const int b = blockIdx.y;
+  const size_t idx = blockIdx.x * (size_t)256 + threadIdx.x;       // over T * C
+  if (idx >= (size_t)T * C) return;
+  const int t = idx / C, co = idx % C;
+  const float* x = wav + (size_t)b * T;
+  float acc = bias[co];
+#pragma unroll
+  for (int k = 0; k < 7; ++k) {
+    const int tt = t + k - 3;
+    acc = fmaf(w[co * 7 + k], (tt >= 0 && tt < T) ? x[tt] : 0.f, acc);
+  }
+  out[(size_t)b * T * C + idx] = acc;
+}
+// F.normalize rows of a codebook (x / max(||x||, 1e-12)) and their squared norms (modeling_dac.py:163,167)
+__global__ void dac_cbnorm_kernel(const float* cb, float* cbn, float* cbsq, int n, int dim) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float ss = 0.f;
+  for (int j = 0; j < dim; ++j) ss += cb[(size_t)i * dim + j] * cb[(size_t)i * dim + j];
+  const float nrm = fmaxf(sqrtf(ss), 1e-12f);
+  float s2 = 0.f;
+  for (int j = 0; j < dim; ++j) { const float v = cb[(size_t)i * dim + j] / nrm; cbn[(size_t)i * dim + j] = v; s2 += v * v; }
+  cbsq[i] = s2;
+}
+// Residual vector quantisation of one latent frame (modeling_dac.py:310-340 over :123-172): for each codebook in order:
+// e = in_proj(residual) (Conv1d 1x1 hidden -> dim), nearest code by dist = -(|e_n|^2 - 2 e_n . c_n) + |c_n|^2 on
+// L2-normalised vectors (first maximum wins), residual -= out_proj(codebook[idx]).  256 threads per frame.
+#define DAC_RVQ_MAXDIM 8
+struct RvqArgs {
+  const float* z;            // [B][T][hidden] encoder output
+  const float* const* w_in;  // per codebook [dim][hidden]
+  const float* const* b_in;  // [dim]
+  const float* const* cb;    // [size][dim] raw
+  const float* const* cbn;   // [size][dim] normalised
+  const float* const* cbsq;  // [size]
+  const float* const* w_out; // [hidden][dim]
+  const float* const* b_out; // [hidden]
+  int* codes;                // [B][nq][T]
+  int nq, T, hidden, dim, size;
+};
+__global__ __launch_bounds__(256) void dac_rvq_kernel(RvqArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* res = smem;                       // [hidden]
+  __shared__ float s_part[4][DAC_RVQ_MAXDIM];
+  __shared__ float s_e[DAC_RVQ_MAXDIM];
+  __shared__ float s_bv[4];
+  __shared__ int s_bi[4];
+  __shared__ int s_idx;
+  const int t = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* zr = a.z + ((size_t)b * a.T + t) * a.hidden;
+  for (int c = tid; c < a.hidden; c += 256) res[c] = zr[c];
+  __syncthreads();
+  for (int q = 0; q < a.nq; ++q) {
+    // projected latent e[j] = b_in[j] + sum_c W_in[j][c] * res[c]
+    float pj[DAC_RVQ_MAXDIM];
+#pragma unroll
+    for (int j = 0; j < DAC_RVQ_MAXDIM; ++j) pj[j] = 0.f;
+    for (int c = tid; c < a.hidden; c += 256) {
+      const float r = res[c];
+#pragma unroll
+      for (int j = 0; j < DAC_RVQ_MAXDIM; ++j) if (j < a.dim) pj[j] = fmaf(a.w_in[q][(size_t)j * a.hidden + c], r, pj[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < DAC_RVQ_MAXDIM; ++j) { pj[j] = wave_sum(pj[j]); if (lane == 0) s_part[wave][j] = pj[j]; }
+    __syncthreads();
+    if (tid == 0) {
+      float e[DAC_RVQ_MAXDIM], ss = 0.f;
+      for (int j = 0; j < a.dim; ++j) { e[j] = ((s_part[0][j] + s_part[1][j]) + (s_part[2][j] + s_part[3][j])) + a.b_in[q][j]; ss += e[j] * e[j]; }
+      const float nrm = fmaxf(sqrtf(ss), 1e-12f);
+      for (int j = 0; j < a.dim; ++j) s_e[j] = e[j] / nrm;
+    }
+    __syncthreads();
+    float en[DAC_RVQ_MAXDIM], l2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < DAC_RVQ_MAXDIM; ++j) { en[j] = j < a.dim ? s_e[j] : 0.f; l2 += en[j] * en[j]; }
+    float best = -INFINITY; int bi = 0x7fffffff;
+    for (int code = tid; code < a.size; code += 256) {
+      float mm = 0.f;
+#pragma unroll
+      for (int j = 0; j < DAC_RVQ_MAXDIM; ++j) if (j < a.dim) mm = fmaf(en[j], a.cbn[q][(size_t)code * a.dim + j], mm);
+      const float dist = -(l2 - 2.0f * mm) + a.cbsq[q][code];
+      if (dist > best) { best = dist; bi = code; }           // ascending codes per thread: the first maximum stays
+    }
+    // block argmax, lowest index among equal maxima
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      const float ov = __shfl_xor(best, off); const int oi = __shfl_xor(bi, off);
+      if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+    }
+    if (lane == 0) { s_bv[wave] = best; s_bi[wave] = bi; }
+    __syncthreads();
+    if (tid == 0) {
+      float bv = s_bv[0]; int ix = s_bi[0];
+      for (int w = 1; w < 4; ++w) if (s_bv[w] > bv || (s_bv[w] == bv && s_bi[w] < ix)) { bv = s_bv[w]; ix = s_bi[w]; }
+      s_idx = ix;
+      a.codes[((size_t)b * a.nq + q) * a.T + t] = ix;
+    }
+    __syncthreads();
+    const int ix = s_idx;
+    for (int c = tid; c < a.hidden; c += 256) {
+      float o = 0.f;
+      for (int j = 0; j < a.dim; ++j) o = fmaf(a.w_out[q][(size_t)c * a.dim + j], a.cb[q][(size_t)ix * a.dim + j], o);
+      res[c] = res[c] - (o + a.b_out[q][c]);
+    }
+    __syncthreads();
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ host
 struct ConvLayer { float *w = nullptr; const float *bias = nullptr, *alpha = nullptr; int Cin = 0, Cout = 0, CoutPad = 0, K = 0, dil = 1, stride = 0; };
 struct zn_dac_s {
@@ -197,6 +328,12 @@ struct zn_dac_s {
   int fin_C = 0;
   float* buf[3] = {nullptr, nullptr, nullptr};
   size_t buf_elems = 0;
+  // encoder (optional: present when the state dict carries encoder.* and quantizer in_proj tensors)
+  bool has_encoder = false;
+  const float *enc_w1 = nullptr, *enc_b1 = nullptr;
+  struct EncBlock { ConvLayer c1[3], c2[3]; ConvLayer down; float* alpha_tiled = nullptr; int stride = 0; } eblocks[8];
+  ConvLayer enc_conv2;
+  const float** rvq_ptrs = nullptr;      // device: 7 arrays of n_codebooks pointers (w_in, b_in, cb, cbn, cbsq, w_out, b_out)
   std::vector<float*> owned;
   std::string err;
 };
@@ -215,7 +352,8 @@ extern "C" int zn_dac_destroy(zn_dac d) {
 }
 
 // output channels are tiled by 128 (NT = 4) or, when that divides evenly, by 96 (NT = 3: the 192- and 96-channel stages)
-static int pad32(int c) { return c % 128 == 0 ? c : (c % 96 == 0 ? c : (c + 127) / 128 * 128); }
+static int pad32(int c) { return c % 128 == 0 ? c : (c % 96 == 0 ? c : (c % 64 == 0 ? c : (c + 127) / 128 * 128)); }
+static int tile_nt(int coutpad) { return coutpad % 128 == 0 ? 4 : (coutpad % 96 == 0 ? 3 : 2); }
 
 static int make_conv(zn_dac d, const std::map<std::string, const zn_dac_tensor*>& t, const std::string& wname, const std::string& bname,
                      const char* aname, int Cin, int Cout, int K, int dil, ConvLayer& L) {
@@ -288,15 +426,87 @@ extern "C" int zn_dac_create(const zn_dac_config* cfg, const zn_dac_tensor* tens
   auto fa = t.find("decoder.snake1.alpha"), fw = t.find("decoder.conv2.weight"), fb = t.find("decoder.conv2.bias");
   if (fa == t.end() || fw == t.end() || fb == t.end() || fw->second->numel != (int64_t)c * 7) { d->err = "missing/mis-shaped final conv tensors"; return fail(ZN_ERR_ARG); }
   d->fin_alpha = fa->second->data_dev; d->fin_w = fw->second->data_dev; d->fin_b = fb->second->data_dev; d->fin_C = c;
+  // ---- encoder + residual VQ (DacEncoder, modeling_dac.py:444-473; DacResidualVectorQuantizer :283-345)
+  if (t.count("encoder.conv1.weight") && t.count("quantizer.quantizers.0.in_proj.weight") && cfg->encoder_hidden_size > 0) {
+    const int eh = cfg->encoder_hidden_size;
+    auto w1 = t.find("encoder.conv1.weight"), b1 = t.find("encoder.conv1.bias");
+    if (b1 == t.end() || w1->second->numel != (int64_t)eh * 7 || eh % 64) { d->err = "missing/mis-shaped encoder.conv1"; return fail(ZN_ERR_ARG); }
+    d->enc_w1 = w1->second->data_dev; d->enc_b1 = b1->second->data_dev;
+    int ch = eh;
+    for (int bi = 0; bi < cfg->n_ratios; ++bi) {
+      const std::string p = "encoder.block." + std::to_string(bi) + ".";
+      const int st = cfg->ratios[cfg->n_ratios - 1 - bi];                 // downsampling_ratios = reversed upsampling ratios
+      auto& E = d->eblocks[bi];
+      E.stride = st;
+      const int dils[3] = {1, 3, 9};
+      for (int u = 0; u < 3; ++u) {
+        const std::string r = p + "res_unit" + std::to_string(u + 1) + ".";
+        const std::string a1 = r + "snake1.alpha", a2 = r + "snake2.alpha";
+        if ((rc = make_conv(d, t, r + "conv1.weight", r + "conv1.bias", a1.c_str(), ch, ch, 7, dils[u], E.c1[u]))) return fail(rc);
+        if ((rc = make_conv(d, t, r + "conv2.weight", r + "conv2.bias", a2.c_str(), ch, ch, 1, 1, E.c2[u]))) return fail(rc);
+      }
+      auto w = t.find(p + "conv1.weight"), b = t.find(p + "conv1.bias"), al = t.find(p + "snake1.alpha");
+      if (w == t.end() || b == t.end() || al == t.end() || w->second->numel != (int64_t)2 * ch * ch * 2 * st || al->second->numel != ch) {
+        d->err = "missing/mis-shaped strided conv tensors in encoder block " + std::to_string(bi); return fail(ZN_ERR_ARG);
+      }
+      ConvLayer& D = E.down;
+      D.Cin = st * ch; D.Cout = 2 * ch; D.CoutPad = pad32(2 * ch); D.K = 3; D.dil = 1; D.bias = b->second->data_dev;
+      if (hipMalloc(&D.w, (size_t)3 * st * ch * D.CoutPad * sizeof(float)) != hipSuccess || hipMalloc(&E.alpha_tiled, (size_t)st * ch * sizeof(float)) != hipSuccess) {
+        d->err = "hipMalloc failed"; return fail(ZN_ERR_HIP);
+      }
+      d->owned.push_back(D.w); d->owned.push_back(E.alpha_tiled);
+      hipLaunchKernelGGL(dac_wstride_kernel, dim3(512), dim3(256), 0, 0, w->second->data_dev, D.w, 2 * ch, ch, st, (st + 1) / 2, D.CoutPad);
+      hipLaunchKernelGGL(dac_tile_kernel, dim3(64), dim3(256), 0, 0, al->second->data_dev, E.alpha_tiled, ch, st);
+      D.alpha = E.alpha_tiled;
+      ch *= 2;
+    }
+    if ((rc = make_conv(d, t, "encoder.conv2.weight", "encoder.conv2.bias", "encoder.snake1.alpha", ch, cfg->hidden_size, 3, 1, d->enc_conv2))) return fail(rc);
+    if (cfg->codebook_dim > DAC_RVQ_MAXDIM) { d->err = "codebook_dim > 8"; return fail(ZN_ERR_UNSUPPORTED); }
+    const int nq = cfg->n_codebooks;
+    std::vector<const float*> ptrs(7 * nq);
+    for (int i = 0; i < nq; ++i) {
+      const std::string q = "quantizer.quantizers." + std::to_string(i) + ".";
+      auto wi = t.find(q + "in_proj.weight"), bi2 = t.find(q + "in_proj.bias"), e = t.find(q + "codebook.weight"), wo = t.find(q + "out_proj.weight"),
+           bo = t.find(q + "out_proj.bias");
+      if (wi == t.end() || bi2 == t.end() || wi->second->numel != (int64_t)cfg->codebook_dim * cfg->hidden_size) { d->err = "missing/mis-shaped in_proj of codebook " + std::to_string(i); return fail(ZN_ERR_ARG); }
+      float *cbn = nullptr, *cbsq = nullptr;
+      if (hipMalloc(&cbn, (size_t)cfg->codebook_size * cfg->codebook_dim * sizeof(float)) != hipSuccess || hipMalloc(&cbsq, cfg->codebook_size * sizeof(float)) != hipSuccess) {
+        d->err = "hipMalloc failed"; return fail(ZN_ERR_HIP);
+      }
+      d->owned.push_back(cbn); d->owned.push_back(cbsq);
+      hipLaunchKernelGGL(dac_cbnorm_kernel, dim3((cfg->codebook_size + 255) / 256), dim3(256), 0, 0, e->second->data_dev, cbn, cbsq, cfg->codebook_size, cfg->codebook_dim);
+      ptrs[0 * nq + i] = wi->second->data_dev; ptrs[1 * nq + i] = bi2->second->data_dev; ptrs[2 * nq + i] = e->second->data_dev;
+      ptrs[3 * nq + i] = cbn; ptrs[4 * nq + i] = cbsq; ptrs[5 * nq + i] = wo->second->data_dev; ptrs[6 * nq + i] = bo->second->data_dev;
+    }
+    float* dp = nullptr;
+    if (hipMalloc(&dp, ptrs.size() * sizeof(float*)) != hipSuccess || hipMemcpy(dp, ptrs.data(), ptrs.size() * sizeof(float*), hipMemcpyHostToDevice) != hipSuccess) {
+      d->err = "hipMalloc/hipMemcpy failed"; return fail(ZN_ERR_HIP);
+    }
+    d->owned.push_back(dp);
+    d->rvq_ptrs = (const float**)dp;
+    d->has_encoder = true;
+  }
   if (hipDeviceSynchronize() != hipSuccess || hipGetLastError() != hipSuccess) { d->err = "weight re-layout kernels failed"; return fail(ZN_ERR_HIP); }
-  for (int nt : {3, 4}) {
+  for (int nt : {2, 3, 4}) {
     const int bytes = (DAC_MAXROWS * (DAC_KC + 1) + DAC_MAXTAPS * DAC_KC * nt * 32) * (int)sizeof(float);
-    hipError_t e = nt == 3 ? hipFuncSetAttribute((const void*)dac_conv_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes)
+    hipError_t e = nt == 2 ? hipFuncSetAttribute((const void*)dac_conv_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes)
+                 : nt == 3 ? hipFuncSetAttribute((const void*)dac_conv_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes)
                            : hipFuncSetAttribute((const void*)dac_conv_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
     if (e != hipSuccess) { d->err = std::string("hipFuncSetAttribute: ") + hipGetErrorString(e); return fail(ZN_ERR_HIP); }
   }
   (void)hipFuncSetAttribute((const void*)dac_final_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   *out = d;
+  return ZN_OK;
+}
+
+static int launch_conv_args(const ConvArgs& a, int coutpad, int B, hipStream_t s) {
+  const int nt = tile_nt(coutpad);
+  const int TN = nt * 32;
+  dim3 grid((a.M + DAC_TM - 1) / DAC_TM, coutpad / TN, B * a.phases);
+  const size_t lds = (size_t)(DAC_MAXROWS * (DAC_KC + 1) + DAC_MAXTAPS * DAC_KC * TN) * sizeof(float);
+  if (nt == 4) hipLaunchKernelGGL((dac_conv_kernel<4>), grid, dim3(256), lds, s, a);
+  else if (nt == 3) hipLaunchKernelGGL((dac_conv_kernel<3>), grid, dim3(256), lds, s, a);
+  else hipLaunchKernelGGL((dac_conv_kernel<2>), grid, dim3(256), lds, s, a);
   return ZN_OK;
 }
 
@@ -309,13 +519,7 @@ static int launch_conv(zn_dac d, const ConvLayer& L, const float* in, int Tin, c
     const int st = L.stride, padT = (st + 1) / 2;   // math.ceil(stride / 2), modeling_dac.py:250
     a.M = Tin + 1; a.taps = 2; a.off0 = 0; a.offstep = -1; a.ostride = st; a.ooff = -padT; a.phases = st;
   }
-  const int nt = (L.CoutPad % 128 == 0) ? 4 : 3;
-  const int TN = nt * 32;
-  dim3 grid((a.M + DAC_TM - 1) / DAC_TM, L.CoutPad / TN, B * a.phases);
-  const size_t lds = (size_t)(DAC_MAXROWS * (DAC_KC + 1) + DAC_MAXTAPS * DAC_KC * TN) * sizeof(float);
-  if (nt == 4) hipLaunchKernelGGL((dac_conv_kernel<4>), grid, dim3(256), lds, s, a);
-  else hipLaunchKernelGGL((dac_conv_kernel<3>), grid, dim3(256), lds, s, a);
-  return ZN_OK;
+  return launch_conv_args(a, L.CoutPad, B, s);
 }
 
 extern "C" int zn_dac_decode(zn_dac d, const int32_t* codes, int32_t B, int32_t T, float* wav, zn_stream stream) {
@@ -352,6 +556,59 @@ extern "C" int zn_dac_decode(zn_dac d, const int32_t* codes, int32_t B, int32_t 
   }
   const size_t lds = (size_t)((DAC_FIN_T + 6) * (d->fin_C + 1) + 7 * d->fin_C) * sizeof(float);
   hipLaunchKernelGGL(dac_final_kernel, dim3((t + DAC_FIN_T - 1) / DAC_FIN_T, B), dim3(DAC_FIN_T), lds, s, x, d->fin_alpha, d->fin_w, d->fin_b, wav, t, d->fin_C);
+  DHIP(d, hipGetLastError());
+  return ZN_OK;
+}
+
+// DACAutoencoder.encode (zonos/autoencoder.py:103-117): wav fp32 [B][T] (T a multiple of the hop: preprocess pads) ->
+// codes int32 [B][n_codebooks][T / hop].
+extern "C" int zn_dac_encode(zn_dac d, const float* wav, int32_t B, int32_t T, int32_t* codes, zn_stream stream) {
+  if (!d) return ZN_ERR_ARG;
+  if (!d->has_encoder) DFAIL(d, ZN_ERR_STATE, "zn_dac_encode: the handle was created without encoder / in_proj tensors");
+  const zn_dac_config& c = d->cfg;
+  int hop = 1;
+  for (int i = 0; i < c.n_ratios; ++i) hop *= c.ratios[i];
+  if (!wav || !codes || B < 1 || T < hop || T % hop) DFAIL(d, ZN_ERR_ARG, "zn_dac_encode: T must be a positive multiple of %d", hop);
+  hipStream_t s = (hipStream_t)stream;
+  // largest activation: [B][T][encoder_hidden] (later stages halve T*C or keep it)
+  size_t need = (size_t)B * T * c.encoder_hidden_size;
+  { size_t tt = T; int ch = c.encoder_hidden_size;
+    for (int i = 0; i < c.n_ratios; ++i) { tt /= d->eblocks[i].stride; ch *= 2; need = std::max(need, (size_t)B * tt * ch); }
+    need = std::max(need, (size_t)B * tt * c.hidden_size); }
+  if (need > d->buf_elems) {
+    DHIP(d, hipStreamSynchronize(s));
+    for (auto& p : d->buf) { if (p) (void)hipFree(p); p = nullptr; }
+    for (auto& p : d->buf) DHIP(d, hipMalloc(&p, need * sizeof(float)));
+    d->buf_elems = need;
+  }
+  float *x = d->buf[0], *y = d->buf[1], *z = d->buf[2];
+  int ch = c.encoder_hidden_size, t = T;
+  { const size_t n = (size_t)T * ch;
+    hipLaunchKernelGGL(dac_enc_conv1_kernel, dim3((unsigned)((n + 255) / 256), B), dim3(256), 0, s, wav, d->enc_w1, d->enc_b1, x, T, ch); }
+  for (int bi = 0; bi < c.n_ratios; ++bi) {
+    auto& E = d->eblocks[bi];
+    for (int u = 0; u < 3; ++u) {                                        // res units: x + conv2(snake2(conv1(snake1(x))))
+      launch_conv(d, E.c1[u], x, t, nullptr, y, t, B, false, s);
+      launch_conv(d, E.c2[u], y, t, x, z, t, B, false, s);
+      std::swap(x, z);
+    }
+    // snake1 -> Conv1d(k = 2s, stride s, pad ceil(s/2)) as a 3-tap GEMM over rows of s time steps
+    const int st = E.stride, to = t / st;
+    ConvArgs a{};
+    a.in = x; a.Tin = to; a.Cin = E.down.Cin; a.w = E.down.w; a.bias = E.down.bias; a.alpha = E.down.alpha; a.skip = nullptr;
+    a.out = y; a.Tout = to; a.Cout = E.down.Cout; a.CoutPad = E.down.CoutPad;
+    a.M = to; a.taps = 3; a.off0 = -1; a.offstep = 1; a.ostride = 1; a.ooff = 0; a.phases = 1;
+    launch_conv_args(a, E.down.CoutPad, B, s);
+    std::swap(x, y);
+    t = to; ch *= 2;
+  }
+  launch_conv(d, d->enc_conv2, x, t, nullptr, y, t, B, false, s);       // snake1 -> conv2 (k = 3)
+  RvqArgs r{};
+  const int nq = c.n_codebooks;
+  r.z = y; r.w_in = d->rvq_ptrs + 0 * nq; r.b_in = d->rvq_ptrs + 1 * nq; r.cb = d->rvq_ptrs + 2 * nq; r.cbn = d->rvq_ptrs + 3 * nq;
+  r.cbsq = d->rvq_ptrs + 4 * nq; r.w_out = d->rvq_ptrs + 5 * nq; r.b_out = d->rvq_ptrs + 6 * nq;
+  r.codes = codes; r.nq = nq; r.T = t; r.hidden = c.hidden_size; r.dim = c.codebook_dim; r.size = c.codebook_size;
+  hipLaunchKernelGGL(dac_rvq_kernel, dim3(t, B), dim3(256), c.hidden_size * sizeof(float), s, r);
   DHIP(d, hipGetLastError());
   return ZN_OK;
 }

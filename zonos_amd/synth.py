@@ -255,11 +255,37 @@ def dac_decoder_spec(hidden=1024, dec_hidden=1536, ratios=(8, 8, 4, 2), n_codebo
     return spec
 
 
-def dac_state_dict(seed: int = 4321, **kw) -> dict:
-    """Synthetic fp32 DAC decoder weights.  Conv weights use the PyTorch-default fan-in scale (so
-    activations stay O(1) through ~30 layers), Snake alpha in [0.5, 1.5], codebooks N(0,1)."""
+def dac_encoder_spec(hidden=1024, enc_hidden=64, ratios=(8, 8, 4, 2), n_codebooks=9, codebook_dim=8, **_):
+    """(name, shape, kind) for the tensors autoencoder.encode() touches beyond the decoder's: DacEncoder
+    (modeling_dac.py:444-473, blocks :212-233 with downsampling_ratios = reversed upsampling ratios) and the quantizers'
+    in_proj (:119)."""
+    spec = [("encoder.conv1.weight", (enc_hidden, 1, 7), "conv"), ("encoder.conv1.bias", (enc_hidden,), "bias")]
+    c = enc_hidden
+    for bi, s in enumerate(reversed(ratios)):
+        b = f"encoder.block.{bi}."
+        for u in (1, 2, 3):
+            r = b + f"res_unit{u}."
+            spec += [(r + "snake1.alpha", (1, c, 1), "alpha"),
+                     (r + "conv1.weight", (c, c, 7), "conv"), (r + "conv1.bias", (c,), "bias"),
+                     (r + "snake2.alpha", (1, c, 1), "alpha"),
+                     (r + "conv2.weight", (c, c, 1), "conv"), (r + "conv2.bias", (c,), "bias")]
+        spec += [(b + "snake1.alpha", (1, c, 1), "alpha"),
+                 (b + "conv1.weight", (2 * c, c, 2 * s), "conv"), (b + "conv1.bias", (2 * c,), "bias")]
+        c *= 2
+    spec += [("encoder.snake1.alpha", (1, c, 1), "alpha"),
+             ("encoder.conv2.weight", (hidden, c, 3), "conv"), ("encoder.conv2.bias", (hidden,), "bias")]
+    for i in range(n_codebooks):
+        q = f"quantizer.quantizers.{i}."
+        spec += [(q + "in_proj.weight", (codebook_dim, hidden, 1), "conv"), (q + "in_proj.bias", (codebook_dim,), "bias")]
+    return spec
+
+
+def dac_state_dict(seed: int = 4321, encoder: bool = True, **kw) -> dict:
+    """Synthetic fp32 DAC weights (decoder + quantizer, and the encoder unless encoder=False).  Conv weights use the
+    PyTorch-default fan-in scale (so activations stay O(1) through ~30 layers), Snake alpha in [0.5, 1.5], codebooks N(0,1)."""
     sd = {}
-    for name, shape, kind in dac_decoder_spec(**kw):
+    dkw = {k: v for k, v in kw.items() if k != "enc_hidden"}
+    for name, shape, kind in dac_decoder_spec(**dkw) + (dac_encoder_spec(**kw) if encoder else []):
         if kind == "emb":
             a = normal(seed, name, shape, 1.0)
         elif kind == "conv":
@@ -272,3 +298,16 @@ def dac_state_dict(seed: int = 4321, **kw) -> dict:
             a = 1.0 + uniform(seed, name, shape, 0.5)
         sd[name] = torch.from_numpy(a)
     return sd
+
+
+def test_waveform(seed: int, name: str, T: int, batch: int = 1) -> torch.Tensor:
+    """Deterministic fp32 test audio [batch, 1, T] in (-1, 1): three sines (220, 1370, 5100 Hz at 44.1 kHz) under a slow
+    envelope plus low-level noise from the counter RNG."""
+    t = np.arange(T, dtype=np.float64) / 44100.0
+    out = np.empty((batch, 1, T), dtype=np.float32)
+    for b in range(batch):
+        ph = uniform(seed, f"{name}.phase.{b}", (3,), np.pi).astype(np.float64)
+        sig = 0.30 * np.sin(2 * np.pi * 220.0 * t + ph[0]) + 0.15 * np.sin(2 * np.pi * 1370.0 * t + ph[1]) + 0.08 * np.sin(2 * np.pi * 5100.0 * t + ph[2])
+        env = 0.6 + 0.4 * np.sin(2 * np.pi * 3.0 * t + b)
+        out[b, 0] = (sig * env).astype(np.float32) + uniform(seed, f"{name}.noise.{b}", (T,), 0.02)
+    return torch.from_numpy(out)
