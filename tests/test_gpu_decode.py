@@ -12,6 +12,7 @@ import torch
 
 from oracle import zonos_oracle as zo
 from zonos_amd import _lib, synth
+from zonos_amd.backbone import HipEngine
 from zonos_amd.testing import build_model
 
 pytestmark = pytest.mark.gpu
@@ -512,3 +513,27 @@ def test_small_m_projections_match_the_gemv_path(full):
         print(f"\n[16 rows vs 8 x 2 rows, layer {layer}] new K/V bit-equal {keq:.5f}; output bit-equal {eq:.5f}, max|diff| {md:.4g}")
         assert keq > 0.995 and eq > 0.9
         assert md <= 2.0 ** -5 * max(1.0, yb.float().abs().max().item())
+
+
+@pytest.mark.parametrize("rows", [5, 8, 13, 16])
+def test_small_m_linear_shapes_vs_fp32_reference(tiny, rows):
+    """zn_op_linear at 5..16 activation rows (the LDS-staged MFMA kernel: 32/64-row workgroups, K split over workgroups
+    with the ticketed combine, clamped edge tiles; short slices fall back to the direct-fragment kernel) against an fp32
+    matmul rounded once to bf16, over the projection shapes of both backbones plus ragged N: bit-equal > 0.98 (fp32
+    summation order), never more than one bf16 ulp of the row scale apart."""
+    model, _, _ = tiny
+    eng = HipEngine(model.backbone, max_rows=16)
+    st = _lib.stream_ptr()
+    for N, K in ((2048, 2048), (3072, 2048), (8512, 2048), (9225, 2048), (16384, 2048), (2048, 4096), (2048, 8192), (1000, 512), (72, 256)):
+        x = torch.from_numpy(synth.normal(5, f"lin.x.{N}.{K}.{rows}", (rows, K))).to(torch.bfloat16)
+        W = torch.from_numpy(synth.uniform(5, f"lin.w.{N}.{K}", (N, K), 1.0 / np.sqrt(K))).to(torch.bfloat16)
+        ref = (x.float() @ W.float().T).to(torch.bfloat16)
+        xd, Wd = x.cuda(), W.cuda()
+        out = torch.empty(rows, N, dtype=torch.bfloat16, device="cuda:0")
+        eng.call("zn_op_linear", xd.data_ptr(), None, None, Wd.data_ptr(), out.data_ptr(), rows, N, K, st)
+        torch.cuda.synchronize()
+        got = out.cpu()
+        eq = float((got.view(torch.int16) == ref.view(torch.int16)).float().mean())
+        md = (got.float() - ref.float()).abs().max().item()
+        print(f"\n[linear rows={rows} N={N} K={K}] bit-equal {eq:.5f} max|d| {md:.3g}")
+        assert eq > 0.98 and md <= 2.0 ** -7 * max(1.0, ref.float().abs().max().item()), (N, K, eq, md)
