@@ -891,7 +891,7 @@ extern "C" int zn_op_silu(zn_handle h, const void* x, void* out, int64_t n, zn_s
 
 extern "C" int zn_op_layernorm(zn_handle h, const void* x, const void* w, const void* b, void* out, int32_t rows, int32_t d, zn_stream stream) {
   if (!h) return ZN_ERR_ARG;
-  if (!x || !w || !b || !out || rows < 1 || d < 8 || d % 8) ZN_FAIL(h, ZN_ERR_ARG, "zn_op_layernorm: bad argument");
+  if (!x || !w || !b || !out || rows < 1 || d < 8 || d % 8 || d > 4096) ZN_FAIL(h, ZN_ERR_ARG, "zn_op_layernorm: bad argument (d <= 4096, multiple of 8)");
   hipLaunchKernelGGL(layernorm_kernel, dim3(rows), dim3(64), 0, (hipStream_t)stream, (const bf16_t*)x, (const bf16_t*)w, (const bf16_t*)b,
                      (bf16_t*)out, d, h->cfg.norm_eps);
   HIPCHK(h, hipGetLastError());

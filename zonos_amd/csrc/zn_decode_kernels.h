@@ -876,29 +876,44 @@ __global__ void gather_pos_kernel(const bf16_t* hidden, bf16_t* x, int S, int s,
   for (int k = threadIdx.x * 8; k < d; k += blockDim.x * 8)
     *(u32x4*)(x + (size_t)r * d + k) = *(const u32x4*)(hidden + ((size_t)r * S + s) * d + k);
 }
-// standalone nn.LayerNorm: one wave per row
+// standalone nn.LayerNorm: one wave per row; the row (d <= 4096) and the affine parameters are requested once, up
+// front, and stay in registers through both statistics passes (one memory round trip instead of three)
 __global__ __launch_bounds__(64) void layernorm_kernel(const bf16_t* x, const bf16_t* w, const bf16_t* b, bf16_t* out, int d, float eps) {
   const int r = blockIdx.x, lane = threadIdx.x;
   const bf16_t* xr = x + (size_t)r * d;
+  constexpr int MV = 8;
+  u32x4 v[MV], g[MV], bb[MV];
+#pragma unroll
+  for (int j = 0; j < MV; ++j) {
+    const int k = min(lane * 8 + j * 512, d - 8);          // clamped, not masked: no exec branch between the requests
+    v[j] = ld16(xr + k); g[j] = ld16(w + k); bb[j] = ld16(b + k);
+  }
+  __builtin_amdgcn_sched_barrier(0);
   float s = 0.f;
-  for (int k = lane * 8; k < d; k += 512) { const u32x4 v = ld16(xr + k); s += lo_f(v.x) + hi_f(v.x) + lo_f(v.y) + hi_f(v.y) + lo_f(v.z) + hi_f(v.z) + lo_f(v.w) + hi_f(v.w); }
+#pragma unroll
+  for (int j = 0; j < MV; ++j)
+    if (lane * 8 + j * 512 < d) s += lo_f(v[j].x) + hi_f(v[j].x) + lo_f(v[j].y) + hi_f(v[j].y) + lo_f(v[j].z) + hi_f(v[j].z) + lo_f(v[j].w) + hi_f(v[j].w);
   const float mean = wave_sum(s) / (float)d;
   float ss = 0.f;
-  for (int k = lane * 8; k < d; k += 512) {
-    const u32x4 v = ld16(xr + k);
-    const float f[8] = {lo_f(v.x), hi_f(v.x), lo_f(v.y), hi_f(v.y), lo_f(v.z), hi_f(v.z), lo_f(v.w), hi_f(v.w)};
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { const float dd = f[e] - mean; ss += dd * dd; }
-  }
+  for (int j = 0; j < MV; ++j)
+    if (lane * 8 + j * 512 < d) {
+      const float f[8] = {lo_f(v[j].x), hi_f(v[j].x), lo_f(v[j].y), hi_f(v[j].y), lo_f(v[j].z), hi_f(v[j].z), lo_f(v[j].w), hi_f(v[j].w)};
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { const float dd = f[e] - mean; ss += dd * dd; }
+    }
   const float rstd = 1.0f / sqrtf(wave_sum(ss) / (float)d + eps);
-  for (int k = lane * 8; k < d; k += 512) {
-    const u32x4 v = ld16(xr + k), g = ld16(w + k), bb = ld16(b + k);
-    u32x4 o;
-    o.x = pack2((lo_f(v.x) - mean) * rstd * lo_f(g.x) + lo_f(bb.x), (hi_f(v.x) - mean) * rstd * hi_f(g.x) + hi_f(bb.x));
-    o.y = pack2((lo_f(v.y) - mean) * rstd * lo_f(g.y) + lo_f(bb.y), (hi_f(v.y) - mean) * rstd * hi_f(g.y) + hi_f(bb.y));
-    o.z = pack2((lo_f(v.z) - mean) * rstd * lo_f(g.z) + lo_f(bb.z), (hi_f(v.z) - mean) * rstd * hi_f(g.z) + hi_f(bb.z));
-    o.w = pack2((lo_f(v.w) - mean) * rstd * lo_f(g.w) + lo_f(bb.w), (hi_f(v.w) - mean) * rstd * hi_f(g.w) + hi_f(bb.w));
-    *(u32x4*)(out + (size_t)r * d + k) = o;
+#pragma unroll
+  for (int j = 0; j < MV; ++j) {
+    const int k = lane * 8 + j * 512;
+    if (k < d) {
+      u32x4 o;
+      o.x = pack2((lo_f(v[j].x) - mean) * rstd * lo_f(g[j].x) + lo_f(bb[j].x), (hi_f(v[j].x) - mean) * rstd * hi_f(g[j].x) + hi_f(bb[j].x));
+      o.y = pack2((lo_f(v[j].y) - mean) * rstd * lo_f(g[j].y) + lo_f(bb[j].y), (hi_f(v[j].y) - mean) * rstd * hi_f(g[j].y) + hi_f(bb[j].y));
+      o.z = pack2((lo_f(v[j].z) - mean) * rstd * lo_f(g[j].z) + lo_f(bb[j].z), (hi_f(v[j].z) - mean) * rstd * hi_f(g[j].z) + hi_f(bb[j].z));
+      o.w = pack2((lo_f(v[j].w) - mean) * rstd * lo_f(g[j].w) + lo_f(bb[j].w), (hi_f(v[j].w) - mean) * rstd * hi_f(g[j].w) + hi_f(bb[j].w));
+      *(u32x4*)(out + (size_t)r * d + k) = o;
+    }
   }
 }
 __global__ void add_lengths_kernel(int* lengths, int rows, int n) {
