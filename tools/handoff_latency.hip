@@ -1,4 +1,4 @@
-// Cross-workgroup hand-off latency on MI355X: how long does one "phase" of a persistent kernel take when every
+// Cross-workgroup hand-off latency on MI355X (hipcc --offload-arch=gfx950 -O3 tools/handoff_latency.hip; measurement only): how long does one "phase" of a persistent kernel take when every
 // workgroup publishes a few values and every workgroup needs all of them?
 //   mode 0: tagged 8-byte words (value | phase tag), consumers spin on the data itself
 //   mode 1: plain stores + release, one atomic counter, poll, acquire, plain loads
