@@ -35,6 +35,7 @@ enum zn_status {
 
 typedef struct zn_handle_s* zn_handle;
 typedef struct zn_dac_s* zn_dac;
+typedef struct zn_spk_s* zn_spk;
 typedef void* zn_stream;
 
 /* Model hyper-parameters: zonos/config.py:55-84 BackboneConfig + :105-126 ZonosConfig (read from config.json
@@ -216,6 +217,18 @@ int zn_dac_decode(zn_dac d, const int32_t* codes_dev, int32_t batch, int32_t T, 
  * positive multiple of the hop (preprocess pads) -> codes int32 [B, n_codebooks, T / hop].  Needs the encoder.* and
  * quantizer.quantizers.{i}.in_proj tensors at zn_dac_create. */
 int zn_dac_encode(zn_dac d, const float* wav_dev, int32_t batch, int32_t T, int32_t* codes_dev, zn_stream stream);
+
+/* ---------------------------------------------------------------- speaker embedding (zonos/speaker_cloning.py) */
+/* ResNet293_based (speaker_cloning.py:419-472: ResNet293 of SimAM blocks -> ASP -> bottleneck Linear) and the LDA Linear
+ * of SpeakerEmbeddingLDA (:800-883), fp32.  Tensors by the reference's state-dict names (front.*, pooling.*,
+ * bottleneck.*; optionally lda.weight / lda.bias), device pointers that must outlive the handle; BatchNorm is folded
+ * when the handle is built.  Runs once per speaker, outside the decode loop. */
+int zn_spk_create(const zn_dac_tensor* tensors, int32_t n_tensors, zn_spk* out);
+int zn_spk_destroy(zn_spk d);
+const char* zn_spk_last_error(zn_spk d);
+/* feat fp32 [B, n_mels, T]: mean-normalised log-mel features (what logFbankCal returns, speaker_cloning.py:81-87), T >= 8
+ * -> emb fp32 [B, emb_dim] (bottleneck output) and, if lda_out != NULL, lda_out fp32 [B, lda_dim]. */
+int zn_spk_embed(zn_spk d, const float* feat_dev, int32_t batch, int32_t T, float* emb_dev, float* lda_out_dev, zn_stream stream);
 
 #ifdef __cplusplus
 }

@@ -577,3 +577,45 @@ def dac_encode(dw: dict, wav: torch.Tensor, ratios=(8, 8, 4, 2), collect: dict |
         residual = residual - F.conv1d(quant, dw[q + "out_proj.weight"], dw[q + "out_proj.bias"])
         codes.append(idx)
     return torch.stack(codes, dim=1)
+
+
+# --------------------------------------------------------------------------- speaker embedding (zonos/speaker_cloning.py)
+def _spk_bn(x: torch.Tensor, sd: dict, p: str) -> torch.Tensor:
+    return F.batch_norm(x, sd[p + "running_mean"], sd[p + "running_var"], sd[p + "weight"], sd[p + "bias"], False, 0.0, 1e-5)
+
+
+def spk_simam(X: torch.Tensor, lambda_p: float = 1e-4) -> torch.Tensor:
+    """speaker_cloning.py:192-215."""
+    n = X.shape[2] * X.shape[3] - 1
+    d = (X - X.mean(dim=[2, 3], keepdim=True)).pow(2)
+    v = d.sum(dim=[2, 3], keepdim=True) / n
+    return X * torch.sigmoid(d / (4 * (v + lambda_p)) + 0.5)
+
+
+def speaker_embed(sd: dict, feats: torch.Tensor, lda: dict | None = None):
+    """ResNet293_based.forward after featCal (speaker_cloning.py:465-472): ResNet of SimAMBasicBlocks (:184-190, :385-392),
+    ASP (:128-136), bottleneck; optionally the LDA Linear (:879-881).  feats fp32 [B, n_mels, T] -> (emb [B, 256], lda_emb)."""
+    x = F.relu(_spk_bn(F.conv2d(feats.unsqueeze(1), sd["front.conv1.weight"], padding=1), sd, "front.bn1."))
+    for li in (1, 2, 3, 4):
+        bi = 0
+        while f"front.layer{li}.{bi}.conv1.weight" in sd:
+            p = f"front.layer{li}.{bi}."
+            stride = 2 if (bi == 0 and li > 1) else 1
+            out = F.relu(_spk_bn(F.conv2d(x, sd[p + "conv1.weight"], stride=stride, padding=1), sd, p + "bn1."))
+            out = spk_simam(_spk_bn(F.conv2d(out, sd[p + "conv2.weight"], padding=1), sd, p + "bn2."))
+            res = x
+            if p + "downsample.0.weight" in sd:
+                res = _spk_bn(F.conv2d(x, sd[p + "downsample.0.weight"], stride=stride), sd, p + "downsample.1.")
+            x = F.relu(out + res)
+            bi += 1
+    B = x.shape[0]
+    xf = x.reshape(B, -1, x.shape[-1])                                                   # [B, C*H, T']
+    a = F.relu(F.conv1d(xf, sd["pooling.attention.0.weight"], sd["pooling.attention.0.bias"]))
+    a = _spk_bn(a, sd, "pooling.attention.2.")
+    w = torch.softmax(F.conv1d(a, sd["pooling.attention.3.weight"], sd["pooling.attention.3.bias"]), dim=2)
+    mu = torch.sum(xf * w, dim=2)
+    sg = torch.sqrt((torch.sum((xf ** 2) * w, dim=2) - mu ** 2).clamp(min=1e-5))
+    emb = F.linear(torch.cat((mu, sg), 1), sd["bottleneck.weight"], sd["bottleneck.bias"])
+    if lda is None:
+        return emb, None
+    return emb, F.linear(emb, lda["weight"], lda["bias"])

@@ -7,7 +7,7 @@ builds `zonos.model.Zonos` around `TorchZonosBackbone` with the build's syntheti
 real `Zonos.generate()`, of `zonos.sampling`, `zonos.codebook_pattern`, `zonos.backbone._torch` and of
 `transformers.models.dac.DacModel.decode`.  Only data (inputs' seeds + expected outputs) is written.
 
-    python tests/golden/make_golden.py [--only tiny,full,ops,sampling,eos,dac,dacenc]
+    python tests/golden/make_golden.py [--only tiny,full,ops,sampling,eos,dac,dacenc,spk]
 """
 import argparse
 import importlib.machinery
@@ -304,6 +304,39 @@ def main():
             out[f"z_{T}"] = z.numpy().astype(np.float32)
         np.savez_compressed(f"{HERE}/dac_encode.npz", **out)
         print("dacenc done")
+
+    if "spk" in only:
+        # the reference's own ResNet293_based (zonos/speaker_cloning.py:419-472) + the LDA Linear, synthetic weights and
+        # features; the feature front end (torchaudio MelSpectrogram) cannot run here (torchaudio absent) and is not part
+        # of these vectors
+        import importlib.machinery
+        import types
+        for name, attrs in (("torchaudio", {}), ("torchaudio.functional", {}),
+                            ("torchaudio.transforms", dict(MelSpectrogram=lambda **k: None, Resample=lambda *a, **k: None))):
+            if name not in sys.modules:
+                m = types.ModuleType(name)
+                m.__spec__ = importlib.machinery.ModuleSpec(name, None)
+                for k, v in attrs.items():
+                    setattr(m, k, v)
+                sys.modules[name] = m
+        sys.modules["torchaudio"].transforms = sys.modules["torchaudio.transforms"]
+        from zonos.speaker_cloning import ResNet293_based
+        seed = 2468
+        sd, lda = synth.speaker_state_dict(seed)
+        net = ResNet293_based().eval()
+        net.load_state_dict(sd, strict=True)
+        out = dict(seed=seed)
+        for T in (64, 104):
+            feats = synth.speaker_features(seed, f"feats{T}", 1, 80, T)
+            with torch.no_grad():
+                h = net.front(feats.unsqueeze(1))
+                emb = net.bottleneck(net.pooling(h))
+                ld = torch.nn.functional.linear(emb, lda["weight"], lda["bias"])
+            out[f"emb_{T}"] = emb.numpy().astype(np.float32)
+            out[f"lda_{T}"] = ld.numpy().astype(np.float32)
+            out[f"front_rms_{T}"] = np.float32(h.pow(2).mean().sqrt())
+        np.savez_compressed(f"{HERE}/speaker.npz", **out)
+        print("spk done")
 
 
 if __name__ == "__main__":

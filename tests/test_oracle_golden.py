@@ -182,3 +182,17 @@ def test_dac_encode_matches_transformers(golden_dir):
         assert codes.shape == (1, 9, T // 512)
         assert np.array_equal(codes.numpy(), g[f"codes_{T}"].astype(np.int64))
         assert np.abs(col["z"].numpy() - g[f"z_{T}"]).max() <= 1e-6
+
+
+def test_speaker_embedding_matches_reference(golden_dir):
+    """oracle speaker_embed vs the reference's ResNet293_based + LDA Linear (zonos/speaker_cloning.py) on synthetic weights
+    and features (goldens recorded by importing the reference class): fp32, same torch ops -> equal to 1e-5 relative."""
+    g = _load(golden_dir, "speaker")
+    seed = int(g["seed"])
+    sd, lda = synth.speaker_state_dict(seed)
+    T = 64
+    feats = synth.speaker_features(seed, f"feats{T}", 1, 80, T)
+    emb, ld = zo.speaker_embed(sd, feats, lda)
+    for got, ref in ((emb.numpy(), g[f"emb_{T}"]), (ld.numpy(), g[f"lda_{T}"])):
+        rel = np.linalg.norm(got - ref) / np.linalg.norm(ref)
+        assert got.shape == ref.shape and rel < 1e-5, rel

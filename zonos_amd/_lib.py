@@ -89,6 +89,10 @@ SIGNATURES = {
     "zn_dac_last_error": (C.c_char_p, [C.c_void_p]),
     "zn_dac_decode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "zn_dac_encode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+    "zn_spk_create": (C.c_int, [C.POINTER(zn_dac_tensor), C.c_int32, C.POINTER(C.c_void_p)]),
+    "zn_spk_destroy": (C.c_int, [C.c_void_p]),
+    "zn_spk_last_error": (C.c_char_p, [C.c_void_p]),
+    "zn_spk_embed": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
 }
 
 _lib = None

@@ -12,7 +12,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libzonos_hip.so")
-SOURCES = ["zn_api.hip", "zn_dac.hip"]
+SOURCES = ["zn_api.hip", "zn_dac.hip", "zn_spk.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function",
          "-fhip-fp32-correctly-rounded-divide-sqrt"]
 

@@ -311,3 +311,58 @@ def test_waveform(seed: int, name: str, T: int, batch: int = 1) -> torch.Tensor:
         env = 0.6 + 0.4 * np.sin(2 * np.pi * 3.0 * t + b)
         out[b, 0] = (sig * env).astype(np.float32) + uniform(seed, f"{name}.noise.{b}", (T,), 0.02)
     return torch.from_numpy(out)
+
+
+# ------------------------------------------------------------------ speaker embedding (zonos/speaker_cloning.py)
+def speaker_state_dict(seed: int = 2468, in_planes: int = 64, num_blocks=(10, 20, 64, 3), n_mels: int = 80, att_dim: int = 128,
+                       emb_dim: int = 256, lda_dim: int = 128) -> tuple[dict, dict]:
+    """Synthetic fp32 weights of ResNet293_based under the reference's state-dict names (speaker_cloning.py:353-392 ResNet,
+    :168-183 SimAMBasicBlock, :115-127 ASP, :460-463) and of the LDA Linear (:860-864).  Conv weights use a He-like scale so
+    that activations stay O(1) through the 97 residual blocks; BatchNorm gets non-trivial affine parameters and running
+    statistics (so that folding bugs show up).  Returns (model state dict, lda state dict)."""
+    sd = {}
+
+    def bn(p, c):
+        sd[p + "weight"] = torch.from_numpy(1.0 + uniform(seed, p + "weight", (c,), 0.2))
+        sd[p + "bias"] = torch.from_numpy(uniform(seed, p + "bias", (c,), 0.1))
+        sd[p + "running_mean"] = torch.from_numpy(uniform(seed, p + "running_mean", (c,), 0.2))
+        sd[p + "running_var"] = torch.from_numpy(1.0 + uniform(seed, p + "running_var", (c,), 0.5))
+        sd[p + "num_batches_tracked"] = torch.tensor(0, dtype=torch.long)
+
+    def conv(name, shape, gain=1.0):
+        fan_in = int(np.prod(shape[1:]))
+        sd[name] = torch.from_numpy(uniform(seed, name, shape, gain * np.sqrt(3.0 / fan_in)))
+
+    conv("front.conv1.weight", (in_planes, 1, 3, 3), 1.4)
+    bn("front.bn1.", in_planes)
+    cin = in_planes
+    for li, nb in enumerate(num_blocks, start=1):
+        planes = in_planes << (li - 1)
+        for bi in range(nb):
+            p = f"front.layer{li}.{bi}."
+            stride = 2 if (bi == 0 and li > 1) else 1
+            conv(p + "conv1.weight", (planes, cin, 3, 3), 1.4)
+            bn(p + "bn1.", planes)
+            conv(p + "conv2.weight", (planes, planes, 3, 3), 0.5)
+            bn(p + "bn2.", planes)
+            if stride != 1 or cin != planes:
+                conv(p + "downsample.0.weight", (planes, cin, 1, 1), 1.0)
+                bn(p + "downsample.1.", planes)
+            cin = planes
+    F = cin * (n_mels // 8)
+    conv("pooling.attention.0.weight", (att_dim, F, 1))
+    sd["pooling.attention.0.bias"] = torch.from_numpy(uniform(seed, "pooling.attention.0.bias", (att_dim,), 0.1))
+    bn("pooling.attention.2.", att_dim)
+    conv("pooling.attention.3.weight", (F, att_dim, 1), 2.0)
+    sd["pooling.attention.3.bias"] = torch.from_numpy(uniform(seed, "pooling.attention.3.bias", (F,), 0.1))
+    conv("bottleneck.weight", (emb_dim, 2 * F))
+    sd["bottleneck.bias"] = torch.from_numpy(uniform(seed, "bottleneck.bias", (emb_dim,), 0.1))
+    lda = {"weight": torch.from_numpy(uniform(seed, "lda.weight", (lda_dim, emb_dim), 1.0 / np.sqrt(emb_dim))),
+           "bias": torch.from_numpy(uniform(seed, "lda.bias", (lda_dim,), 0.1))}
+    return sd, lda
+
+
+def speaker_features(seed: int, name: str, batch: int, n_mels: int, frames: int) -> torch.Tensor:
+    """Synthetic mean-normalised log-mel-like features [batch, n_mels, frames] (what logFbankCal returns)."""
+    x = torch.from_numpy(normal(seed, name, (batch, n_mels, frames), 1.0))
+    return x - x.mean(dim=2, keepdim=True)
