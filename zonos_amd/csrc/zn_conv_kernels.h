@@ -55,30 +55,59 @@ __global__ __launch_bounds__(256) void dac_conv_kernel(ConvArgs a) {
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[nt][e] = 0.f;
 
-  for (int c0 = 0; c0 < a.Cin; c0 += DAC_KC) {
-    __syncthreads();
-    // stage input rows [m0+offmin, m0+offmin+nrows) x KC channels, Snake on the way in (zero outside [0,Tin))
-    for (int i = tid; i < nrows * (DAC_KC / 4); i += 256) {
+  // Per-thread staging slots: the next chunk's global requests are issued before this chunk's MFMAs and written to LDS
+  // (Snake applied on the way) after them, so that the HBM/L2 latency of a chunk hides behind the previous chunk's math.
+  constexpr int IN_P = (DAC_MAXROWS * (DAC_KC / 4) + 255) / 256;             // input pieces (f32x4) per thread
+  constexpr int W_P = (DAC_MAXTAPS * DAC_KC * (TN / 4) + 255) / 256;         // weight pieces per thread
+  f32x4 rin[IN_P], ral[IN_P], rw[W_P];
+  const int n_in = nrows * (DAC_KC / 4), n_w = a.taps * DAC_KC * (TN / 4);
+  auto fetch = [&](int c0) {
+#pragma unroll
+    for (int j = 0; j < IN_P; ++j) {
+      const int i = tid + j * 256;
       const int row = i / (DAC_KC / 4), c4 = (i % (DAC_KC / 4)) * 4;
-      const int t = m0 + offmin + row;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (t >= 0 && t < a.Tin) {
-        v = *(const f32x4*)(inb + (size_t)t * a.Cin + c0 + c4);
-        if (a.alpha) {
-          const f32x4 al = *(const f32x4*)(a.alpha + c0 + c4);
-          v.x = snake_f(v.x, al.x); v.y = snake_f(v.y, al.y); v.z = snake_f(v.z, al.z); v.w = snake_f(v.w, al.w);
-        }
+      int t = m0 + offmin + row;
+      t = t < 0 ? 0 : (t >= a.Tin ? a.Tin - 1 : t);                          // clamped; validity is re-derived when storing
+      if (i < n_in) {
+        rin[j] = *(const f32x4*)(inb + (size_t)t * a.Cin + c0 + c4);
+        if (a.alpha) ral[j] = *(const f32x4*)(a.alpha + c0 + c4);
       }
-      float* d = s_in + row * (DAC_KC + 1) + c4;
-      d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
     }
-    // stage weights: taps x KC rows of TN output channels
-    for (int i = tid; i < a.taps * DAC_KC * (TN / 4); i += 256) {
+#pragma unroll
+    for (int j = 0; j < W_P; ++j) {
+      const int i = tid + j * 256;
       const int rowi = i / (TN / 4), c4 = (i % (TN / 4)) * 4;
       const int tap = rowi / DAC_KC, ci = rowi % DAC_KC;
-      *(f32x4*)(s_w + (size_t)rowi * TN + c4) = *(const f32x4*)(wp + ((size_t)tap * a.Cin + c0 + ci) * a.CoutPad + n0 + c4);
+      if (i < n_w) rw[j] = *(const f32x4*)(wp + ((size_t)tap * a.Cin + c0 + ci) * a.CoutPad + n0 + c4);
+    }
+  };
+  fetch(0);
+  for (int c0 = 0; c0 < a.Cin; c0 += DAC_KC) {
+    __syncthreads();                                     // the previous chunk's fragment reads are done
+    // input rows [m0+offmin, m0+offmin+nrows) x KC channels, Snake on the way in (zero outside [0,Tin))
+#pragma unroll
+    for (int j = 0; j < IN_P; ++j) {
+      const int i = tid + j * 256;
+      if (i < n_in) {
+        const int row = i / (DAC_KC / 4), c4 = (i % (DAC_KC / 4)) * 4;
+        const int t = m0 + offmin + row;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (t >= 0 && t < a.Tin) {
+          v = rin[j];
+          if (a.alpha) { v.x = snake_f(v.x, ral[j].x); v.y = snake_f(v.y, ral[j].y); v.z = snake_f(v.z, ral[j].z); v.w = snake_f(v.w, ral[j].w); }
+        }
+        float* d = s_in + row * (DAC_KC + 1) + c4;
+        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+      }
+    }
+    // weights: taps x KC rows of TN output channels
+#pragma unroll
+    for (int j = 0; j < W_P; ++j) {
+      const int i = tid + j * 256;
+      if (i < n_w) { const int rowi = i / (TN / 4), c4 = (i % (TN / 4)) * 4; *(f32x4*)(s_w + (size_t)rowi * TN + c4) = rw[j]; }
     }
     __syncthreads();
+    if (c0 + DAC_KC < a.Cin) fetch(c0 + DAC_KC);
     const int ai = lane & 31, ak = lane >> 5;
     for (int tap = 0; tap < a.taps; ++tap) {
       const float* arow = s_in + (wave * 32 + ai + a.off0 + tap * a.offstep - offmin) * (DAC_KC + 1) + ak;
