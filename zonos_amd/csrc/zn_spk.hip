@@ -9,11 +9,12 @@
 // (a "batch" of rows, batch strides = row pitch): the centre row pass writes bias + conv, the other two accumulate
 // through the skip path.  Stride 2 reads every other row (in_bs = 2 rows) and, along the width, rows of 2 steps
 // ([Wp/2][2*Cin], a 2-tap GEMM whose re-laid-out weight is zero where the 3-tap window does not reach).  BatchNorm (eval)
-// is folded into each conv's weight and bias when the handle is built.  SimAM + residual + ReLU is one kernel per block
-// (per-channel mean and energy over the map, three sweeps by the same workgroup).
+// is folded into each conv's weight and bias when the handle is built.  SimAM + residual + ReLU is two launches per block
+// (per-channel sums in double over position slices, then the element-wise pass).
 #include "../../include/zonos_hip.h"
 #include "zn_conv_kernels.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <map>
@@ -97,33 +98,35 @@ __global__ __launch_bounds__(256) void spk_conv1_kernel(const float* feat, const
   out[((size_t)(y + 1) * Wp + x) * C + co] = fmaxf((acc - bn.m[co]) * sc + bn.b[co], 0.f);
 }
 // SimAM (speaker_cloning.py:192-215) + residual + ReLU: per channel mu = mean(X), d = (X - mu)^2, v = sum(d) / (H*W - 1),
-// out = relu(X * sigmoid(d / (4 (v + 1e-4)) + 0.5) + res).  One workgroup per 32 channels: 8 position lanes x 32 channels.
-__global__ __launch_bounds__(256) void spk_simam_kernel(const float* x, const float* res, float* out, int H, int W, int Wp, int C) {
+// out = relu(X * sigmoid(d / (4 (v + 1e-4)) + 0.5) + res).  Two launches over the whole map: per-channel sums of x and
+// x^2 in double (slices of positions per workgroup, fp64 atomics: sum(d) = sum x^2 - n mu^2 is exact to fp32 accuracy in
+// double), then the element-wise pass.
+__global__ __launch_bounds__(256) void spk_simam_stats_kernel(const float* x, double* stats /*[C][2], zeroed*/, int H, int W, int Wp, int C, int per) {
   const int c = blockIdx.x * 32 + (threadIdx.x & 31), pl = threadIdx.x >> 5;
-  __shared__ float red[8][32];
-  const int npos = H * W;
-  float s = 0.f;
-  for (int p = pl; p < npos; p += 8) s += x[((size_t)(p / W + 1) * Wp + p % W) * C + c];
-  red[pl][threadIdx.x & 31] = s;
+  __shared__ double red[2][8][32];
+  const int npos = H * W, p0 = blockIdx.y * per, p1 = min(npos, p0 + per);
+  double s = 0.0, q = 0.0;
+  for (int p = p0 + pl; p < p1; p += 8) { const double v = (double)x[((size_t)(p / W + 1) * Wp + p % W) * C + c]; s += v; q += v * v; }
+  red[0][pl][threadIdx.x & 31] = s; red[1][pl][threadIdx.x & 31] = q;
   __syncthreads();
-  float tot = 0.f;
+  if (pl < 2) {
+    double t = 0.0;
 #pragma unroll
-  for (int j = 0; j < 8; ++j) tot += red[j][threadIdx.x & 31];
-  const float mu = tot / (float)npos;
-  __syncthreads();
-  float ss = 0.f;
-  for (int p = pl; p < npos; p += 8) { const float dd = x[((size_t)(p / W + 1) * Wp + p % W) * C + c] - mu; ss += dd * dd; }
-  red[pl][threadIdx.x & 31] = ss;
-  __syncthreads();
-  tot = 0.f;
-#pragma unroll
-  for (int j = 0; j < 8; ++j) tot += red[j][threadIdx.x & 31];
-  const float v = tot / (float)(npos - 1);
-  const float den = 4.0f * (v + 1e-4f);
-  for (int p = pl; p < npos; p += 8) {
-    const size_t o = ((size_t)(p / W + 1) * Wp + p % W) * C + c;
+    for (int j = 0; j < 8; ++j) t += red[pl][j][threadIdx.x & 31];
+    atomicAdd(stats + (size_t)c * 2 + pl, t);
+  }
+}
+__global__ __launch_bounds__(256) void spk_simam_apply_kernel(const float* x, const float* res, const double* stats, float* out, int H, int W, int Wp, int C) {
+  const size_t n = (size_t)H * W * C;
+  const double npos = (double)H * W;
+  for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const int c = i % C, w = (i / C) % W, h = i / ((size_t)C * W);
+    const double sx = stats[(size_t)c * 2], sq = stats[(size_t)c * 2 + 1];
+    const float mu = (float)(sx / npos);
+    const float v = (float)((sq - sx * sx / npos) / (npos - 1.0));
+    const size_t o = ((size_t)(h + 1) * Wp + w) * C + c;
     const float xv = x[o], dd = (xv - mu) * (xv - mu);
-    const float e = dd / den + 0.5f;
+    const float e = dd / (4.0f * (v + 1e-4f)) + 0.5f;
     out[o] = fmaxf(xv * (1.0f / (1.0f + expf(-e))) + res[o], 0.f);
   }
 }
@@ -175,6 +178,7 @@ struct zn_spk_s {
   float* buf[4] = {nullptr, nullptr, nullptr, nullptr};
   size_t buf_elems = 0;
   float *xt = nullptr, *att = nullptr, *logit = nullptr, *pooled = nullptr;
+  double* simam_stats = nullptr;   // [max channels][2]
   size_t asp_T = 0;
   std::vector<float*> owned;
   std::string err;
@@ -191,6 +195,7 @@ extern "C" int zn_spk_destroy(zn_spk dd) {
   for (float* p : d->owned) (void)hipFree(p);
   for (float* p : d->buf) if (p) (void)hipFree(p);
   for (float* p : {d->xt, d->att, d->logit, d->pooled}) if (p) (void)hipFree(p);
+  if (d->simam_stats) (void)hipFree(d->simam_stats);
   delete d;
   return ZN_OK;
 }
@@ -299,7 +304,9 @@ extern "C" int zn_spk_create(const zn_dac_tensor* tensors, int32_t n, zn_spk* ou
     if (!lw) return fail(ZN_ERR_ARG);
     d->lda_w = lw->data_dev; d->lda_b = t["lda.bias"]->data_dev;
   }
-  if (hipMalloc(&d->pooled, (size_t)(2 * F + d->emb_dim) * sizeof(float)) != hipSuccess) { d->err = "hipMalloc failed"; return fail(ZN_ERR_HIP); }
+  if (hipMalloc(&d->pooled, (size_t)(2 * F + d->emb_dim) * sizeof(float)) != hipSuccess || hipMalloc(&d->simam_stats, (size_t)C * 2 * sizeof(double)) != hipSuccess) {
+    d->err = "hipMalloc failed"; return fail(ZN_ERR_HIP);
+  }
   if (hipDeviceSynchronize() != hipSuccess || hipGetLastError() != hipSuccess) { d->err = "weight preparation kernels failed"; return fail(ZN_ERR_HIP); }
   { hipError_t e = zn_conv_set_attrs(); if (e != hipSuccess) { d->err = std::string("hipFuncSetAttribute: ") + hipGetErrorString(e); return fail(ZN_ERR_HIP); } }
   *out = d;
@@ -384,7 +391,11 @@ extern "C" int zn_spk_embed(zn_spk dd, const float* feat, int32_t B, int32_t T, 
         res = r;
       }
       // SimAM(out) + residual, ReLU -> new x (written over t1, which is free now)
-      hipLaunchKernelGGL(spk_simam_kernel, dim3(Co / 32), dim3(256), 0, s, t2, res, t1, Ho, Wo, Wpo, Co);
+      SHIP(d, hipMemsetAsync(d->simam_stats, 0, (size_t)Co * 2 * sizeof(double), s));
+      { const int npos = Ho * Wo, per = 2048, ns = (npos + per - 1) / per;
+        hipLaunchKernelGGL(spk_simam_stats_kernel, dim3(Co / 32, ns), dim3(256), 0, s, t2, d->simam_stats, Ho, Wo, Wpo, Co, per);
+        const size_t n = (size_t)npos * Co;
+        hipLaunchKernelGGL(spk_simam_apply_kernel, dim3((unsigned)std::min<size_t>((n + 255) / 256, 4096)), dim3(256), 0, s, t2, res, d->simam_stats, t1, Ho, Wo, Wpo, Co); }
       if (st == 2) SHIP(d, hipMemsetAsync(x, 0, (size_t)(Ho + 2) * Wpo * Co * sizeof(float), s));   // x becomes scratch with the new layout
       std::swap(x, t1);
       H = Ho; W = Wo; Wp = Wpo; C = Co;
