@@ -214,6 +214,33 @@ def test_attention_decode_vs_cpu_sdpa(full, fused_limit):
     eng.call("zn_debug_tune", 5, 448)
 
 
+def test_attention_long_context_split_pass_vs_cpu_sdpa(full):
+    """KV capacities above 2048 run the P.V pass as one workgroup per 512-key block with a ticketed in-order combine
+    (acc = acc * f_j + pv_j, the reference's recurrence): same bar as the other launch shapes, contexts up to 4600 keys."""
+    import torch.nn.functional as F
+    model, _ = full
+    eng = model.engine(1)
+    st = _lib.stream_ptr()
+    gen = torch.Generator().manual_seed(1)
+    cap = 4608
+    kv = torch.randn(2, cap, 2, 4, 128, generator=gen).to(torch.bfloat16)
+    kvd = kv.to("cuda:0")
+    for L in (1, 512, 513, 2049, 3000, 4600):
+        q = torch.randn(2, 16, 1, 128, generator=gen).to(torch.bfloat16)
+        ref = F.scaled_dot_product_attention(q, kv[:, :L, 0].transpose(1, 2), kv[:, :L, 1].transpose(1, 2), enable_gqa=True)
+        qd = q.transpose(1, 2).reshape(2, 2048).contiguous().to("cuda:0")
+        lengths = torch.full((2,), L - 1, dtype=torch.int32, device="cuda:0")
+        out = torch.empty(2, 2048, dtype=torch.bfloat16, device="cuda:0")
+        for rep in range(2):        # twice: the arrival tickets must be back at zero after a launch
+            eng.call("zn_op_attn_decode", qd.data_ptr(), kvd.data_ptr(), cap, lengths.data_ptr(), None, out.data_ptr(), 2, st)
+        torch.cuda.synchronize()
+        got = out.cpu().view(2, 16, 128)
+        r = ref[:, :, 0]
+        eq = float((got.view(torch.int16) == r.contiguous().view(torch.int16)).float().mean())
+        print(f"\n[attn split L={L}] bit-equal {eq:.5f} max|d| {(got.float() - r.float()).abs().max().item():.3g}")
+        assert eq > 0.99, (L, eq)
+
+
 def test_layer0_decode_vs_reference_block(golden_dir, full):
     """One decode step of block 0 at Zonos-v0.1-transformer dims over a synthetic KV history (L = 1, 17, 900):
     reference TransformerBlock output (golden) vs zn_op_layer_decode."""

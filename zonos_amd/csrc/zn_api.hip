@@ -38,6 +38,8 @@ struct zn_handle_s {
   float *logits_raw = nullptr, *last_logits = nullptr;
   int* tok_raw = nullptr;
   float *scores = nullptr, *cmax = nullptr;
+  float* pv_part = nullptr;    // split P.V pass: partials per (row, kv head, slice, block)
+  int* pv_tickets = nullptr;
   bf16_t *pf_x = nullptr, *pf_n = nullptr, *pf_qkv = nullptr, *pf_a = nullptr, *pf_u = nullptr, *pf_m = nullptr;   // batched-prefill workspace
   size_t pf_rows = 0;
   int prefill_mode = 1;     // 1 = batched (MFMA GEMMs + tiled attention), 0 = position by position through the decode kernels
@@ -54,7 +56,7 @@ struct zn_handle_s {
   int *lengths = nullptr, *codes = nullptr;
   int force_eos_step = -1;
   float eos_bias = 0.f;
-  int tune[8] = {512, 512, 512, 1024, 256, 448, 2, 2};   // target workgroups: in_proj, out_proj, fc1, fc2, heads; [5] longest context of the fused attention launch; [6] > 1: multi-step graphs; [7] > 1: LDS-staged small-M projections
+  int tune[12] = {512, 512, 512, 1024, 256, 448, 2, 2, 0, 0, 0, 0};   // target workgroups: in_proj, out_proj, fc1, fc2, heads; [5] longest context of the fused attention launch; [6] > 1: multi-step graphs; [7] > 1: LDS-staged small-M projections; [9]: KV capacity above which the P.V pass splits per block (0 = 2048)
   const int* tok_override = nullptr;
   int tok_override_calls = 0;
   hipStream_t cap_stream = nullptr;
@@ -110,7 +112,7 @@ static void free_graph(zn_handle h) {
 extern "C" int zn_destroy(zn_handle h) {
   if (!h) return ZN_OK;
   free_graph(h);
-  void* ptrs[] = {h->emb_tables_dev, h->x, h->q, h->o1, h->mbuf, h->nbuf, h->logits_raw, h->last_logits, h->tok_raw, h->scores, h->cmax, h->pf_x, h->pf_n, h->pf_qkv, h->pf_a, h->pf_u, h->pf_m, h->st, h->remaining, h->stopping, h->res, h->hn, h->m_zx, h->m_xbc, h->m_y, h->m_g, h->g16_part, h->g16_tickets};
+  void* ptrs[] = {h->emb_tables_dev, h->x, h->q, h->o1, h->mbuf, h->nbuf, h->logits_raw, h->last_logits, h->tok_raw, h->scores, h->cmax, h->pv_part, h->pv_tickets, h->pf_x, h->pf_n, h->pf_qkv, h->pf_a, h->pf_u, h->pf_m, h->st, h->remaining, h->stopping, h->res, h->hn, h->m_zx, h->m_xbc, h->m_y, h->m_g, h->g16_part, h->g16_tickets};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (h->done_host) (void)hipHostFree(h->done_host);
   if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
@@ -328,9 +330,10 @@ template <int HD>
 static int launch_attn_g(const AttnArgs& a, int G, dim3 grid, bool fused, hipStream_t s) {
   switch (G) {
 #define ZN_ATTN_CASE(GG) case GG: \
-    if (fused) { hipLaunchKernelGGL((attn_pv_kernel<HD, GG, true>), dim3((HD / 32) * grid.y * grid.z), dim3(512), 0, s, a); return 0; } \
+    if (fused) { hipLaunchKernelGGL((attn_pv_kernel<HD, GG, 1>), dim3((HD / 32) * grid.y * grid.z), dim3(512), 0, s, a); return 0; } \
     hipLaunchKernelGGL((attn_scores_kernel<HD, GG>), grid, dim3(256), 0, s, a); \
-    hipLaunchKernelGGL((attn_pv_kernel<HD, GG, false>), dim3(HD / 32, grid.y, grid.z), dim3(512), 0, s, a); return 0;
+    if (a.nbcap > 0) { hipLaunchKernelGGL((attn_pv_kernel<HD, GG, 2>), dim3(HD / 32, grid.y, grid.z * a.nbcap), dim3(512), 0, s, a); return 0; } \
+    hipLaunchKernelGGL((attn_pv_kernel<HD, GG, 0>), dim3(HD / 32, grid.y, grid.z), dim3(512), 0, s, a); return 0;
     ZN_ATTN_CASE(1) ZN_ATTN_CASE(2) ZN_ATTN_CASE(4) ZN_ATTN_CASE(8)
 #undef ZN_ATTN_CASE
   }
@@ -341,11 +344,16 @@ static int ensure_attn_ws(zn_handle h, int max_len) {
   const int lcap = ((max_len + 511) / 512) * 512;
   if (lcap <= h->lcap) return ZN_OK;
   free_graph(h);
-  for (float** p : {&h->scores, &h->cmax}) if (*p) { (void)hipFree(*p); *p = nullptr; }
+  for (float** p : {&h->scores, &h->cmax, &h->pv_part}) if (*p) { (void)hipFree(*p); *p = nullptr; }
+  if (h->pv_tickets) { (void)hipFree(h->pv_tickets); h->pv_tickets = nullptr; }
   const size_t RH = (size_t)h->max_rows * h->cfg.n_heads;
   const int nc = lcap / ZN_ACHUNK;
   HIPCHK(h, hipMalloc(&h->scores, RH * lcap * sizeof(float)));
   HIPCHK(h, hipMalloc(&h->cmax, RH * nc * sizeof(float)));
+  { const size_t groups = (size_t)h->max_rows * h->cfg.n_heads_kv * (h->hd / 32);
+    HIPCHK(h, hipMalloc(&h->pv_part, groups * (lcap / 512) * (size_t)(h->G * 32 + h->G) * sizeof(float)));
+    HIPCHK(h, hipMalloc(&h->pv_tickets, groups * sizeof(int)));
+    HIPCHK(h, hipMemset(h->pv_tickets, 0, groups * sizeof(int))); }
   h->lcap = lcap;
   return ZN_OK;
 }
@@ -362,6 +370,9 @@ static int run_attention(zn_handle h, const bf16_t* q, const bf16_t* kv, int max
   dim3 grid((max_len + ZN_ACHUNK - 1) / ZN_ACHUNK, c.n_heads_kv, rows);
   // one fused launch for short contexts (the caller bounds the context: h->attn_fused), two passes beyond
   const bool fused = h->attn_fused;
+  // long KV capacities: the P.V pass runs one workgroup per 512-key block (tune[9] = capacity from which it does; 0 = 2048)
+  const int split_from = h->tune[9] > 0 ? h->tune[9] : 2048;
+  a.part = h->pv_part; a.tickets = h->pv_tickets; a.nbcap = (!fused && max_len > split_from && h->lcap / 512 <= 32) ? h->lcap / 512 : 0;
   int r2 = hd == 128 ? launch_attn_g<128>(a, h->G, grid, fused, s) : hd == 64 ? launch_attn_g<64>(a, h->G, grid, fused, s)
                                                                              : launch_attn_g<32>(a, h->G, grid, fused, s);
   if (r2) ZN_FAIL(h, ZN_ERR_UNSUPPORTED, "attention: unsupported group %d", h->G);
@@ -768,7 +779,7 @@ extern "C" int zn_debug_token_override(zn_handle h, const int32_t* tokens_dev, i
   return ZN_OK;
 }
 extern "C" int zn_debug_tune(zn_handle h, int32_t key, int32_t value) {
-  if (!h || key < 0 || key >= 8 || value < 1) return ZN_ERR_ARG;
+  if (!h || key < 0 || key >= 12 || value < 1) return ZN_ERR_ARG;
   h->tune[key] = value; free_graph(h);
   return ZN_OK;
 }

@@ -512,6 +512,9 @@ struct AttnArgs {
   int ext_scalar;       // used when ext == NULL and > 0
   int max_len, n_heads, n_heads_kv, lcap;   // lcap = scores row stride (multiple of 512)
   int rows;             // activation rows (fused variant's 1-D grid decode)
+  float* part;          // split variant: per (row, kv head, slice, block) partial [G*32 + G] (P.V sums, e sums)
+  int* tickets;         // split variant: arrival counter per (row, kv head, slice)
+  int nbcap;            // split variant: blocks the grid covers (lcap / 512)
   float scale;
   float* scores;        // [rows][Hq][lcap]
   float* cmax;          // [rows][Hq][lcap/64]   per-64-key-chunk maxima
@@ -582,8 +585,13 @@ __global__ __launch_bounds__(256) void attn_scores_kernel(AttnArgs a) {
 // workgroups of one (row, kv head) repeat it, and the 1-D grid puts them on one XCD so that K comes from that XCD's
 // L2 after the first touch) and then runs pass 2 from LDS: one launch instead of two on the latency-bound chain.
 #define ZN_AFUSED_MAX 2048
-template <int HD, int G, bool FUSED>
+// MODE 2 (long contexts): one workgroup per (slice, kv head, row, 512-key BLOCK) instead of one per (slice, kv head, row)
+// walking every block: the block's running max comes from the chunk maxima of all earlier chunks, its unnormalised P.V
+// and e sums leave as write-through partials, and the last workgroup of a (row, kv head, slice) to arrive (ticket, no
+// waiting) replays the reference's recurrence acc = acc * f_j + pv_j over the blocks in order and normalises.
+template <int HD, int G, int MODE>
 __global__ __launch_bounds__(512) void attn_pv_kernel(AttnArgs a) {
+  constexpr bool FUSED = MODE == 1, SPLIT = MODE == 2;
   constexpr int NW = 8;                                   // waves per workgroup; 16 keys per wave-load -> 128 keys per round
   constexpr int NR = 512 / (NW * 16);                     // rounds per 512-key block
   constexpr int GL = (G + 3) / 4;                         // heads a lane evaluates: g = vsub + 4*q
@@ -594,7 +602,9 @@ __global__ __launch_bounds__(512) void attn_pv_kernel(AttnArgs a) {
     const int npairs = a.n_heads_kv * a.rows;
     const int pair = blockIdx.x % npairs;
     slice = blockIdx.x / npairs; kvh = pair % a.n_heads_kv; r = pair / a.n_heads_kv;
-  } else { slice = blockIdx.x; kvh = blockIdx.y; r = blockIdx.z; }
+  } else if constexpr (SPLIT) { slice = blockIdx.x; kvh = blockIdx.y; r = blockIdx.z / a.nbcap; }
+  else { slice = blockIdx.x; kvh = blockIdx.y; r = blockIdx.z; }
+  const int jb = SPLIT ? (int)(blockIdx.z % a.nbcap) : 0;       // SPLIT: the block this workgroup owns
   // length (and span) first; the first block's requests below do not wait for them (clamped addresses, masked use)
   const int Lraw = a.lengths[r];
   const int Eraw = a.ext ? a.ext[r] : a.ext_scalar;
@@ -616,16 +626,16 @@ __global__ __launch_bounds__(512) void attn_pv_kernel(AttnArgs a) {
   float scn[FUSED ? 1 : NR][GL], cmn[GL];
 #pragma unroll
   for (int i = 0; i < NR; ++i) {
-    const int idx = i * (NW * 16) + wave * 16 + vkey;
+    const int idx = jb * 512 + i * (NW * 16) + wave * 16 + vkey;
     vnext[i] = ld16(vbase + (size_t)min(idx, a.max_len - 1) * kvrow);
     if constexpr (!FUSED) {
 #pragma unroll
-      for (int q = 0; q < GL; ++q) scn[i][q] = srow[q][idx];          // idx < 512 <= lcap
+      for (int q = 0; q < GL; ++q) scn[i][q] = srow[q][idx];          // idx < 512 * (jb + 1) <= lcap
     }
   }
   if constexpr (!FUSED) {
 #pragma unroll
-    for (int q = 0; q < GL; ++q) cmn[q] = crow[q][lane >> 3];         // chunk < 8 <= lcap / 64
+    for (int q = 0; q < GL; ++q) cmn[q] = crow[q][8 * jb + (lane >> 3)];   // chunk < 8 * (jb + 1) <= lcap / 64
   }
   float acc[G][8], lsum[GL], m_run[GL];
 #pragma unroll
@@ -708,7 +718,27 @@ __global__ __launch_bounds__(512) void attn_pv_kernel(AttnArgs a) {
   int E = Eraw > 0 ? Eraw : L;
   if (E < L) E = L;
   const int nchunks = (L + ZN_ACHUNK - 1) / ZN_ACHUNK;
-  for (int j = 0; j < nb; ++j) {
+  if constexpr (SPLIT) {
+    if (jb >= nb) return;                                 // the grid covers the capacity; blocks past the context do nothing
+    // running max before this block = max over every earlier chunk maximum (lanes with equal lane & 3 hold one head)
+#pragma unroll
+    for (int q = 0; q < GL; ++q) {
+      float pm = -INFINITY;
+      for (int j0 = 0; j0 < jb; j0 += 8) {                 // eight requests in flight (chunks < 8 * jb all exist: jb < nb)
+        float t8[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t8[u] = crow[q][8 * min(j0 + u, jb - 1) + (lane >> 3)];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) pm = fmaxf(pm, t8[u]);
+      }
+      pm = fmaxf(pm, dpp_mov<ZN_DPP_ROR4>(pm));
+      pm = fmaxf(pm, dpp_mov<ZN_DPP_ROR8>(pm));
+      pm = fmaxf(pm, __shfl_xor(pm, 16));
+      pm = fmaxf(pm, __shfl_xor(pm, 32));
+      m_run[q] = pm;
+    }
+  }
+  for (int j = SPLIT ? jb : 0; j < (SPLIT ? jb + 1 : nb); ++j) {
     const int t0 = j * 512;
     const int nkeys = min(512, L - t0);
     // this block's chunk maxima, 4 value pieces and 4*GL scores per lane were requested one block ahead
@@ -731,7 +761,7 @@ __global__ __launch_bounds__(512) void attn_pv_kernel(AttnArgs a) {
         else sc[i][q] = ok ? scn[i][q] : 0.f;
       }
     }
-    if (j + 1 < nb) {                                     // next block's requests fly during this block's arithmetic
+    if (!SPLIT && j + 1 < nb) {                           // next block's requests fly during this block's arithmetic
 #pragma unroll
       for (int i = 0; i < NR; ++i) {
         const int nidx = t0 + 512 + i * (NW * 16) + wave * 16 + vkey;
@@ -757,7 +787,7 @@ __global__ __launch_bounds__(512) void attn_pv_kernel(AttnArgs a) {
       bm = fmaxf(bm, __shfl_xor(bm, 16));
       bm = fmaxf(bm, __shfl_xor(bm, 32));
       mnew[q] = fmaxf(m_run[q], bm);
-      f[q] = (j == 0) ? 0.f : expf(m_run[q] - mnew[q]);
+      f[q] = (SPLIT || j == 0) ? 0.f : expf(m_run[q] - mnew[q]);
       m_run[q] = mnew[q];
       lsum[q] = __fmul_rn(lsum[q], f[q]);
     }
@@ -830,14 +860,73 @@ __global__ __launch_bounds__(512) void attn_pv_kernel(AttnArgs a) {
     }
   }
   __syncthreads();
+  float v = 0.f, l = 0.f;
+  const int g = tid >> 5, d = tid & 31;
   if (tid < G * 32) {
-    const int g = tid >> 5, d = tid & 31;
-    float v = 0.f, l = 0.f;
 #pragma unroll
     for (int w = 0; w < NW * 4; ++w) v += s_acc[w][g][d];
 #pragma unroll
     for (int w = 0; w < NW; ++w) l += s_l[w][g];
-    a.out[((size_t)r * a.n_heads + kvh * G + g) * HD + slice * 32 + d] = f2bf(__fmul_rn(v, 1.0f / l));
+  }
+  if constexpr (!SPLIT) {
+    if (tid < G * 32) a.out[((size_t)r * a.n_heads + kvh * G + g) * HD + slice * 32 + d] = f2bf(__fmul_rn(v, 1.0f / l));
+  } else {
+    constexpr int PSZ = G * 32 + G;
+    const int group = (r * a.n_heads_kv + kvh) * (HD / 32) + slice;
+    float* pp = a.part + ((size_t)group * a.nbcap + jb) * PSZ;
+    if (tid < G * 32) {
+      st_wt(pp + g * 32 + d, v);
+      if (d == 0) st_wt(pp + G * 32 + g, l);
+    }
+    __builtin_amdgcn_s_waitcnt(0);                        // stores acknowledged before the ticket
+    __syncthreads();
+    __shared__ int s_last;
+    if (tid == 0) {
+      const int t = __hip_atomic_fetch_add(a.tickets + group, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      s_last = (t == nb - 1);
+      if (s_last) __hip_atomic_store(a.tickets + group, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (!s_last) return;
+    // the reference's recurrence over the blocks, in order: acc = acc * f_j + pv_j, lsum = lsum * f_j + sum_j,
+    // f_j = exp(m_{j-1} - m_j) with m_j the running maximum through block j (from the chunk maxima of pass 1)
+    __shared__ float s_bmax[G][32];                       // block maxima per head (nbcap <= 32: 16384 keys)
+    if (tid < G * 32 && d < nb) {
+      const float* crq = a.cmax + ((size_t)r * a.n_heads + kvh * G + g) * cstride;
+      float t8[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) t8[u] = crq[min(8 * d + u, nchunks - 1)];
+      float bm = -INFINITY;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) if (8 * d + u < nchunks) bm = fmaxf(bm, t8[u]);
+      s_bmax[g][d] = bm;
+    }
+    __syncthreads();
+    if (tid >= G * 32) return;
+    const float* pb = a.part + (size_t)group * a.nbcap * PSZ;
+    float tot = 0.f, lt = 0.f, mprev = -INFINITY;
+    for (int j0 = 0; j0 < nb; j0 += 8) {
+      // eight blocks' partials requested at once (one memory round trip per eight blocks, not per block)
+      float pv[8], pl[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int j = min(j0 + u, nb - 1);
+        pv[u] = ld_wt(pb + (size_t)j * PSZ + g * 32 + d);
+        pl[u] = ld_wt(pb + (size_t)j * PSZ + G * 32 + g);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int j = j0 + u;
+        if (j < nb) {
+          const float mj = fmaxf(mprev, s_bmax[g][j]);
+          const float fj = (j == 0) ? 0.f : expf(mprev - mj);
+          mprev = mj;
+          tot = __fadd_rn(__fmul_rn(tot, fj), pv[u]);
+          lt = __fadd_rn(__fmul_rn(lt, fj), pl[u]);
+        }
+      }
+    }
+    a.out[((size_t)r * a.n_heads + kvh * G + g) * HD + slice * 32 + d] = f2bf(__fmul_rn(tot, 1.0f / lt));
   }
 }
 
