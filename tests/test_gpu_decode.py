@@ -215,7 +215,7 @@ def test_attention_decode_vs_cpu_sdpa(full, fused_limit):
 
 
 def test_attention_long_context_split_pass_vs_cpu_sdpa(full):
-    """KV capacities above 2048 run the P.V pass as one workgroup per 512-key block with a ticketed in-order combine
+    """KV capacities above 1408 run the P.V pass as one workgroup per 512-key block with a ticketed in-order combine
     (acc = acc * f_j + pv_j, the reference's recurrence): same bar as the other launch shapes, contexts up to 4600 keys."""
     import torch.nn.functional as F
     model, _ = full

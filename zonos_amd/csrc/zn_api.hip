@@ -56,7 +56,7 @@ struct zn_handle_s {
   int *lengths = nullptr, *codes = nullptr;
   int force_eos_step = -1;
   float eos_bias = 0.f;
-  int tune[12] = {512, 512, 512, 1024, 256, 448, 2, 2, 0, 0, 0, 0};   // target workgroups: in_proj, out_proj, fc1, fc2, heads; [5] longest context of the fused attention launch; [6] > 1: multi-step graphs; [7] > 1: LDS-staged small-M projections; [9]: KV capacity above which the P.V pass splits per block (0 = 2048)
+  int tune[12] = {512, 512, 512, 1024, 256, 448, 2, 2, 0, 0, 0, 0};   // target workgroups: in_proj, out_proj, fc1, fc2, heads; [5] longest context of the fused attention launch; [6] > 1: multi-step graphs; [7] > 1: LDS-staged small-M projections; [9]: KV capacity above which the P.V pass splits per block (0 = 1408)
   const int* tok_override = nullptr;
   int tok_override_calls = 0;
   hipStream_t cap_stream = nullptr;
@@ -370,8 +370,8 @@ static int run_attention(zn_handle h, const bf16_t* q, const bf16_t* kv, int max
   dim3 grid((max_len + ZN_ACHUNK - 1) / ZN_ACHUNK, c.n_heads_kv, rows);
   // one fused launch for short contexts (the caller bounds the context: h->attn_fused), two passes beyond
   const bool fused = h->attn_fused;
-  // long KV capacities: the P.V pass runs one workgroup per 512-key block (tune[9] = capacity from which it does; 0 = 2048)
-  const int split_from = h->tune[9] > 0 ? h->tune[9] : 2048;
+  // long KV capacities: the P.V pass runs one workgroup per 512-key block (tune[9] = capacity from which it does; 0 = 1408)
+  const int split_from = h->tune[9] > 0 ? h->tune[9] : 1408;   // measured crossover: ~1400 keys of capacity
   a.part = h->pv_part; a.tickets = h->pv_tickets; a.nbcap = (!fused && max_len > split_from && h->lcap / 512 <= 32) ? h->lcap / 512 : 0;
   int r2 = hd == 128 ? launch_attn_g<128>(a, h->G, grid, fused, s) : hd == 64 ? launch_attn_g<64>(a, h->G, grid, fused, s)
                                                                              : launch_attn_g<32>(a, h->G, grid, fused, s);
