@@ -236,7 +236,12 @@ static bool run_gemm16s(zn_handle h, GemvArgs g, hipStream_t s) {
   if (groups > ZN_G16_MAX_GROUPS) return false;
   int ks = 1;
   while (groups * ks < 448 && ks < 16 && K % (2 * ks * ZN_G16_KC) == 0) ks *= 2;
-  if (ks > 1 && K / ks < 512) return false;   // short slices: the combine costs more than the direct-fragment kernel's access pattern
+  if (ks > 1 && K / ks < 512) {
+    // short slices: the combine costs more than the direct-fragment kernel's access pattern, unless a shallower split
+    // still fills the chip (in_proj, N = 3072: 96 groups x 4 slices of 512)
+    ks /= 2;
+    if (ks < 2 || K / ks < 512 || groups * ks < 320) return false;
+  }
   if ((size_t)ks * 16 * groups * nwv * 16 * sizeof(float) > h->g16_part_bytes) return false;
   g.part = h->g16_part; g.tickets = h->g16_tickets; g.ksplit = ks;
   if (nwv == 4) hipLaunchKernelGGL((gemm16s_kernel<EPI, 4>), dim3(groups, ks), dim3(256), 0, s, g);
