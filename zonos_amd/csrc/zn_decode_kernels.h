@@ -1,7 +1,8 @@
-// Decode-step kernels (S = 1, R = 2B rows): weight-streaming bf16 GEMV with fused prologues/epilogues,
-// KV-cached GQA attention that reproduces the reference CPU flash-attention rounding points, embedding sum,
-// sampler and frame bookkeeping.  All HBM-bound: weights are read once per step with 16-B non-temporal loads,
-// activations (a few KB) live in registers, reductions are wavefront shuffles.
+// Decode-step kernels (S = 1, R = 2B rows): weight-streaming bf16 GEMV with fused prologues/epilogues (R <= 4), small-M
+// MFMA projections for 5..16 rows (direct-fragment and LDS-staged), KV-cached GQA attention that reproduces the
+// reference CPU flash-attention rounding points (two-pass, fused single launch for short contexts, per-block split for
+// long ones), embedding sum, sampler and frame bookkeeping.  All HBM-bound: weights are read once per step with 16-B
+// non-temporal loads, activations (a few KB) live in registers or LDS, reductions are wavefront shuffles.
 #pragma once
 #include "zn_common.h"
 
