@@ -47,13 +47,16 @@ def test_add_layernorm_vs_oracle():
                 assert torch.equal(_bits(rd.cpu()), _bits(ref_res))          # the residual stream is exact (one fp32 add, one rounding)
 
 
-@pytest.mark.parametrize("cfg_name", ["tiny", "wide"])
+GROUPS_CFG = dict(synth.HYBRID_TINY_CFG, ssm_cfg={"layer": "Mamba2", "d_state": 64, "ngroups": 2})   # two B/C groups, two heads each
+
+
+@pytest.mark.parametrize("cfg_name", ["tiny", "wide", "groups"])
 def test_mamba2_step_vs_oracle(cfg_name):
     """Six consecutive tokens through the Mamba2 mixer of layer 0 from random states.  The conv window holds in_proj
     outputs (bf16 GEMV results: fp32 summation order may flip a last bit), SSM state and outputs additionally see libm
     ulp differences in exp/log1p before one bf16 rounding: bit-equal fractions > 0.98 (window, state) / > 0.8 (output),
     max |diff| <= 2^-6 of the output scale."""
-    cfg = synth.HYBRID_TINY_CFG if cfg_name == "tiny" else WIDE_CFG
+    cfg = {"tiny": synth.HYBRID_TINY_CFG, "wide": WIDE_CFG, "groups": GROUPS_CFG}[cfg_name]
     model, sd = build_model(cfg, 11, "cuda:0")
     eng = model.engine(1)
     st = _lib.stream_ptr()
