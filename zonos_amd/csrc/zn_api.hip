@@ -622,6 +622,11 @@ static int ensure_prefill_ws(zn_handle h, size_t M) {
 static void launch_gemm(const bf16_t* A, int lda, const bf16_t* W, bf16_t* out, int ldo, const bf16_t* resid, int M, int N, int K, hipStream_t s) {
   GemmArgs g{A, W, out, resid, M, N, K, lda, ldo};
   dim3 grid((N + 127) / 128, (M + 127) / 128);
+  if (M >= 256 && K % ZN_PG_KC == 0 && lda % 8 == 0) {   // long prompts: LDS-staged panels (coalesced row pieces)
+    if (resid) hipLaunchKernelGGL((gemm_bf16s_kernel<1>), grid, dim3(256), 0, s, g);
+    else hipLaunchKernelGGL((gemm_bf16s_kernel<0>), grid, dim3(256), 0, s, g);
+    return;
+  }
   if (resid) hipLaunchKernelGGL((gemm_bf16_kernel<1>), grid, dim3(256), 0, s, g);
   else hipLaunchKernelGGL((gemm_bf16_kernel<0>), grid, dim3(256), 0, s, g);
 }

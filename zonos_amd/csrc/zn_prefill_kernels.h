@@ -73,6 +73,83 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs a) {
     }
 }
 
+// LDS-staged variant for M >= 256 rows (long prompts).  The direct-fragment kernel above asks the vector-memory pipe for
+// 16 different rows per 16-lane phase (the access pattern that bounded the decode-side gemm16_kernel); here both operand
+// panels of a 128 x 128 x 64 step are fetched as whole 128-byte row pieces (8 lanes x 16 B per row piece), stored to LDS
+// with a +8-element row pad (conflict-free 16-B fragment reads) and the fragments come from LDS; the next step's global
+// requests are in flight during the MFMAs.  Same tile shape, accumulation type and epilogue as above.
+#define ZN_PG_KC 64
+template <int EPI>
+__global__ __launch_bounds__(256) void gemm_bf16s_kernel(GemmArgs a) {
+  constexpr int KC = ZN_PG_KC, LDW = KC + 8;
+  __shared__ __attribute__((aligned(16))) bf16_t As[128 * LDW];
+  __shared__ __attribute__((aligned(16))) bf16_t Bs[128 * LDW];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int mb = blockIdx.y * 128, nb = blockIdx.x * 128;
+  const int fr = lane & 15, fg = lane >> 4;
+  // staging slots: 128 rows x 8 pieces of 16 B per panel = 1024 pieces over 256 threads
+  const bf16_t* ap[4];
+  const bf16_t* wp[4];
+  int sl[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int idx = j * 256 + tid, row = idx >> 3, c16 = idx & 7;
+    ap[j] = a.A + (size_t)min(mb + row, a.M - 1) * a.lda + c16 * 8;          // clamped rows: masked in the epilogue
+    wp[j] = a.W + (size_t)min(nb + row, a.N - 1) * a.K + c16 * 8;
+    sl[j] = row * LDW + c16 * 8;
+  }
+  u32x4 ra[4], rw[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { ra[j] = ld16(ap[j]); rw[j] = ld16(wp[j]); }
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int k0 = 0; k0 < a.K; k0 += KC) {
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { *(u32x4*)&As[sl[j]] = ra[j]; *(u32x4*)&Bs[sl[j]] = rw[j]; }
+    __syncthreads();
+    if (k0 + KC < a.K) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { ra[j] = ld16(ap[j] + k0 + KC); rw[j] = ld16(wp[j] + k0 + KC); }
+    }
+#pragma unroll
+    for (int ks = 0; ks < KC / 32; ++ks) {
+      u32x4 fa[4], fw[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        fa[i] = *(const u32x4*)&As[(wm * 64 + i * 16 + fr) * LDW + 32 * ks + 8 * fg];
+        fw[i] = *(const u32x4*)&Bs[(wn * 64 + i * 16 + fr) * LDW + 32 * ks + 8 * fg];
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(zn_bf16x8p, fa[i]), __builtin_bit_cast(zn_bf16x8p, fw[j]), acc[i][j], 0, 0, 0);
+    }
+  }
+  const int m0 = mb + wm * 64, n0 = nb + wn * 64;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = n0 + j * 16 + fr;
+      if (n >= a.N) continue;
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int m = m0 + i * 16 + 4 * fg + reg;
+        if (m >= a.M) continue;
+        const size_t o = (size_t)m * a.ldo + n;
+        float v = bfround(acc[i][j][reg]);
+        if constexpr (EPI == 1) v = bf2f(a.resid[o]) + v;
+        a.out[o] = f2bf(v);
+      }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ row-wise pieces
 // q|k|v split, interleaved-pair RoPE (fp32, separate roundings) and KV append for all positions (_torch.py:399-411).
 // qkv [R][S][nq + 2*nkv]: q is rotated in place, k (rotated) and v go to the cache at position base + s.
