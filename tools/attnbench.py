@@ -25,7 +25,7 @@ def main():
     eng.call("zn_debug_eos_bias", float("-inf"))
     st = _lib.stream_ptr()
     for L0 in Ls:
-        for fused, multi in ((448, 2), (448, 1)):
+        for fused, multi in ((2048, 2), (1, 2)):
             eng.call("zn_debug_tune", 5, fused); eng.call("zn_debug_tune", 6, multi)
             max_new = L0 + n + 64
             ip = model.setup_cache(2, L0 + n + 40)
@@ -46,7 +46,7 @@ def main():
             e1.record()
             torch.cuda.synchronize()
             ms = e0.elapsed_time(e1) / n
-            print(f"L {L0 + 10:5d}..{L0 + 10 + n:5d} max_len {ip.max_seqlen:5d} {'8-step graph' if multi > 1 else '1-step graph'}: {ms:.4f} ms/step", flush=True)
+            print(f"L {L0 + 10:5d}..{L0 + 10 + n:5d} max_len {ip.max_seqlen:5d} {'fused attention   ' if fused > 1 else 'two-pass attention'}: {ms:.4f} ms/step", flush=True)
 
 
 main()

@@ -56,7 +56,7 @@ struct zn_handle_s {
   int *lengths = nullptr, *codes = nullptr;
   int force_eos_step = -1;
   float eos_bias = 0.f;
-  int tune[12] = {512, 512, 512, 1024, 256, 448, 2, 2, 0, 0, 0, 0};   // target workgroups: in_proj, out_proj, fc1, fc2, heads; [5] longest context of the fused attention launch; [6] > 1: multi-step graphs; [7] > 1: LDS-staged small-M projections; [9]: KV capacity above which the P.V pass splits per block (0 = 1408)
+  int tune[12] = {512, 512, 512, 1024, 256, 832, 2, 2, 0, 0, 0, 0};   // target workgroups: in_proj, out_proj, fc1, fc2, heads; [5] longest context of the fused attention launch; [6] > 1: multi-step graphs; [7] > 1: LDS-staged small-M projections; [9]: KV capacity above which the P.V pass splits per block (0 = 1408)
   const int* tok_override = nullptr;
   int tok_override_calls = 0;
   hipStream_t cap_stream = nullptr;

@@ -663,36 +663,45 @@ __global__ __launch_bounds__(512) void attn_pv_kernel(AttnArgs a) {
       if (kn < G) v = ld16(a.q + ((size_t)r * a.n_heads + kvh * G + kn) * HD + 32 * st + 8 * kg);
       qa[st] = __builtin_bit_cast(zn_bf16x8, v);
     }
-    const bf16_t* kbase = a.kv + (size_t)r * a.max_len * kvrow + (size_t)kvh * HD + 8 * kg;
+    // K rows are fetched whole (16 lanes x 16 B = one 256-byte key row per 16-lane phase; a fragment-shaped request would
+    // touch 16 different rows per phase and bound the pass by the vector-memory pipe) and staged per wave in padded LDS,
+    // where the MFMA B fragments (key = lane & 15, k-group = lane >> 4) are read back conflict-free.
+    constexpr int KLD = HD + 8, LPK = HD / 8, KPL = 64 / LPK, NLD = 16 / KPL;   // lanes per key row, keys per wave-load, loads per tile
+    __shared__ __attribute__((aligned(16))) bf16_t s_k[NW][16 * KLD];
+    const int kq = lane / LPK, kd = lane % LPK;                      // key within a load's group, 16-B piece of its row
+    const bf16_t* kbase = a.kv + (size_t)r * a.max_len * kvrow + (size_t)kvh * HD + kd * 8;
     typedef __attribute__((ext_vector_type(4))) float f32x4_t;
-    u32x4 kk[TPW][KST];
+    u32x4 kk[TPW][NLD];
 #pragma unroll
-    for (int tl = 0; tl < TPW; ++tl) {                               // block 0, before the length is known
-      const bf16_t* kp = kbase + (size_t)min((tl * NW + wave) * 16 + kn, a.max_len - 1) * kvrow;
+    for (int tl = 0; tl < TPW; ++tl)                                   // block 0, before the length is known
 #pragma unroll
-      for (int st = 0; st < KST; ++st) kk[tl][st] = ld16(kp + 32 * st);
-    }
+      for (int i = 0; i < NLD; ++i)
+        kk[tl][i] = ld16(kbase + (size_t)min((tl * NW + wave) * 16 + KPL * i + kq, a.max_len - 1) * kvrow);
     __builtin_amdgcn_sched_barrier(0);
     L = Lraw + 1; nb = (L + 511) >> 9;
+    bf16_t* kw = &s_k[wave][0];
     for (int j = 0; j < nb; ++j) {
       float mx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
       const int tb = j * 512, tend = min(L, tb + 512);
       if (j > 0) {
 #pragma unroll
-        for (int tl = 0; tl < TPW; ++tl) {
-          const int t = tb + (tl * NW + wave) * 16 + kn;
-          const bf16_t* kp = kbase + (size_t)min(t, L - 1) * kvrow;   // clamped, not masked: no exec branch between the loads
+        for (int tl = 0; tl < TPW; ++tl)
 #pragma unroll
-          for (int st = 0; st < KST; ++st) kk[tl][st] = ld16(kp + 32 * st);
-        }
+          for (int i = 0; i < NLD; ++i)                                // clamped, not masked: no exec branch between the loads
+            kk[tl][i] = ld16(kbase + (size_t)min(tb + (tl * NW + wave) * 16 + KPL * i + kq, L - 1) * kvrow);
       }
 #pragma unroll
       for (int tl = 0; tl < TPW; ++tl) {
         const int tt = tb + (tl * NW + wave) * 16;
         if (tt < tend) {                                          // wave-uniform
+#pragma unroll
+          for (int i = 0; i < NLD; ++i) *(u32x4*)(kw + (KPL * i + kq) * KLD + kd * 8) = kk[tl][i];
           f32x4_t c = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-          for (int st = 0; st < KST; ++st) c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa[st], __builtin_bit_cast(zn_bf16x8, kk[tl][st]), c, 0, 0, 0);
+          for (int st = 0; st < KST; ++st) {
+            const u32x4 bfrag = *(const u32x4*)(kw + kn * KLD + 32 * st + 8 * kg);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa[st], __builtin_bit_cast(zn_bf16x8, bfrag), c, 0, 0, 0);
+          }
           const int t = tt + kn;
 #pragma unroll
           for (int reg = 0; reg < 4; ++reg) {
