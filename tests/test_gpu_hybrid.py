@@ -155,3 +155,29 @@ def test_hybrid_batch_rows_match_single_runs(B):
             assert same == 1.0
         else:
             assert torch.equal(out[i, :, :3], singles[i][0, :, :3]) and same > 0.5
+
+
+def test_hybrid_full_width_stack_vs_oracle():
+    """Six layers at the real widths (d 2048, Mamba2 d_inner 4096 / 64 heads / d_state 128, one attention + MLP layer,
+    peaky heads) teacher-forced on the oracle's inputs for 24 steps: logits within 2^-5 of the largest |logit|, greedy
+    indices equal wherever the oracle's margin exceeds twice that (the full-dims bar of the transformer tests)."""
+    cfg = dict(synth.HYBRID_FULL_CFG, n_layer=6, attn_layer_idx=[2])
+    model, sd = build_model(cfg, 29, "cuda:0", peaky=True)
+    cond = synth.conditioning(29, "cond", 2, 12, cfg["d_model"])
+    max_new = 24
+    tr = zo.GenTrace()
+    zo.generate(sd, dict(cfg), cond, max_new_tokens=max_new, cfg_scale=2.0, sampling_params=GREEDY, trace=tr)
+    ref = torch.stack(tr.logits).numpy()
+    got = _trace_run(model, cond, max_new, torch.stack(tr.inputs).numpy()).numpy()
+    fin = np.isfinite(ref)
+    assert np.array_equal(np.isfinite(got), fin)
+    diff = np.abs(np.where(fin, got - ref, 0.0))
+    maxabs = float(np.abs(np.where(fin, ref, 0)).max())
+    tol = max(0.06, 2.0 ** -5 * maxabs)
+    srt = np.sort(np.where(fin, ref, -np.inf), axis=-1)
+    margin = srt[..., -1] - srt[..., -2]
+    ga, ra = np.where(fin, got, -np.inf).argmax(-1), np.where(fin, ref, -np.inf).argmax(-1)
+    print(f"\n[hybrid full width, 6 layers] {len(got)} calls: exact logits {float((diff == 0).mean()):.4f}, max|diff| {diff.max():.4g} "
+          f"(max|logit| {maxabs:.1f}, tol {tol:.3g}); argmax equal {float((ga == ra).mean()):.4f}, decisive pairs {float((margin > 2 * tol).mean()):.3f}")
+    assert diff.max() <= tol
+    assert np.array_equal(ga[margin > 2 * tol], ra[margin > 2 * tol])
