@@ -184,7 +184,11 @@ int zn_op_layer_decode(zn_handle h, int32_t layer, void* x_dev, void* kv_dev, in
  * lengths[r]+1 keys -> out bf16 [rows, Hq*hd]; reproduces the CPU flash-attention rounding points. */
 int zn_op_attn_decode(zn_handle h, const void* q_dev, const void* kv_dev, int32_t max_len, const int32_t* lengths_dev,
                       const int32_t* ext_dev, void* out_dev, int32_t rows, zn_stream stream);
-/* embed_codes_static (codec_utils.py:37): codes int32 [B, n_codebooks] -> bf16 [B, d], sequential bf16 adds. */
+/* Causal prefill attention alone (_torch.py:413-417 with is_causal=True, the S > 1 call): q bf16 [rows, positions, Hq*hd]
+ * (post-RoPE), kv [rows, max_len, 2, Hkv, hd] holding the keys of positions 0..positions-1 -> out bf16
+ * [rows, positions, Hq*hd]; same CPU flash-attention rounding points as zn_op_attn_decode, incl. its query-block split. */
+int zn_op_attn_prefill(zn_handle h, const void* q_dev, const void* kv_dev, int32_t max_len, void* out_dev, int32_t positions,
+                       int32_t rows, zn_stream stream);
 /* mamba_ssm layer_norm_fn(prenorm=True) of the hybrid Block: s = h + res (fp32), res <- bf16(s) in place (res NULL:
  * s = h), out = bf16(LayerNorm(s)).  h/res/out bf16 [rows, d]. */
 int zn_op_add_layernorm(zn_handle h, const void* hidden, void* res, const void* w, const void* b, void* out, int32_t rows,
@@ -192,6 +196,7 @@ int zn_op_add_layernorm(zn_handle h, const void* hidden, void* res, const void* 
 /* One token through the Mamba2 mixer of hybrid layer `layer` (mamba_ssm Mamba2.step): x bf16 [rows, d] (already
  * normalised), state = the layer's zn_mamba_state_bytes_per_layer buffer (updated), out bf16 [rows, d]. */
 int zn_op_mamba_step(zn_handle h, int32_t layer, const void* x, void* state, void* out, int32_t rows, zn_stream stream);
+/* embed_codes_static (codec_utils.py:37): codes int32 [B, n_codebooks] -> bf16 [B, d], sequential bf16 adds. */
 int zn_op_embed(zn_handle h, const int32_t* codes_dev, void* out_dev, int32_t batch, zn_stream stream);
 /* sample_from_logits (sampling.py:166-231) on fp32 logits [B, n_codebooks, vocab_head]; recent int32
  * [B, n_codebooks, window] or NULL; tokens int32 [B, n_codebooks]; probs_out (optional) receives the filtered

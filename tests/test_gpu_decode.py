@@ -241,6 +241,37 @@ def test_attention_long_context_split_pass_vs_cpu_sdpa(full):
         assert eq > 0.99, (L, eq)
 
 
+@pytest.mark.parametrize("kernel", [1, 2], ids=["mfma", "valu"])
+def test_attention_prefill_vs_cpu_sdpa(full, kernel):
+    """zn_op_attn_prefill vs torch CPU SDPA(is_causal=True) — the S > 1 call of _torch.py:415 — on random bf16 q/K/V at
+    S = 10, 77, 257, 807, 1300 (below/above the CPU flash kernel's query splits of 32/64/256, across 512-key blocks,
+    ragged last tiles): bit-equal fraction > 0.99 for both kernels (matrix-core tiles at head size 128; the VALU
+    kernel that serves the other head sizes), residual = fp32 summation order."""
+    import torch.nn.functional as F
+    model, _ = full
+    eng = model.engine(1)
+    eng.call("zn_debug_tune", 10, kernel)
+    st = _lib.stream_ptr()
+    gen = torch.Generator().manual_seed(2)
+    try:
+        for S in (10, 77, 257, 807, 1300):
+            cap = S + 5
+            q = torch.randn(2, 16, S, 128, generator=gen).to(torch.bfloat16)
+            kv = torch.randn(2, cap, 2, 4, 128, generator=gen).to(torch.bfloat16)
+            ref = F.scaled_dot_product_attention(q, kv[:, :S, 0].transpose(1, 2), kv[:, :S, 1].transpose(1, 2), is_causal=True, enable_gqa=True)
+            qd = q.transpose(1, 2).reshape(2, S, 2048).contiguous().to("cuda:0")
+            kvd = kv.to("cuda:0")
+            out = torch.full((2, S, 2048), float("nan"), dtype=torch.bfloat16, device="cuda:0")
+            eng.call("zn_op_attn_prefill", qd.data_ptr(), kvd.data_ptr(), cap, out.data_ptr(), S, 2, st)
+            torch.cuda.synchronize()
+            got = out.cpu().view(2, S, 16, 128).transpose(1, 2).contiguous()
+            eq = float((got.view(torch.int16) == ref.contiguous().view(torch.int16)).float().mean())
+            print(f"\n[prefill attn kernel={kernel} S={S}] bit-equal {eq:.5f} max|d| {(got.float() - ref.float()).abs().max().item():.3g}")
+            assert eq > 0.99, (S, eq)
+    finally:
+        eng.call("zn_debug_tune", 10, 1)
+
+
 def test_layer0_decode_vs_reference_block(golden_dir, full):
     """One decode step of block 0 at Zonos-v0.1-transformer dims over a synthetic KV history (L = 1, 17, 900):
     reference TransformerBlock output (golden) vs zn_op_layer_decode."""

@@ -56,7 +56,7 @@ struct zn_handle_s {
   int *lengths = nullptr, *codes = nullptr;
   int force_eos_step = -1;
   float eos_bias = 0.f;
-  int tune[12] = {512, 512, 512, 1024, 256, 832, 2, 2, 0, 0, 0, 0};   // target workgroups: in_proj, out_proj, fc1, fc2, heads; [5] longest context of the fused attention launch; [6] > 1: multi-step graphs; [7] > 1: LDS-staged small-M projections; [9]: KV capacity above which the P.V pass splits per block (0 = 1408)
+  int tune[12] = {512, 512, 512, 1024, 256, 832, 2, 2, 0, 0, 0, 0};   // target workgroups: in_proj, out_proj, fc1, fc2, heads; [5] longest context of the fused attention launch; [6] > 1: multi-step graphs; [7] > 1: LDS-staged small-M projections; [9]: KV capacity above which the P.V pass splits per block (0 = 1408); [10] = 2: VALU prefill attention
   const int* tok_override = nullptr;
   int tok_override_calls = 0;
   hipStream_t cap_stream = nullptr;
@@ -632,7 +632,18 @@ static void launch_gemm(const bf16_t* A, int lda, const bf16_t* W, bf16_t* out, 
 }
 
 template <int HD>
-static int launch_prefill_attn(const PrefillAttnArgs& a, int G, int R, hipStream_t s) {
+static int launch_prefill_attn(const PrefillAttnArgs& a, int G, int R, bool mfma, hipStream_t s) {
+  if constexpr (HD == 128) {
+    if (mfma) {   // both contractions on the matrix cores (same row semantics)
+      dim3 grid((a.S + 64 / G - 1) / (64 / G), a.n_heads_kv, R);
+      switch (G) {
+        case 1: hipLaunchKernelGGL((attn_prefill_mfma_kernel<1>), grid, dim3(256), 0, s, a); return 0;
+        case 2: hipLaunchKernelGGL((attn_prefill_mfma_kernel<2>), grid, dim3(256), 0, s, a); return 0;
+        case 4: hipLaunchKernelGGL((attn_prefill_mfma_kernel<4>), grid, dim3(256), 0, s, a); return 0;
+        case 8: hipLaunchKernelGGL((attn_prefill_mfma_kernel<8>), grid, dim3(256), 0, s, a); return 0;
+      }
+    }
+  }
   switch (G) {
 #define ZN_PA(GG) case GG: hipLaunchKernelGGL((attn_prefill_kernel<HD, GG>), dim3((a.S + 64 / GG - 1) / (64 / GG), a.n_heads_kv, R), dim3(256), 0, s, a); return 0;
     ZN_PA(1) ZN_PA(2) ZN_PA(4) ZN_PA(8)
@@ -644,6 +655,20 @@ static int launch_prefill_attn(const PrefillAttnArgs& a, int G, int R, hipStream
 static int qsplit(int S) { return S >= 768 ? 256 : S >= 192 ? 64 : 32; }   // query split of the CPU flash kernel
 
 // All S positions at once: row-wise kernels over M = R*S rows, MFMA GEMMs, tiled exact causal attention.
+// causal attention of S prefill positions over the keys already written for them (SDPA is_causal=True, _torch.py:415)
+static int prefill_attention(zn_handle h, const bf16_t* q, int ldq, const bf16_t* kv, int max_len, bf16_t* out, int ldo, int S, int R,
+                             hipStream_t s) {
+  const zn_config& c = h->cfg;
+  const int hd = h->hd;
+  PrefillAttnArgs pa{};
+  pa.q = q; pa.ldq = ldq; pa.kv = kv; pa.out = out; pa.ldo = ldo; pa.S = S; pa.base = 0; pa.max_len = max_len;
+  pa.n_heads = c.n_heads; pa.n_heads_kv = c.n_heads_kv; pa.qsplit = qsplit(S); pa.scale = (float)(1.0 / std::sqrt((double)hd));
+  const bool mfma = h->tune[10] != 2;   // tune[10] = 2: the VALU kernel at every head size
+  int r2 = hd == 128 ? launch_prefill_attn<128>(pa, h->G, R, mfma, s) : hd == 64 ? launch_prefill_attn<64>(pa, h->G, R, mfma, s) : launch_prefill_attn<32>(pa, h->G, R, mfma, s);
+  if (r2) ZN_FAIL(h, ZN_ERR_UNSUPPORTED, "prefill attention: unsupported group %d", h->G);
+  return ZN_OK;
+}
+
 static int prefill_batched(zn_handle h, const bf16_t* hidden, int S, hipStream_t s) {
   const zn_config& c = h->cfg;
   const int R = h->rows, M = R * S, d = c.d_model, hd = h->hd, nq = c.n_heads * hd, nkv = c.n_heads_kv * hd, nqkv = nq + 2 * nkv, F = c.d_ff;
@@ -656,11 +681,8 @@ static int prefill_batched(zn_handle h, const bf16_t* hidden, int S, hipStream_t
     hipLaunchKernelGGL(layernorm_kernel, dim3(M), dim3(64), 0, s, h->pf_x, (const bf16_t*)lw.norm_w, (const bf16_t*)lw.norm_b, h->pf_n, d, c.norm_eps);
     launch_gemm(h->pf_n, d, (const bf16_t*)lw.in_proj, h->pf_qkv, nqkv, nullptr, M, nqkv, d, s);
     hipLaunchKernelGGL(rope_kv_rows_kernel, dim3(S, R), dim3(256), 0, s, h->pf_qkv, kv, h->rope, S, 0, h->max_len, c.n_heads, c.n_heads_kv, hd, c.rope_positions);
-    PrefillAttnArgs pa{};
-    pa.q = h->pf_qkv; pa.ldq = nqkv; pa.kv = kv; pa.out = h->pf_a; pa.ldo = nq; pa.S = S; pa.base = 0; pa.max_len = h->max_len;
-    pa.n_heads = c.n_heads; pa.n_heads_kv = c.n_heads_kv; pa.qsplit = qsplit(S); pa.scale = (float)(1.0 / std::sqrt((double)hd));
-    int r2 = hd == 128 ? launch_prefill_attn<128>(pa, h->G, R, s) : hd == 64 ? launch_prefill_attn<64>(pa, h->G, R, s) : launch_prefill_attn<32>(pa, h->G, R, s);
-    if (r2) ZN_FAIL(h, ZN_ERR_UNSUPPORTED, "prefill attention: unsupported group %d", h->G);
+    rc = prefill_attention(h, h->pf_qkv, nqkv, kv, h->max_len, h->pf_a, nq, S, R, s);
+    if (rc) return rc;
     if (c.double_out_proj) {
       launch_gemm(h->pf_a, nq, (const bf16_t*)lw.out_proj, h->pf_n, d, nullptr, M, d, nq, s);
       launch_gemm(h->pf_n, d, (const bf16_t*)lw.out_proj, h->pf_x, d, h->pf_x, M, d, nq, s);
@@ -962,6 +984,17 @@ extern "C" int zn_op_attn_decode(zn_handle h, const void* q, const void* kv, int
   if (rc) return rc;
   h->attn_fused = attn_fused_for(h, max_len);
   rc = run_attention(h, (const bf16_t*)q, (const bf16_t*)kv, max_len, lengths, ext, 0, (bf16_t*)out, rows, (hipStream_t)stream);
+  if (rc) return rc;
+  HIPCHK(h, hipGetLastError());
+  return ZN_OK;
+}
+
+extern "C" int zn_op_attn_prefill(zn_handle h, const void* q, const void* kv, int32_t max_len, void* out, int32_t positions, int32_t rows,
+                                  zn_stream stream) {
+  if (!h) return ZN_ERR_ARG;
+  if (!q || !kv || !out || rows < 1 || positions < 1 || max_len < positions) ZN_FAIL(h, ZN_ERR_ARG, "zn_op_attn_prefill: bad argument");
+  const int nq = h->cfg.n_heads * h->hd;
+  int rc = prefill_attention(h, (const bf16_t*)q, nq, (const bf16_t*)kv, max_len, (bf16_t*)out, nq, positions, rows, (hipStream_t)stream);
   if (rc) return rc;
   HIPCHK(h, hipGetLastError());
   return ZN_OK;

@@ -316,3 +316,186 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(PrefillAttnArgs a) {
     }
   }
 }
+
+// ------------------------------------------------------------------------------------------------ attention on the matrix cores
+// Same row semantics as attn_prefill_kernel (the reference CPU flash kernel: 512-key blocks, running max, fexp_u20 on the
+// first 16*floor(n/16) keys of the block's span / libm exp on the tail, row sum of the unrounded e, P = bf16(e), rescale
+// by exp(m_old - m_new)), with both contractions on v_mfma_f32_16x16x32_bf16.  A workgroup owns 64 query rows (64/G
+// positions x G heads of one kv head), 16 per wave, and walks the keys in 64-key chunks staged row-major in LDS by
+// coalesced 16-byte pieces.  Per 512-key block: pass 1 computes S = Q K^T per chunk and keeps only the row maxima;
+// pass 2 recomputes S, forms e and P, writes the wave's P tile to LDS in A-operand order and accumulates P.V.
+// Neither contraction cares about the order of its k index nor P.V about the order of its output columns, so both are
+// permuted to fit the data as it lies: k-slot 4*fn + ct of P holds key ct*16 + fn (a lane's four scores of one row are one
+// 8-byte LDS store), and column fn of output tile dt is dim 8*fn + dt, which lets a lane fetch V as eight 16-byte row
+// pieces (keys of its k-slots x dims 8*fn..8*fn+7) and transpose them in registers (v_perm_b32) into the eight B operands.
+// The accumulators (16 rows x 128 dims per wave) live in registers in the D layout: col = lane & 15, row = 4*(lane>>4)+reg.
+template <int G>
+__global__ __launch_bounds__(256) void attn_prefill_mfma_kernel(PrefillAttnArgs a) {
+  constexpr int HD = 128, TQ = 64 / G, KP = HD + 8, PP = 64 + 8, OP = HD + 4;
+  constexpr int K_BYTES = 64 * KP * 2, P_BYTES = 4 * 16 * PP * 2, O_BYTES = 4 * 16 * OP * 4;
+  constexpr int SMEM = (2 * K_BYTES + P_BYTES) > O_BYTES ? (2 * K_BYTES + P_BYTES) : O_BYTES;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM];
+  bf16_t* s_k = (bf16_t*)smem;                          // [key][dim]
+  bf16_t* s_v = (bf16_t*)(smem + K_BYTES);              // [key][dim]
+  bf16_t* s_p = (bf16_t*)(smem + 2 * K_BYTES);          // per wave [row][k-slot]
+  float* s_o = (float*)smem;                            // epilogue staging [wave][row][dim] (after the key loop)
+  const int s0 = ((int)gridDim.x - 1 - (int)blockIdx.x) * TQ, kvh = blockIdx.y, r = blockIdx.z;     // longest rows first
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fn = lane & 15, fg = lane >> 4;
+  u32x4 qa[4];                                          // A operand: row = fn, k = 32*st + 8*fg + j
+  {
+    const int arow = wave * 16 + fn;
+    const int as = min(s0 + arow / G, a.S - 1), ag = arow % G;
+    const bf16_t* qp = a.q + ((size_t)r * a.S + as) * a.ldq + (size_t)(kvh * G + ag) * HD + 8 * fg;
+#pragma unroll
+    for (int st = 0; st < 4; ++st) qa[st] = ld16(qp + 32 * st);
+  }
+  int Lrow[4], Erow[4];             // keys row 4*fg + reg of this wave may see / keys spanned by its query block in the reference
+#pragma unroll
+  for (int reg = 0; reg < 4; ++reg) {
+    const int row = wave * 16 + 4 * fg + reg, s = s0 + row / G;
+    const bool ok = s < a.S;
+    Lrow[reg] = ok ? a.base + s + 1 : 0;
+    const int sq = ok ? s : s0;
+    Erow[reg] = a.base + min((sq / a.qsplit) * a.qsplit + a.qsplit, a.S);
+  }
+  const int Lmax = a.base + min(s0 + TQ, a.S);
+  f32x4 acc[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float lsum[4] = {0.f, 0.f, 0.f, 0.f}, m_run[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+  const size_t kvrow = (size_t)2 * a.n_heads_kv * HD;
+  const bf16_t* kg = a.kv + (size_t)r * a.max_len * kvrow + (size_t)kvh * HD;
+  const bf16_t* vg = kg + (size_t)a.n_heads_kv * HD;
+  bf16_t* pw = s_p + wave * 16 * PP;
+
+  // scaled scores of one staged chunk: sc[ct][reg] = row 4*fg+reg, key ct*16 + fn
+  auto scores = [&](f32x4 (&sc)[4]) {
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
+      f32x4 c = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int st = 0; st < 4; ++st) {
+        const u32x4 kb = *(const u32x4*)(s_k + (ct * 16 + fn) * KP + 32 * st + 8 * fg);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(zn_bf16x8p, qa[st]), __builtin_bit_cast(zn_bf16x8p, kb), c, 0, 0, 0);
+      }
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) sc[ct][reg] = __fmul_rn(c[reg], a.scale);
+    }
+  };
+  // rows at or past Lmax are never visible to this workgroup; their (clamped) loads are zeroed so that 0 * V stays 0
+  auto stage = [&](int tb, bool with_v) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int i = tid + 256 * j, key = i >> 4, pc = i & 15, t = tb + key;
+      const size_t off = (size_t)min(t, Lmax - 1) * kvrow + 8 * pc;
+      u32x4 kx = ld16(kg + off);
+      if (t >= Lmax) kx = u32x4{0, 0, 0, 0};
+      *(u32x4*)(s_k + key * KP + 8 * pc) = kx;
+      if (with_v) {
+        u32x4 vx = ld16(vg + off);
+        if (t >= Lmax) vx = u32x4{0, 0, 0, 0};
+        *(u32x4*)(s_v + key * KP + 8 * pc) = vx;
+      }
+    }
+  };
+
+  for (int t0 = 0; t0 < Lmax; t0 += 512) {
+    const int nch = min(8, (Lmax - t0 + 63) / 64);
+    // ---------------- pass 1: block maxima of the rows
+    float mx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    for (int c = 0; c < nch; ++c) {
+      __syncthreads();
+      stage(t0 + c * 64, false);
+      __syncthreads();
+      f32x4 sc[4];
+      scores(sc);
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct) {
+        const int t = t0 + c * 64 + ct * 16 + fn;
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) mx[reg] = fmaxf(mx[reg], t < Lrow[reg] ? sc[ct][reg] : -INFINITY);
+      }
+    }
+    float mnew[4];
+    int nvec[4];
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      const float bm = group_max<16>(mx[reg]);            // over the 16 key lanes of the row group
+      mnew[reg] = fmaxf(m_run[reg], bm);
+      const float f = (t0 == 0) ? 0.f : expf(m_run[reg] - mnew[reg]);
+      m_run[reg] = mnew[reg];
+      lsum[reg] = __fmul_rn(lsum[reg], f);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) acc[i][reg] = __fmul_rn(acc[i][reg], f);
+      nvec[reg] = min(512, Erow[reg] - t0) & ~15;
+    }
+    // ---------------- pass 2: e / P / P.V
+    for (int c = 0; c < nch; ++c) {
+      __syncthreads();
+      stage(t0 + c * 64, true);
+      __syncthreads();
+      f32x4 sc[4];
+      scores(sc);
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        float e[4];
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) {
+          const int idx = c * 64 + ct * 16 + fn, t = t0 + idx;
+          const float x = __fsub_rn(sc[ct][reg], mnew[reg]);
+          const float ev = (idx < nvec[reg]) ? zn_fexp_u20(x) : expf(x);
+          e[ct] = (t < Lrow[reg]) ? ev : 0.f;
+          lsum[reg] += e[ct];
+        }
+        uint2 pk; pk.x = pack2(e[0], e[1]); pk.y = pack2(e[2], e[3]);
+        *(uint2*)(pw + (4 * fg + reg) * PP + 4 * fn) = pk;             // k-slots 4*fn .. 4*fn+3
+      }
+      // the P tile is private to the wave: LDS ops of one wave complete in order, so a wave-level fence is enough
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const u32x4 pa = *(const u32x4*)(pw + fn * PP + 32 * ks + 8 * fg);       // k-slots 32*ks + 8*fg + j
+        u32x4 vr[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {                                             // slot sigma holds key (sigma&3)*16 + (sigma>>2)
+          const int key = (j & 3) * 16 + 8 * ks + 2 * fg + (j >> 2);
+          vr[j] = *(const u32x4*)(s_v + key * KP + 8 * fn);
+        }
+#pragma unroll
+        for (int dt = 0; dt < 8; ++dt) {
+          const unsigned sel = (dt & 1) ? 0x07060302u : 0x05040100u;
+          u32x4 vb;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const unsigned lo = (dt >> 1) == 0 ? vr[2 * q].x : (dt >> 1) == 1 ? vr[2 * q].y : (dt >> 1) == 2 ? vr[2 * q].z : vr[2 * q].w;
+            const unsigned hi = (dt >> 1) == 0 ? vr[2 * q + 1].x : (dt >> 1) == 1 ? vr[2 * q + 1].y : (dt >> 1) == 2 ? vr[2 * q + 1].z : vr[2 * q + 1].w;
+            const unsigned pr = __builtin_amdgcn_perm(hi, lo, sel);
+            if (q == 0) vb.x = pr; else if (q == 1) vb.y = pr; else if (q == 2) vb.z = pr; else vb.w = pr;
+          }
+          acc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(zn_bf16x8p, pa), __builtin_bit_cast(zn_bf16x8p, vb), acc[dt], 0, 0, 0);
+        }
+      }
+    }
+  }
+  // row sums are split over the 16 key lanes of each row group; normalise and stage the tile for coalesced stores
+  __syncthreads();
+#pragma unroll
+  for (int reg = 0; reg < 4; ++reg) {
+    const float l = group_sum<16>(lsum[reg]);
+    const float rl = 1.0f / l;
+#pragma unroll
+    for (int dt = 0; dt < 8; ++dt) s_o[(wave * 16 + 4 * fg + reg) * OP + 8 * fn + dt] = __fmul_rn(acc[dt][reg], rl);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {                          // 16 rows x 16 pieces of 8 dims per wave
+    const int i = lane + 64 * j, row = i >> 4, pc = i & 15, grow = wave * 16 + row, s = s0 + grow / G, g = grow % G;
+    if (s >= a.S) continue;
+    const float* o = s_o + grow * OP + 8 * pc;
+    u32x4 ov;
+    ov.x = pack2(o[0], o[1]); ov.y = pack2(o[2], o[3]); ov.z = pack2(o[4], o[5]); ov.w = pack2(o[6], o[7]);
+    *(u32x4*)(a.out + ((size_t)r * a.S + s) * a.ldo + (size_t)(kvh * G + g) * HD + 8 * pc) = ov;
+  }
+}
