@@ -211,7 +211,7 @@ def test_attention_decode_vs_cpu_sdpa(full, fused_limit):
         eq = float((got.view(torch.int16) == r.contiguous().view(torch.int16)).float().mean())
         print(f"\n[attn L={L}] bit-equal {eq:.5f} max|d| {(got.float() - r.float()).abs().max().item():.3g}")
         assert eq > 0.99, (L, eq)
-    eng.call("zn_debug_tune", 5, 832)
+    eng.call("zn_debug_tune", 5, 704)
 
 
 def test_attention_long_context_split_pass_vs_cpu_sdpa(full):

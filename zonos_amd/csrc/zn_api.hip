@@ -56,7 +56,7 @@ struct zn_handle_s {
   int *lengths = nullptr, *codes = nullptr;
   int force_eos_step = -1;
   float eos_bias = 0.f;
-  int tune[12] = {512, 512, 512, 1024, 256, 832, 2, 2, 0, 0, 0, 0};   // target workgroups: in_proj, out_proj, fc1, fc2, heads; [5] longest context of the fused attention launch; [6] > 1: multi-step graphs; [7] > 1: LDS-staged small-M projections; [9]: KV capacity above which the P.V pass splits per block (0 = 1408); [10] = 2: VALU prefill attention
+  int tune[12] = {512, 512, 512, 1024, 256, 704, 2, 2, 0, 0, 0, 0};   // target workgroups: in_proj, out_proj, fc1, fc2, heads; [5] longest context of the fused attention launch; [6] > 1: multi-step graphs; [7] > 1: LDS-staged small-M projections; [9]: KV capacity above which the P.V pass splits per block (0 = 1408); [10] = 2: VALU prefill attention; [11] = 2: no in-workgroup-split small-M kernel
   const int* tok_override = nullptr;
   int tok_override_calls = 0;
   hipStream_t cap_stream = nullptr;
@@ -131,6 +131,7 @@ extern "C" int zn_create(const zn_config* cfg, const zn_weights* w, int32_t max_
   if (hd != 32 && hd != 64 && hd != 128) ZN_FAIL((zn_handle) nullptr, ZN_ERR_UNSUPPORTED, "head_dim %d not in {32,64,128}", hd);
   if (G != 1 && G != 2 && G != 4 && G != 8) ZN_FAIL((zn_handle) nullptr, ZN_ERR_UNSUPPORTED, "GQA group %d not in {1,2,4,8}", G);
   if (c.d_model % 8 || c.d_ff % 8 || c.d_model > 4096) ZN_FAIL((zn_handle) nullptr, ZN_ERR_UNSUPPORTED, "d_model/d_ff must be multiples of 8, d_model <= 4096");
+  if (c.n_codebooks > ZN_FRAME_MAXQ) ZN_FAIL((zn_handle) nullptr, ZN_ERR_UNSUPPORTED, "n_codebooks > %d", ZN_FRAME_MAXQ);
   if (c.vocab_head > ZN_SAMPLE_MAXV) ZN_FAIL((zn_handle) nullptr, ZN_ERR_UNSUPPORTED, "vocab_head > %d", ZN_SAMPLE_MAXV);
   if (max_rows < 2 || max_rows % 2) ZN_FAIL((zn_handle) nullptr, ZN_ERR_ARG, "max_rows must be even and >= 2");
   if (c.arch != 0 && c.arch != 1) ZN_FAIL((zn_handle) nullptr, ZN_ERR_ARG, "zn_create: arch must be 0 (transformer) or 1 (hybrid)");
@@ -249,6 +250,23 @@ static bool run_gemm16s(zn_handle h, GemvArgs g, hipStream_t s) {
   return true;
 }
 
+// rows in (4, 16], K = 8 waves x 128 x {2, 4} and few weight rows (the LDS-staged kernel would have to split K over
+// workgroups): one 16-row tile per workgroup, K split over its waves, no cross-workgroup combine.  tune[11] = 2 disables.
+template <int EPI>
+static bool run_gemm16k(zn_handle h, const GemvArgs& g, hipStream_t s) {
+  if constexpr (EPI == EPI_SILU) return false;
+  else {
+    if (h->tune[11] == 2) return false;
+    const int per = ZN_G16K_NKW * ZN_G16K_KCH, nch = g.K / per;
+    if (g.K % per || (nch != 2 && nch != 4)) return false;
+    const int tiles = (g.N + 15) / 16;
+    if (tiles >= 1024) return false;                                  // many rows: the 64-row workgroups fill the chip without a split
+    if (nch == 2) hipLaunchKernelGGL((gemm16k_kernel<EPI, 2>), dim3(tiles), dim3(ZN_G16K_NKW * 64), 0, s, g);
+    else hipLaunchKernelGGL((gemm16k_kernel<EPI, 4>), dim3(tiles), dim3(ZN_G16K_NKW * 64), 0, s, g);
+    return true;
+  }
+}
+
 template <int PRO, int EPI>
 static int run_gemm16(zn_handle h, GemvArgs a, int rows, hipStream_t s) {
   const int K = a.K;
@@ -275,6 +293,7 @@ static int run_gemm16(zn_handle h, GemvArgs a, int rows, hipStream_t s) {
     if (g.lengths) g.lengths += r0;
     if (g.q_out) g.q_out += (size_t)r0 * a.n_heads * a.hd;
     if (g.kv) g.kv += (size_t)r0 * a.max_len * 2 * a.n_heads_kv * a.hd;
+    if (h->tune[7] > 1 && run_gemm16k<EPI>(h, g, s)) continue;
     if (h->tune[7] > 1 && run_gemm16s<EPI>(h, g, s)) continue;
     if constexpr (EPI != EPI_SILU) {
       if (tiles <= 192 && a.N % 8 == 0) {   // N = d_model: 8-row tiles so that every CU gets a workgroup

@@ -406,6 +406,7 @@ __global__ __launch_bounds__(NWV * 64) void gemm16s_kernel(GemvArgs a) {
 #pragma unroll
   for (int j = 0; j < 8; ++j) wr[j] = ld_nt16(wp[j]);
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  // one chunk in flight per thread: two or four (register sets requested further ahead) measured 1-3 % slower per step
   for (int c = 0; c < nchunks; ++c) {
     __syncthreads();                                   // the previous chunk's fragment reads are done
 #pragma unroll
@@ -498,6 +499,88 @@ __global__ __launch_bounds__(NWV * 64) void gemm16s_kernel(GemvArgs a) {
       gemv_epilogue<EPI>(a, m, rowA, rowB, b_ok, rowA >> 1, Ct[2 * pj][m], b_ok ? Ct[2 * pj + 1][m] : 0.f, resid, cs, sn, pos);
     }
   }
+}
+
+// ------------------------------------------------------------------------------------------------ small-M MFMA, K split inside the workgroup
+// Short contractions (K = 8 x 256 or 8 x 512: in_proj, out_proj) with few weight rows cannot fill the chip with
+// gemm16s_kernel's 32/64-row workgroups unless K is split over workgroups, and that combine (write-through partials,
+// ticket, read-back) is three dependent memory round trips on a launch-bound chain.  Here a workgroup owns one 16-row
+// weight tile over the whole K: its 8 waves take K/8 each, request their entire slice at once (weights as whole
+// 256-byte row pieces -> per-wave LDS -> B fragments; activations straight as A fragments, they are L2-resident), and the
+// eight partial tiles meet in LDS in wave order - one memory round trip, deterministic.  (K = 8192, fc2, in rounds of four
+// chunks per wave was measured 3 % slower per step than the split-K kernel: a 16-row tile re-reads the activations once
+// per 16 weight rows, which is as many bytes through the vector-memory pipe as the weights themselves.)
+#define ZN_G16K_NKW 8
+#define ZN_G16K_KCH 128
+template <int EPI, int NCH>      // NCH = 128-wide chunks per wave: K = 8 * 128 * NCH
+__global__ __launch_bounds__(ZN_G16K_NKW * 64) void gemm16k_kernel(GemvArgs a) {
+  static_assert(EPI != EPI_SILU, "gemm16k: row-pair epilogues only");
+  constexpr int NKW = ZN_G16K_NKW, KCH = ZN_G16K_KCH, LDW = KCH + 8, KS = KCH * NCH;
+  __shared__ __attribute__((aligned(16))) bf16_t Ws[NKW][16 * LDW];
+  __shared__ float Ct[NKW][16][17];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n = lane & 15, g = lane >> 4;
+  const int tile = blockIdx.x, K = a.K, kbeg = wave * KS;
+  // epilogue operands first (item = tid < 128: activation row m, weight-row pair pj): their round trips overlap the stream's
+  const int em = tid & 15, epj = (tid >> 4) & 7;
+  const int erowA = tile * 16 + 2 * epj, erowB = erowA + 1;
+  const bool e_on = tid < 128 && em < a.nrows && erowA < a.N, eb_ok = erowB < a.N;
+  unsigned resid = 0; int pos = 0;
+  if constexpr (EPI == EPI_RESID) {
+    if (e_on) { const size_t o = (size_t)em * a.N + erowA; resid = eb_ok ? *(const unsigned*)(a.resid + o) : (unsigned)a.resid[o]; }
+  }
+  if constexpr (EPI == EPI_ROPE_KV) { if (e_on) pos = a.lengths[em]; }
+  // weights: load i of chunk c = rows 4i .. 4i+3 of the tile, 16 lanes x 16 B = 256 contiguous bytes of one row each
+  u32x4 wr[NCH][4], xr[NCH][KCH / 32];
+  const int wsub = lane & 15, wq = lane >> 4;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = min(tile * 16 + 4 * i + wq, a.N - 1);        // clamped: never out of bounds; masked in the epilogue
+      wr[c][i] = ld_nt16(a.W + (size_t)row * K + kbeg + c * KCH + 8 * wsub);
+    }
+  {
+    const bf16_t* xp = a.x + (size_t)min(n, a.nrows - 1) * K + kbeg + 8 * g;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+      for (int st = 0; st < KCH / 32; ++st) xr[c][st] = ld16(xp + c * KCH + 32 * st);
+  }
+  float cs = 1.f, sn = 0.f;
+  if constexpr (EPI == EPI_ROPE_KV) {
+    if (e_on && erowA < (a.n_heads + a.n_heads_kv) * a.hd) {
+      const int i = (erowA % a.hd) >> 1;
+      const int p = pos < a.rope_positions ? pos : a.rope_positions - 1;
+      const float2 c2 = *(const float2*)(a.rope + ((size_t)p * (a.hd >> 1) + i) * 2);
+      cs = c2.x; sn = c2.y;
+    }
+  }
+  bf16_t* ws = &Ws[wave][0];
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *(u32x4*)(ws + (4 * i + wq) * LDW + 8 * wsub) = wr[c][i];
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");           // the region is private to the wave: its LDS ops complete in order
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int st = 0; st < KCH / 32; ++st) {
+      const u32x4 bw = *(const u32x4*)(ws + n * LDW + 32 * st + 8 * g);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(zn_bf16x8, xr[c][st]), __builtin_bit_cast(zn_bf16x8, bw), acc, 0, 0, 0);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+  // D layout: col (weight row of the tile) = lane & 15, row (activation row) = 4*(lane>>4) + reg
+#pragma unroll
+  for (int reg = 0; reg < 4; ++reg) Ct[wave][n][4 * g + reg] = acc[reg];
+  __syncthreads();
+  if (!e_on) return;
+  float vA = 0.f, vB = 0.f;
+#pragma unroll
+  for (int w = 0; w < NKW; ++w) { vA += Ct[w][2 * epj][em]; vB += Ct[w][2 * epj + 1][em]; }
+  gemv_epilogue<EPI>(a, em, erowA, erowB, eb_ok, erowA >> 1, vA, eb_ok ? vB : 0.f, resid, cs, sn, pos);
 }
 
 // ------------------------------------------------------------------------------------------------ attention
@@ -623,7 +706,7 @@ __global__ __launch_bounds__(512) void attn_pv_kernel(AttnArgs a) {
     srow[q] = a.scores + ((size_t)r * a.n_heads + kvh * G + g) * a.lcap;
     crow[q] = a.cmax + ((size_t)r * a.n_heads + kvh * G + g) * cstride;
   }
-  u32x4 vnext[NR];
+  u32x4 vnext[NR], vnextB[FUSED ? NR : 1];                // FUSED: values of even / odd blocks, requested two blocks ahead
   float scn[FUSED ? 1 : NR][GL], cmn[GL];
 #pragma unroll
   for (int i = 0; i < NR; ++i) {
@@ -671,25 +754,28 @@ __global__ __launch_bounds__(512) void attn_pv_kernel(AttnArgs a) {
     const int kq = lane / LPK, kd = lane % LPK;                      // key within a load's group, 16-B piece of its row
     const bf16_t* kbase = a.kv + (size_t)r * a.max_len * kvrow + (size_t)kvh * HD + kd * 8;
     typedef __attribute__((ext_vector_type(4))) float f32x4_t;
-    u32x4 kk[TPW][NLD];
+    // two register sets: block j+1's keys are requested as soon as the length is known (j = 0) or block j-1's set is
+    // free, one whole block ahead of their use
+    u32x4 kkA[TPW][NLD], kkB[TPW][NLD];
+    auto issue_k = [&](u32x4 (&kk)[TPW][NLD], int tb, int lim) {
 #pragma unroll
-    for (int tl = 0; tl < TPW; ++tl)                                   // block 0, before the length is known
+      for (int tl = 0; tl < TPW; ++tl)
 #pragma unroll
-      for (int i = 0; i < NLD; ++i)
-        kk[tl][i] = ld16(kbase + (size_t)min((tl * NW + wave) * 16 + KPL * i + kq, a.max_len - 1) * kvrow);
+        for (int i = 0; i < NLD; ++i)                                  // clamped, not masked: no exec branch between the loads
+          kk[tl][i] = ld16(kbase + (size_t)min(tb + (tl * NW + wave) * 16 + KPL * i + kq, lim) * kvrow);
+    };
+    issue_k(kkA, 0, a.max_len - 1);                                    // block 0, before the length is known
     __builtin_amdgcn_sched_barrier(0);
     L = Lraw + 1; nb = (L + 511) >> 9;
+    if (nb > 1) {                                                      // wave-uniform
+      issue_k(kkB, 512, L - 1);
+#pragma unroll
+      for (int i = 0; i < NR; ++i) vnextB[i] = ld16(vbase + (size_t)min(512 + i * (NW * 16) + wave * 16 + vkey, L - 1) * kvrow);
+    }
     bf16_t* kw = &s_k[wave][0];
-    for (int j = 0; j < nb; ++j) {
+    auto block_scores = [&](u32x4 (&kk)[TPW][NLD], int j) {
       float mx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
       const int tb = j * 512, tend = min(L, tb + 512);
-      if (j > 0) {
-#pragma unroll
-        for (int tl = 0; tl < TPW; ++tl)
-#pragma unroll
-          for (int i = 0; i < NLD; ++i)                                // clamped, not masked: no exec branch between the loads
-            kk[tl][i] = ld16(kbase + (size_t)min(tb + (tl * NW + wave) * 16 + KPL * i + kq, L - 1) * kvrow);
-      }
 #pragma unroll
       for (int tl = 0; tl < TPW; ++tl) {
         const int tt = tb + (tl * NW + wave) * 16;
@@ -718,6 +804,14 @@ __global__ __launch_bounds__(512) void attn_pv_kernel(AttnArgs a) {
       for (int g = 0; g < G; ++g) {
         const float m = wave_max(kg == g / 4 ? mx[g % 4] : -INFINITY);
         if (lane == 0) s_bm[j][wave][g] = m;
+      }
+    };
+    for (int j = 0; j < nb; j += 2) {
+      block_scores(kkA, j);
+      if (j + 2 < nb) issue_k(kkA, (j + 2) * 512, L - 1);
+      if (j + 1 < nb) {
+        block_scores(kkB, j + 1);
+        if (j + 3 < nb) issue_k(kkB, (j + 3) * 512, L - 1);
       }
     }
     __syncthreads();
@@ -764,14 +858,25 @@ __global__ __launch_bounds__(512) void attn_pv_kernel(AttnArgs a) {
     for (int i = 0; i < NR; ++i) {
       const int idx = i * (NW * 16) + wave * 16 + vkey;
       const bool ok = idx < nkeys;
-      vv[i] = ok ? vnext[i] : u32x4{0, 0, 0, 0};
+      if constexpr (FUSED) vv[i] = ok ? ((j & 1) ? vnextB[i] : vnext[i]) : u32x4{0, 0, 0, 0};
+      else vv[i] = ok ? vnext[i] : u32x4{0, 0, 0, 0};
 #pragma unroll
       for (int q = 0; q < GL; ++q) {
         if constexpr (FUSED) sc[i][q] = ok ? s_sc[min(vsub + 4 * q, G - 1)][t0 + idx] : 0.f;
         else sc[i][q] = ok ? scn[i][q] : 0.f;
       }
     }
-    if (!SPLIT && j + 1 < nb) {                           // next block's requests fly during this block's arithmetic
+    if (FUSED) {                                          // block j+2 into the set block j has just left
+      if (j + 2 < nb) {                                   // (uniform branches: each set is loaded in place)
+        if (j & 1) {
+#pragma unroll
+          for (int i = 0; i < NR; ++i) vnextB[i] = ld16(vbase + (size_t)min(t0 + 1024 + i * (NW * 16) + wave * 16 + vkey, L - 1) * kvrow);
+        } else {
+#pragma unroll
+          for (int i = 0; i < NR; ++i) vnext[i] = ld16(vbase + (size_t)min(t0 + 1024 + i * (NW * 16) + wave * 16 + vkey, L - 1) * kvrow);
+        }
+      }
+    } else if (!SPLIT && j + 1 < nb) {                    // next block's requests fly during this block's arithmetic
 #pragma unroll
       for (int i = 0; i < NR; ++i) {
         const int nidx = t0 + 512 + i * (NW * 16) + wave * 16 + vkey;
@@ -949,18 +1054,30 @@ struct EmbedArgs {
   bf16_t* out;                  // [2*batch or batch][d]
   int dup;                      // 1: also write row b + batch (CFG duplicate, generation_utils.py:192)
 };
+#define ZN_EMBED_MAXQ 16
 __global__ __launch_bounds__(256) void embed_kernel(EmbedArgs a) {
   const int b = blockIdx.x;
   const int col = a.col_dev ? *a.col_dev : a.col;
-  for (int k = threadIdx.x * 8; k < a.d; k += 256 * 8) {
-    float acc[8];
-    for (int i = 0; i < a.n_q; ++i) {
-      int code = a.codes[(size_t)b * a.sb + (size_t)i * a.si + col];
-      code = code < 0 ? 0 : (code >= a.vocab_embed ? a.vocab_embed - 1 : code);
-      const u32x4 v = ld16(a.tables[i] + (size_t)code * a.d + k);
-      const float f[8] = {lo_f(v.x), hi_f(v.x), lo_f(v.y), hi_f(v.y), lo_f(v.z), hi_f(v.z), lo_f(v.w), hi_f(v.w)};
+  // all codes, then all table rows, are requested before the first add (three memory round trips on the step's
+  // launch-bound tail instead of one per codebook); indices past n_q repeat the last codebook and are not added
+  int code[ZN_EMBED_MAXQ];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) acc[e] = (i == 0) ? f[e] : bfround(acc[e] + f[e]);  // python sum(): bf16 adds
+  for (int i = 0; i < ZN_EMBED_MAXQ; ++i) {
+    const int c = a.codes[(size_t)b * a.sb + (size_t)min(i, a.n_q - 1) * a.si + col];
+    code[i] = c < 0 ? 0 : (c >= a.vocab_embed ? a.vocab_embed - 1 : c);
+  }
+  for (int k = threadIdx.x * 8; k < a.d; k += 256 * 8) {
+    u32x4 v[ZN_EMBED_MAXQ];
+#pragma unroll
+    for (int i = 0; i < ZN_EMBED_MAXQ; ++i) v[i] = ld16(a.tables[min(i, a.n_q - 1)] + (size_t)code[i] * a.d + k);
+    float acc[8];
+#pragma unroll
+    for (int i = 0; i < ZN_EMBED_MAXQ; ++i) {
+      if (i < a.n_q) {
+        const float f[8] = {lo_f(v[i].x), hi_f(v[i].x), lo_f(v[i].y), hi_f(v[i].y), lo_f(v[i].z), hi_f(v[i].z), lo_f(v[i].w), hi_f(v[i].w)};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = (i == 0) ? f[e] : bfround(acc[e] + f[e]);  // python sum(): bf16 adds
+      }
     }
     u32x4 o;
     o.x = pack2(acc[0], acc[1]); o.y = pack2(acc[2], acc[3]); o.z = pack2(acc[4], acc[5]); o.w = pack2(acc[6], acc[7]);
@@ -1266,43 +1383,46 @@ struct FrameArgs {
   const int* override; // test hook: raw tokens [calls][B][n_q] replacing the sampled ones (call 0 = first frame)
   int override_calls;
 };
+#define ZN_FRAME_MAXQ 16
 __global__ __launch_bounds__(256) void frame_update_kernel(FrameArgs a) {
-  const int o = a.st->offset;
+  // 16 lanes per utterance, one per codebook: every cell, token and counter is requested at once (the per-codebook loop
+  // of the reference becomes one memory round trip); lanes of one utterance share a wave, so all of them have read the
+  // counters before lane 0 of the group rewrites them.  n_q <= 16 is checked by zn_create.
+  const int o = a.st->offset, stp = a.st->step;
   __shared__ int s_done;
   if (threadIdx.x == 0) s_done = 1;
   __syncthreads();
-  for (int b = threadIdx.x; b < a.batch; b += blockDim.x) {
+  const int cb = threadIdx.x & (ZN_FRAME_MAXQ - 1);
+  for (int b = threadIdx.x / ZN_FRAME_MAXQ; b < a.batch; b += blockDim.x / ZN_FRAME_MAXQ) {
     const int* tk = a.tokens + b * a.n_q;
-    const int call = a.first ? 0 : a.st->step + 1;
+    const int call = a.first ? 0 : stp + 1;
     if (a.override && call < a.override_calls) tk = a.override + ((size_t)call * a.batch + b) * a.n_q;
-    if (a.first) {
-      for (int cb = 0; cb < a.n_q; ++cb) {
-        int* cell = a.codes + ((size_t)b * a.n_q + cb) * a.t_total + o;
-        if (o < a.t_total && *cell == -1) *cell = tk[cb];
-      }
+    const int cbc = min(cb, a.n_q - 1);
+    const int col = a.first ? o : o + 1;
+    const bool in_range = cb < a.n_q && col < a.t_total;
+    int* cell = a.codes + ((size_t)b * a.n_q + cbc) * a.t_total + min(col, a.t_total - 1);
+    const int cur = *cell, tok = tk[cbc], tok0 = tk[0];
+    if (a.first) {                                           // model.py:423-431: plain write-where-unknown
+      if (in_range && cur == -1) *cell = tok;
       continue;
     }
     // model.py:483-497 + tensor_ops.py:155-211
     int rem = a.remaining[b];
     int stop = a.stopping[b];
-    if (tk[0] == a.eos_id) { rem = rem < a.n_q ? rem : a.n_q; stop = 1; }
+    if (tok0 == a.eos_id) { rem = rem < a.n_q ? rem : a.n_q; stop = 1; }
     int eos_idx = a.n_q - rem; if (eos_idx > a.n_q - 1) eos_idx = a.n_q - 1;
-    const int col = o + 1;
-    if (col < a.t_total) {
-      for (int cb = 0; cb < a.n_q; ++cb) {
-        int t = tk[cb];
-        if (stop && cb < eos_idx) t = a.mask_id; else if (stop && cb == eos_idx) t = a.eos_id;
-        int* cell = a.codes + ((size_t)b * a.n_q + cb) * a.t_total + col;
-        if (*cell == -1) *cell = t;                         // tensor_ops.py:42-49
-      }
+    int t = tok;
+    if (stop && cb < eos_idx) t = a.mask_id; else if (stop && cb == eos_idx) t = a.eos_id;
+    if (in_range && cur == -1) *cell = t;                    // tensor_ops.py:42-49
+    rem -= 1;                                                // tensor_ops.py:87
+    if (cb == 0) {
+      a.remaining[b] = rem; a.stopping[b] = stop;
+      if (rem > 0) atomicAnd(&s_done, 0);
     }
-    rem -= 1;                                               // tensor_ops.py:87
-    a.remaining[b] = rem; a.stopping[b] = stop;
-    if (rem > 0) atomicAnd(&s_done, 0);
   }
   __syncthreads();
   if (!a.first) {
     for (int r = threadIdx.x; r < a.rows; r += blockDim.x) a.lengths[r] += 1;   // tensor_ops.py:85-86
-    if (threadIdx.x == 0) { a.st->offset = o + 1; a.st->step += 1; a.st->all_done = s_done; }
+    if (threadIdx.x == 0) { a.st->offset = o + 1; a.st->step = stp + 1; a.st->all_done = s_done; }
   }
 }
