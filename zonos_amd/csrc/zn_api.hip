@@ -252,18 +252,18 @@ static bool run_gemm16s(zn_handle h, GemvArgs g, hipStream_t s) {
 
 // rows in (4, 16], K = 8 waves x 128 x {2, 4} and few weight rows (the LDS-staged kernel would have to split K over
 // workgroups): one 16-row tile per workgroup, K split over its waves, no cross-workgroup combine.  tune[11] = 2 disables.
-template <int EPI>
-static bool run_gemm16k(zn_handle h, const GemvArgs& g, hipStream_t s) {
-  if constexpr (EPI == EPI_SILU) return false;
-  else {
-    if (h->tune[11] == 2) return false;
-    const int per = ZN_G16K_NKW * ZN_G16K_KCH, nch = g.K / per;
-    if (g.K % per || (nch != 2 && nch != 4)) return false;
+static bool gemm16k_fits(zn_handle h, int epi, int N, int K) {
+  if (epi == EPI_SILU || h->tune[7] <= 1 || h->tune[11] == 2) return false;
+  const int per = ZN_G16K_NKW * ZN_G16K_KCH, nch = K / per;
+  if (K % per || (nch != 2 && nch != 4)) return false;
+  return (N + 15) / 16 < 1024;                                        // many rows: the 64-row workgroups fill the chip without a split
+}
+template <int PRO, int EPI>
+static void run_gemm16k(const GemvArgs& g, hipStream_t s) {
+  if constexpr (EPI != EPI_SILU) {
     const int tiles = (g.N + 15) / 16;
-    if (tiles >= 1024) return false;                                  // many rows: the 64-row workgroups fill the chip without a split
-    if (nch == 2) hipLaunchKernelGGL((gemm16k_kernel<EPI, 2>), dim3(tiles), dim3(ZN_G16K_NKW * 64), 0, s, g);
-    else hipLaunchKernelGGL((gemm16k_kernel<EPI, 4>), dim3(tiles), dim3(ZN_G16K_NKW * 64), 0, s, g);
-    return true;
+    if (g.K / (ZN_G16K_NKW * ZN_G16K_KCH) == 2) hipLaunchKernelGGL((gemm16k_kernel<EPI, 2, PRO>), dim3(tiles), dim3(ZN_G16K_NKW * 64), 0, s, g);
+    else hipLaunchKernelGGL((gemm16k_kernel<EPI, 4, PRO>), dim3(tiles), dim3(ZN_G16K_NKW * 64), 0, s, g);
   }
 }
 
@@ -283,7 +283,11 @@ static int run_gemm16(zn_handle h, GemvArgs a, int rows, hipStream_t s) {
     GemvArgs g = a;
     const int nr = rows - r0 < 16 ? rows - r0 : 16;
     g.nrows = nr;
-    if (PRO == PRO_LN) {
+    const bool k16 = gemm16k_fits(h, EPI, a.N, K);
+    // that kernel normalises its rows itself when at most one workgroup per CU repeats the statistics (in_proj: 8.7 us vs
+    // 4.8 + 6.2; the heads' 577 tiles: 21.8 vs 5.0 + 11.9)
+    const bool k16_ln = k16 && PRO == PRO_LN && tiles <= 256;
+    if (PRO == PRO_LN && !k16_ln) {
       hipLaunchKernelGGL(layernorm_kernel, dim3(nr), dim3(64), 0, s, a.x + (size_t)r0 * K, a.ln_w, a.ln_b, h->nbuf, K, a.eps);
       g.x = h->nbuf;
     } else g.x = a.x + (size_t)r0 * K;
@@ -293,7 +297,10 @@ static int run_gemm16(zn_handle h, GemvArgs a, int rows, hipStream_t s) {
     if (g.lengths) g.lengths += r0;
     if (g.q_out) g.q_out += (size_t)r0 * a.n_heads * a.hd;
     if (g.kv) g.kv += (size_t)r0 * a.max_len * 2 * a.n_heads_kv * a.hd;
-    if (h->tune[7] > 1 && run_gemm16k<EPI>(h, g, s)) continue;
+    if (k16) {
+      if (k16_ln) run_gemm16k<PRO, EPI>(g, s); else run_gemm16k<PRO_NONE, EPI>(g, s);
+      continue;
+    }
     if (h->tune[7] > 1 && run_gemm16s<EPI>(h, g, s)) continue;
     if constexpr (EPI != EPI_SILU) {
       if (tiles <= 192 && a.N % 8 == 0) {   // N = d_model: 8-row tiles so that every CU gets a workgroup

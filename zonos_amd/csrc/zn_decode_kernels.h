@@ -512,12 +512,16 @@ __global__ __launch_bounds__(NWV * 64) void gemm16s_kernel(GemvArgs a) {
 // per 16 weight rows, which is as many bytes through the vector-memory pipe as the weights themselves.)
 #define ZN_G16K_NKW 8
 #define ZN_G16K_KCH 128
-template <int EPI, int NCH>      // NCH = 128-wide chunks per wave: K = 8 * 128 * NCH
+// PRO_LN: the workgroup holds whole activation rows (as A fragments, spread over its waves), so nn.LayerNorm runs in
+// place on them - row sums through LDS in wave order, two statistics passes like layernorm_kernel - instead of as a
+// launch of its own in front (4.8 us at 16 rows).
+template <int EPI, int NCH, int PRO>      // NCH = 128-wide chunks per wave: K = 8 * 128 * NCH
 __global__ __launch_bounds__(ZN_G16K_NKW * 64) void gemm16k_kernel(GemvArgs a) {
   static_assert(EPI != EPI_SILU, "gemm16k: row-pair epilogues only");
   constexpr int NKW = ZN_G16K_NKW, KCH = ZN_G16K_KCH, LDW = KCH + 8, KS = KCH * NCH;
   __shared__ __attribute__((aligned(16))) bf16_t Ws[NKW][16 * LDW];
   __shared__ float Ct[NKW][16][17];
+  __shared__ float s_red[2][NKW][16];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int n = lane & 15, g = lane >> 4;
   const int tile = blockIdx.x, K = a.K, kbeg = wave * KS;
@@ -530,8 +534,27 @@ __global__ __launch_bounds__(ZN_G16K_NKW * 64) void gemm16k_kernel(GemvArgs a) {
     if (e_on) { const size_t o = (size_t)em * a.N + erowA; resid = eb_ok ? *(const unsigned*)(a.resid + o) : (unsigned)a.resid[o]; }
   }
   if constexpr (EPI == EPI_ROPE_KV) { if (e_on) pos = a.lengths[em]; }
-  // weights: load i of chunk c = rows 4i .. 4i+3 of the tile, 16 lanes x 16 B = 256 contiguous bytes of one row each
+  // activations (and LayerNorm parameters) are requested first: requests return in order, and the statistics passes then
+  // run while the weights are still on their way
   u32x4 wr[NCH][4], xr[NCH][KCH / 32];
+  u32x4 lw[PRO == PRO_LN ? NCH : 1][KCH / 32], lb[PRO == PRO_LN ? NCH : 1][KCH / 32];
+  {
+    const bf16_t* xp = a.x + (size_t)min(n, a.nrows - 1) * K + kbeg + 8 * g;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+      for (int st = 0; st < KCH / 32; ++st) xr[c][st] = ld16(xp + c * KCH + 32 * st);
+    if constexpr (PRO == PRO_LN) {
+#pragma unroll
+      for (int c = 0; c < NCH; ++c)
+#pragma unroll
+        for (int st = 0; st < KCH / 32; ++st) {
+          lw[c][st] = ld16(a.ln_w + kbeg + 8 * g + c * KCH + 32 * st);
+          lb[c][st] = ld16(a.ln_b + kbeg + 8 * g + c * KCH + 32 * st);
+        }
+    }
+  }
+  // weights: load i of chunk c = rows 4i .. 4i+3 of the tile, 16 lanes x 16 B = 256 contiguous bytes of one row each
   const int wsub = lane & 15, wq = lane >> 4;
 #pragma unroll
   for (int c = 0; c < NCH; ++c)
@@ -540,13 +563,6 @@ __global__ __launch_bounds__(ZN_G16K_NKW * 64) void gemm16k_kernel(GemvArgs a) {
       const int row = min(tile * 16 + 4 * i + wq, a.N - 1);        // clamped: never out of bounds; masked in the epilogue
       wr[c][i] = ld_nt16(a.W + (size_t)row * K + kbeg + c * KCH + 8 * wsub);
     }
-  {
-    const bf16_t* xp = a.x + (size_t)min(n, a.nrows - 1) * K + kbeg + 8 * g;
-#pragma unroll
-    for (int c = 0; c < NCH; ++c)
-#pragma unroll
-      for (int st = 0; st < KCH / 32; ++st) xr[c][st] = ld16(xp + c * KCH + 32 * st);
-  }
   float cs = 1.f, sn = 0.f;
   if constexpr (EPI == EPI_ROPE_KV) {
     if (e_on && erowA < (a.n_heads + a.n_heads_kv) * a.hd) {
@@ -555,6 +571,55 @@ __global__ __launch_bounds__(ZN_G16K_NKW * 64) void gemm16k_kernel(GemvArgs a) {
       const float2 c2 = *(const float2*)(a.rope + ((size_t)p * (a.hd >> 1) + i) * 2);
       cs = c2.x; sn = c2.y;
     }
+  }
+  if constexpr (PRO == PRO_LN) {
+    // lane (n, g) holds 32 * NCH values of activation row n; the row's other values sit in lanes n + 16 q and in the
+    // other waves.  fp32 statistics (nn.LayerNorm): mean, then the centred second moment, each summed lane -> row group
+    // -> waves in a fixed order.
+    float ps = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+      for (int st = 0; st < KCH / 32; ++st) {
+        const u32x4 v = xr[c][st];
+        ps += lo_f(v.x) + hi_f(v.x) + lo_f(v.y) + hi_f(v.y) + lo_f(v.z) + hi_f(v.z) + lo_f(v.w) + hi_f(v.w);
+      }
+    ps += __shfl_xor(ps, 16); ps += __shfl_xor(ps, 32);
+    if (g == 0) s_red[0][wave][n] = ps;
+    __syncthreads();
+    float tot = 0.f;
+#pragma unroll
+    for (int w = 0; w < NKW; ++w) tot += s_red[0][w][n];
+    const float mean = tot / (float)K;
+    float pss = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+      for (int st = 0; st < KCH / 32; ++st) {
+        const u32x4 v = xr[c][st];
+        const float f[8] = {lo_f(v.x), hi_f(v.x), lo_f(v.y), hi_f(v.y), lo_f(v.z), hi_f(v.z), lo_f(v.w), hi_f(v.w)};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const float dd = f[e] - mean; pss += dd * dd; }
+      }
+    pss += __shfl_xor(pss, 16); pss += __shfl_xor(pss, 32);
+    if (g == 0) s_red[1][wave][n] = pss;
+    __syncthreads();
+    float tot2 = 0.f;
+#pragma unroll
+    for (int w = 0; w < NKW; ++w) tot2 += s_red[1][w][n];
+    const float rstd = 1.0f / sqrtf(tot2 / (float)K + a.eps);
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+      for (int st = 0; st < KCH / 32; ++st) {
+        const u32x4 v = xr[c][st], gw = lw[c][st], gb = lb[c][st];
+        u32x4 o;
+        o.x = pack2((lo_f(v.x) - mean) * rstd * lo_f(gw.x) + lo_f(gb.x), (hi_f(v.x) - mean) * rstd * hi_f(gw.x) + hi_f(gb.x));
+        o.y = pack2((lo_f(v.y) - mean) * rstd * lo_f(gw.y) + lo_f(gb.y), (hi_f(v.y) - mean) * rstd * hi_f(gw.y) + hi_f(gb.y));
+        o.z = pack2((lo_f(v.z) - mean) * rstd * lo_f(gw.z) + lo_f(gb.z), (hi_f(v.z) - mean) * rstd * hi_f(gw.z) + hi_f(gb.z));
+        o.w = pack2((lo_f(v.w) - mean) * rstd * lo_f(gw.w) + lo_f(gb.w), (hi_f(v.w) - mean) * rstd * hi_f(gw.w) + hi_f(gb.w));
+        xr[c][st] = o;
+      }
   }
   bf16_t* ws = &Ws[wave][0];
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
