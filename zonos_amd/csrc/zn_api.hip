@@ -297,6 +297,7 @@ static int run_gemm16(zn_handle h, GemvArgs a, int rows, hipStream_t s) {
     if (g.lengths) g.lengths += r0;
     if (g.q_out) g.q_out += (size_t)r0 * a.n_heads * a.hd;
     if (g.kv) g.kv += (size_t)r0 * a.max_len * 2 * a.n_heads_kv * a.hd;
+    if (g.conv_state) { g.conv_state += (size_t)r0 * a.conv_dim * 4; g.xbc += (size_t)r0 * a.conv_dim; }
     if (k16) {
       if (k16_ln) run_gemm16k<PRO, EPI>(g, s); else run_gemm16k<PRO_NONE, EPI>(g, s);
       continue;
@@ -346,6 +347,7 @@ static int run_gemv(zn_handle h, GemvArgs a, int rows, int target_blocks, hipStr
     if (g.lengths) g.lengths += r0;
     if (g.q_out) g.q_out += (size_t)r0 * a.n_heads * a.hd;
     if (g.kv) g.kv += (size_t)r0 * a.max_len * 2 * a.n_heads_kv * a.hd;
+    if (g.conv_state) { g.conv_state += (size_t)r0 * a.conv_dim * 4; g.xbc += (size_t)r0 * a.conv_dim; }
     if (launch_gemv_rows<PRO, EPI>(g, nr, ks, nch, blocks, full, s) != 0) ZN_FAIL(h, ZN_ERR_UNSUPPORTED, "gemv: no kernel for ks=%d nch=%d", ks, nch);
   }
   return ZN_OK;
@@ -479,8 +481,11 @@ static int mamba_mixer(zn_handle h, int li, const bf16_t* n, void* state, bf16_t
   int rc;
   {
     GemvArgs a{};
+    // in_proj with the conv window update + SiLU of its xBC rows in the epilogue (causal_conv1d_update; one launch less)
     a.W = (const bf16_t*)lw.m_in_proj; a.N = h->m_d_in_proj; a.K = c.d_model; a.x = n; a.out = h->m_zx;
-    if ((rc = run_gemv<PRO_NONE, EPI_STORE>(h, a, rows, (h->m_d_in_proj / 2 + 3) / 4, s))) return rc;
+    a.conv_state = (bf16_t*)state; a.conv_w = (const bf16_t*)lw.m_conv_w; a.conv_b = (const bf16_t*)lw.m_conv_b; a.xbc = h->m_xbc;
+    a.d_inner = c.m_d_inner; a.conv_dim = h->m_conv_dim;
+    if ((rc = run_gemv<PRO_NONE, EPI_MAMBA>(h, a, rows, (h->m_d_in_proj / 2 + 3) / 4, s))) return rc;
   }
   size_t conv_bytes = 0;   // the state buffer is laid out for exactly `rows` rows (zn_mamba_state_bytes_per_layer)
   (void)zn_mamba_state_bytes_per_layer(&c, rows, &conv_bytes);
@@ -491,7 +496,6 @@ static int mamba_mixer(zn_handle h, int li, const bf16_t* n, void* state, bf16_t
   m.norm_w = (const bf16_t*)lw.m_norm_w; m.xbc = h->m_xbc; m.y = h->m_y; m.g = h->m_g;
   m.d_inner = c.m_d_inner; m.conv_dim = h->m_conv_dim; m.nheads = h->m_nheads; m.d_state = c.m_d_state; m.ngroups = c.m_ngroups;
   m.d_in_proj = h->m_d_in_proj; m.eps = c.norm_eps;
-  hipLaunchKernelGGL(mamba_conv_kernel, dim3((h->m_conv_dim + 255) / 256, rows), dim3(256), 0, s, m);
   m.rows = rows;
   if (c.m_d_state == 128) hipLaunchKernelGGL((mamba_ssm_kernel<128, 2>), dim3(h->m_nheads, (rows + 1) / 2), dim3(256), 0, s, m);
   else hipLaunchKernelGGL((mamba_ssm_kernel<64, 2>), dim3(h->m_nheads, (rows + 1) / 2), dim3(256), 0, s, m);

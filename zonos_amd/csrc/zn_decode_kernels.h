@@ -8,7 +8,7 @@
 
 // ------------------------------------------------------------------------------------------------ GEMV
 enum { PRO_NONE = 0, PRO_LN = 1 };
-enum { EPI_STORE = 0, EPI_RESID = 1, EPI_SILU = 2, EPI_ROPE_KV = 3, EPI_F32 = 4 };
+enum { EPI_STORE = 0, EPI_RESID = 1, EPI_SILU = 2, EPI_ROPE_KV = 3, EPI_F32 = 4, EPI_MAMBA = 5 };
 
 struct GemvArgs {
   const bf16_t* W;  // [N][K]
@@ -35,13 +35,44 @@ struct GemvArgs {
   float* part;
   int* tickets;
   int ksplit;
+  // EPI_MAMBA (Mamba2 in_proj, out = [z | xBC | dt] bf16 [rows][N]): weight rows [d_inner, d_inner + conv_dim) also go
+  // through the causal-conv window update (causal_conv1d_update, width 4) + SiLU
+  bf16_t* conv_state;      // [rows][conv_dim][4]
+  const bf16_t* conv_w;    // [conv_dim][4]
+  const bf16_t* conv_b;    // [conv_dim]
+  bf16_t* xbc;             // [rows][conv_dim] activated conv output
+  int d_inner, conv_dim;
 };
+
+// EPI_MAMBA operands of activation row r and the weight-row pair starting at rowA (both rows lie in the same segment:
+// d_inner and conv_dim are even): window state and taps of the two channels, their biases.  Requested ahead of the epilogue.
+ZN_DEVINL void mamba_epi_operands(const GemvArgs& a, int r, int rowA, unsigned& cb, u32x4& cst, u32x4& cw) {
+  const int c = rowA - a.d_inner;
+  if (c >= 0 && c < a.conv_dim) {
+    cst = ld16(a.conv_state + ((size_t)r * a.conv_dim + c) * 4);
+    cw = ld16(a.conv_w + (size_t)c * 4);
+    cb = *(const unsigned*)(a.conv_b + c);
+  }
+}
+// one channel of causal_conv1d_update: window (e0 e1 | e2 e3) <- (e1 e2 | e3 x); out = silu(bias + sum_i w[i] * win[i]) with
+// separately rounded fp32 multiplies and adds in tap order
+ZN_DEVINL float mamba_conv_channel(unsigned& s0, unsigned& s1, unsigned w0, unsigned w1, float bias, bf16_t xn) {
+  const float e1 = hi_f(s0), e2 = lo_f(s1), e3 = hi_f(s1), e4 = bf2f(xn);
+  s0 = (s0 >> 16) | (s1 << 16);
+  s1 = (s1 >> 16) | ((unsigned)xn << 16);
+  float acc = bias;
+  acc = __fadd_rn(acc, __fmul_rn(lo_f(w0), e1));
+  acc = __fadd_rn(acc, __fmul_rn(hi_f(w0), e2));
+  acc = __fadd_rn(acc, __fmul_rn(lo_f(w1), e3));
+  acc = __fadd_rn(acc, __fmul_rn(hi_f(w1), e4));
+  return acc / (1.0f + expf(-acc));
+}
 
 // Fused epilogues shared by the GEMV (rows <= 4) and the small-M MFMA kernel (rows <= 16): finishes activation row r
 // for the weight-row pair (rowA, rowB) of work unit u.
 template <int EPI>
 ZN_DEVINL void gemv_epilogue(const GemvArgs& a, int r, int rowA, int rowB, bool b_ok, int u, float vA, float vB, unsigned resid, float cs,
-                             float sn, int pos) {
+                             float sn, int pos, u32x4 cst = u32x4{0, 0, 0, 0}, u32x4 cw = u32x4{0, 0, 0, 0}) {
   if constexpr (EPI == EPI_STORE) {
     if (a.bias) { vA += bf2f(a.bias[rowA]); if (b_ok) vB += bf2f(a.bias[rowB]); }
     if (b_ok) *(unsigned*)(a.out + (size_t)r * a.N + rowA) = pack2(vA, vB);
@@ -59,6 +90,18 @@ ZN_DEVINL void gemv_epilogue(const GemvArgs& a, int r, int rowA, int rowB, bool 
     const float y = bfround(vA), g = bfround(vB);
     const float s = bfround(g / (1.0f + expf(-g)));
     a.out[(size_t)r * (a.N >> 1) + u] = f2bf(y * s);
+  } else if constexpr (EPI == EPI_MAMBA) {
+    // Mamba2.step: zxbcdt = in_proj(x) (bf16), then xBC through the conv window; z and dt are consumed as stored
+    const bf16_t xa = f2bf(vA), xb = f2bf(vB);
+    *(unsigned*)(a.out + (size_t)r * a.N + rowA) = (unsigned)xa | ((unsigned)xb << 16);
+    const int c = rowA - a.d_inner;
+    if (c >= 0 && c < a.conv_dim) {
+      unsigned s0 = cst.x, s1 = cst.y, s2 = cst.z, s3 = cst.w;
+      const float o0 = mamba_conv_channel(s0, s1, cw.x, cw.y, lo_f(resid), xa);
+      const float o1 = mamba_conv_channel(s2, s3, cw.z, cw.w, hi_f(resid), xb);
+      *(u32x4*)(a.conv_state + ((size_t)r * a.conv_dim + c) * 4) = u32x4{s0, s1, s2, s3};
+      *(unsigned*)(a.xbc + (size_t)r * a.conv_dim + c) = pack2(o0, o1);
+    }
   } else if constexpr (EPI == EPI_ROPE_KV) {
     // split q|k|v (_torch.py:399-405), interleaved-pair RoPE in fp32 (_torch.py:57-68), KV append (:105-106)
     const int hd = a.hd, nq = a.n_heads * hd, nk = a.n_heads_kv * hd;
@@ -80,6 +123,7 @@ template <int NCH> struct WTile {
   u32x4 a[NCH], b[NCH];
   unsigned resid;   // EPI_RESID: this lane's (row = lane) residual pair, requested with the weights so that the
   float cs, sn;     // EPI_ROPE_KV: cos/sin      epilogue never has to wait behind the next unit's prefetch
+  u32x4 cst, cw;    // EPI_MAMBA: conv window state and taps of the pair's two channels (biases in resid)
 };
 
 template <int NCH, int KSPLIT, int EPI, bool FULL>
@@ -105,7 +149,9 @@ ZN_DEVINL void gemv_load_unit(const GemvArgs& a, int u, int lane, int kw, int kb
     }
   }
   t.resid = 0; t.cs = 1.f; t.sn = 0.f;
+  if constexpr (EPI == EPI_MAMBA) { t.cst = u32x4{0, 0, 0, 0}; t.cw = u32x4{0, 0, 0, 0}; }
   if (u_ok && lane < a.nrows) {
+    if constexpr (EPI == EPI_MAMBA) mamba_epi_operands(a, lane, rowA, t.resid, t.cst, t.cw);
     if constexpr (EPI == EPI_RESID) {
       const size_t o = (size_t)lane * a.N + rowA;
       t.resid = b_ok ? *(const unsigned*)(a.resid + o) : (unsigned)a.resid[o];
@@ -257,7 +303,8 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs a) {
 #pragma unroll
     for (int r = 0; r < R; ++r) if (lane == r) { vA = accA[r]; vB = accB[r]; }
     if (lane >= (FULL ? R : a.nrows)) continue;
-    gemv_epilogue<EPI>(a, lane, rowA, rowB, b_ok, u, vA, vB, cur.resid, cur.cs, cur.sn, pos);
+    if constexpr (EPI == EPI_MAMBA) gemv_epilogue<EPI>(a, lane, rowA, rowB, b_ok, u, vA, vB, cur.resid, cur.cs, cur.sn, pos, cur.cst, cur.cw);
+    else gemv_epilogue<EPI>(a, lane, rowA, rowB, b_ok, u, vA, vB, cur.resid, cur.cs, cur.sn, pos);
   }
 }
 
@@ -343,7 +390,11 @@ __global__ __launch_bounds__(NW * 64) void gemm16_kernel(GemvArgs a) {
         cs = c2.x; sn = c2.y;
       }
     }
-    gemv_epilogue<EPI>(a, m, rowA, rowB, b_ok, rowA >> 1, vA, vB, resid, cs, sn, pos);
+    if constexpr (EPI == EPI_MAMBA) {
+      u32x4 cst = u32x4{0, 0, 0, 0}, cw = u32x4{0, 0, 0, 0};
+      mamba_epi_operands(a, m, rowA, resid, cst, cw);
+      gemv_epilogue<EPI>(a, m, rowA, rowB, b_ok, rowA >> 1, vA, vB, resid, cs, sn, pos, cst, cw);
+    } else gemv_epilogue<EPI>(a, m, rowA, rowB, b_ok, rowA >> 1, vA, vB, resid, cs, sn, pos);
   }
 }
 
@@ -496,7 +547,11 @@ __global__ __launch_bounds__(NWV * 64) void gemm16s_kernel(GemvArgs a) {
           cs = c2.x; sn = c2.y;
         }
       }
-      gemv_epilogue<EPI>(a, m, rowA, rowB, b_ok, rowA >> 1, Ct[2 * pj][m], b_ok ? Ct[2 * pj + 1][m] : 0.f, resid, cs, sn, pos);
+      if constexpr (EPI == EPI_MAMBA) {
+        u32x4 cst = u32x4{0, 0, 0, 0}, cw = u32x4{0, 0, 0, 0};
+        mamba_epi_operands(a, m, rowA, resid, cst, cw);
+        gemv_epilogue<EPI>(a, m, rowA, rowB, b_ok, rowA >> 1, Ct[2 * pj][m], b_ok ? Ct[2 * pj + 1][m] : 0.f, resid, cs, sn, pos, cst, cw);
+      } else gemv_epilogue<EPI>(a, m, rowA, rowB, b_ok, rowA >> 1, Ct[2 * pj][m], b_ok ? Ct[2 * pj + 1][m] : 0.f, resid, cs, sn, pos);
     }
   }
 }
@@ -534,6 +589,8 @@ __global__ __launch_bounds__(ZN_G16K_NKW * 64) void gemm16k_kernel(GemvArgs a) {
     if (e_on) { const size_t o = (size_t)em * a.N + erowA; resid = eb_ok ? *(const unsigned*)(a.resid + o) : (unsigned)a.resid[o]; }
   }
   if constexpr (EPI == EPI_ROPE_KV) { if (e_on) pos = a.lengths[em]; }
+  u32x4 cst = u32x4{0, 0, 0, 0}, cw = u32x4{0, 0, 0, 0};
+  if constexpr (EPI == EPI_MAMBA) { if (e_on) mamba_epi_operands(a, em, erowA, resid, cst, cw); }
   // activations (and LayerNorm parameters) are requested first: requests return in order, and the statistics passes then
   // run while the weights are still on their way
   u32x4 wr[NCH][4], xr[NCH][KCH / 32];
@@ -645,7 +702,7 @@ __global__ __launch_bounds__(ZN_G16K_NKW * 64) void gemm16k_kernel(GemvArgs a) {
   float vA = 0.f, vB = 0.f;
 #pragma unroll
   for (int w = 0; w < NKW; ++w) { vA += Ct[w][2 * epj][em]; vB += Ct[w][2 * epj + 1][em]; }
-  gemv_epilogue<EPI>(a, em, erowA, erowB, eb_ok, erowA >> 1, vA, eb_ok ? vB : 0.f, resid, cs, sn, pos);
+  gemv_epilogue<EPI>(a, em, erowA, erowB, eb_ok, erowA >> 1, vA, eb_ok ? vB : 0.f, resid, cs, sn, pos, cst, cw);
 }
 
 // ------------------------------------------------------------------------------------------------ attention
