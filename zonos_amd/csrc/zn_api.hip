@@ -31,6 +31,7 @@ struct zn_handle_s {
   bf16_t *x = nullptr, *q = nullptr, *o1 = nullptr, *mbuf = nullptr, *nbuf = nullptr;
   // hybrid backbone (arch 1): residual stream, normalised activations, Mamba2 intermediates
   bf16_t *res = nullptr, *hn = nullptr, *m_zx = nullptr, *m_xbc = nullptr, *m_y = nullptr, *m_g = nullptr;
+  float* m_vg = nullptr;            // [rows][m_d_inner] fp32 y * silu(z) (mamba_ssm_kernel -> out_proj prologue)
   int m_nheads = 0, m_conv_dim = 0, m_d_in_proj = 0;
   float* g16_part = nullptr;   // gemm16s_kernel: split-K partial tiles
   int* g16_tickets = nullptr;
@@ -112,7 +113,7 @@ static void free_graph(zn_handle h) {
 extern "C" int zn_destroy(zn_handle h) {
   if (!h) return ZN_OK;
   free_graph(h);
-  void* ptrs[] = {h->emb_tables_dev, h->x, h->q, h->o1, h->mbuf, h->nbuf, h->logits_raw, h->last_logits, h->tok_raw, h->scores, h->cmax, h->pv_part, h->pv_tickets, h->pf_x, h->pf_n, h->pf_qkv, h->pf_a, h->pf_u, h->pf_m, h->st, h->remaining, h->stopping, h->res, h->hn, h->m_zx, h->m_xbc, h->m_y, h->m_g, h->g16_part, h->g16_tickets};
+  void* ptrs[] = {h->emb_tables_dev, h->x, h->q, h->o1, h->mbuf, h->nbuf, h->logits_raw, h->last_logits, h->tok_raw, h->scores, h->cmax, h->pv_part, h->pv_tickets, h->pf_x, h->pf_n, h->pf_qkv, h->pf_a, h->pf_u, h->pf_m, h->st, h->remaining, h->stopping, h->res, h->hn, h->m_zx, h->m_xbc, h->m_y, h->m_g, h->m_vg, h->g16_part, h->g16_tickets};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (h->done_host) (void)hipHostFree(h->done_host);
   if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
@@ -183,6 +184,7 @@ extern "C" int zn_create(const zn_config* cfg, const zn_weights* w, int32_t max_
     ZC(hipMalloc(&h->m_zx, R * h->m_d_in_proj * 2));
     ZC(hipMalloc(&h->m_xbc, R * h->m_conv_dim * 2));
     ZC(hipMalloc(&h->m_y, R * c.m_d_inner * 2));
+    ZC(hipMalloc(&h->m_vg, R * c.m_d_inner * sizeof(float)));
     ZC(hipMalloc(&h->m_g, R * c.m_d_inner * 2));
   }
 #undef ZC
@@ -269,6 +271,8 @@ static void run_gemm16k(const GemvArgs& g, hipStream_t s) {
 
 template <int PRO, int EPI>
 static int run_gemm16(zn_handle h, GemvArgs a, int rows, hipStream_t s) {
+  if constexpr (PRO == PRO_GATED) ZN_FAIL(h, ZN_ERR_UNSUPPORTED, "gated-norm prologue: at most 4 rows (got %d)", rows);
+  else {
   const int K = a.K;
   // few weight-row tiles (N = d_model: 128 workgroups) -> more waves per workgroup so that every CU still keeps enough
   // loads in flight
@@ -317,6 +321,7 @@ static int run_gemm16(zn_handle h, GemvArgs a, int rows, hipStream_t s) {
     else hipLaunchKernelGGL((gemm16_kernel<4, EPI>), dim3(tiles), dim3(256), 0, s, g);
   }
   return ZN_OK;
+  }
 }
 
 template <int PRO, int EPI>
@@ -497,15 +502,23 @@ static int mamba_mixer(zn_handle h, int li, const bf16_t* n, void* state, bf16_t
   m.d_inner = c.m_d_inner; m.conv_dim = h->m_conv_dim; m.nheads = h->m_nheads; m.d_state = c.m_d_state; m.ngroups = c.m_ngroups;
   m.d_in_proj = h->m_d_in_proj; m.eps = c.norm_eps;
   m.rows = rows;
+  // RMSNormGated: up to 4 rows (the GEMV, whose waves hold whole rows) the gate product leaves the state-update kernel
+  // in fp32 and the row statistic + weight run as the prologue of out_proj (one launch less; batch-1 step 1.28 -> 1.17 ms);
+  // more rows, or several norm groups: a launch of its own (at 16 rows the prologue's fp32 fragment loads in each of the
+  // 128 workgroups cost more than the launch: 1.92 -> 2.14 ms, measured)
+  const bool gated_pro = c.m_ngroups == 1 && c.m_d_inner % 8 == 0 && rows <= 4 && c.m_d_inner <= 4096;
+  m.vg = gated_pro ? h->m_vg : nullptr;
   if (c.m_d_state == 128) hipLaunchKernelGGL((mamba_ssm_kernel<128, 2>), dim3(h->m_nheads, (rows + 1) / 2), dim3(256), 0, s, m);
   else hipLaunchKernelGGL((mamba_ssm_kernel<64, 2>), dim3(h->m_nheads, (rows + 1) / 2), dim3(256), 0, s, m);
-  hipLaunchKernelGGL(mamba_gated_norm_kernel, dim3(c.m_ngroups, rows), dim3(256), 0, s, m);
-  {
-    GemvArgs a{};
-    a.W = (const bf16_t*)lw.m_out_proj; a.N = c.d_model; a.K = c.m_d_inner; a.x = h->m_g; a.out = out;
-    if ((rc = run_gemv<PRO_NONE, EPI_STORE>(h, a, rows, h->tune[3], s))) return rc;
+  GemvArgs o{};
+  o.W = (const bf16_t*)lw.m_out_proj; o.N = c.d_model; o.K = c.m_d_inner; o.out = out;
+  if (gated_pro) {
+    o.gv = h->m_vg; o.ln_w = (const bf16_t*)lw.m_norm_w; o.eps = c.norm_eps;
+    return run_gemv<PRO_GATED, EPI_STORE>(h, o, rows, h->tune[3], s);
   }
-  return ZN_OK;
+  hipLaunchKernelGGL(mamba_gated_norm_kernel, dim3(c.m_ngroups, rows), dim3(256), 0, s, m);
+  o.x = h->m_g;
+  return run_gemv<PRO_NONE, EPI_STORE>(h, o, rows, h->tune[3], s);
 }
 
 // One token through hybrid layer li (mamba_ssm Block, fused_add_norm): hidden h->x / residual h->res in, same out.
@@ -514,6 +527,8 @@ static int hybrid_layer(zn_handle h, int li, void* cache, int max_len, const int
   const zn_layer_weights& lw = h->layers[li];
   const int d = c.d_model, hd = h->hd, nq = c.n_heads * hd, nkv = c.n_heads_kv * hd;
   int rc;
+  // (the add + LayerNorm as a prologue of the GEMV that consumes it - every workgroup repeating it, the residual
+  // ping-ponging between two buffers - was measured slower than this launch: batch-1 step 1.17 -> 1.24 ms)
   launch_add_ln(h->x, h->res, li > 0, 1, lw.norm_w, lw.norm_b, h->hn, rows, d, c.norm_eps, s);
   if (lw.kind == 1) return mamba_mixer(h, li, h->hn, cache, h->x, rows, s);
   {  // MHA: in_proj -> split -> interleaved RoPE(q,k) -> KV append

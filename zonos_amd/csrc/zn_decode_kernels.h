@@ -7,7 +7,7 @@
 #include "zn_common.h"
 
 // ------------------------------------------------------------------------------------------------ GEMV
-enum { PRO_NONE = 0, PRO_LN = 1 };
+enum { PRO_NONE = 0, PRO_LN = 1, PRO_GATED = 2 };
 enum { EPI_STORE = 0, EPI_RESID = 1, EPI_SILU = 2, EPI_ROPE_KV = 3, EPI_F32 = 4, EPI_MAMBA = 5 };
 
 struct GemvArgs {
@@ -19,6 +19,8 @@ struct GemvArgs {
   const bf16_t* x;  // bf16 [rows][K]
   const bf16_t *ln_w, *ln_b;
   float eps;
+  const float* gv;     // PRO_GATED (Mamba2 RMSNormGated, one group): fp32 [rows][K] gated values y * silu(z) in place of x;
+                       // the prologue adds the row's RMS statistic and the weight ln_w
   const int* lengths;  // int32 [rows]: keys already in the cache (position of the new token)
   int hd, n_heads;
   // epilogue
@@ -186,22 +188,36 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs a) {
   // unit's weights (they do not depend on the activations), then pin that order; the prologue then waits only for the
   // former while the HBM stream is already in flight.
   u32x4 xr[NCH][R];
-  u32x4 lng[PRO == PRO_LN ? NCH : 1], lnb[PRO == PRO_LN ? NCH : 1];
+  u32x4 lng[PRO != PRO_NONE ? NCH : 1], lnb[PRO == PRO_LN ? NCH : 1];
+  u32x4 zr[PRO == PRO_GATED ? NCH : 1][R];
 #pragma unroll
   for (int c = 0; c < NCH; ++c) {
     const int k = (c * 64 + lane) * 8;
     const bool kv_ok = FULL || k < kw;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-      if constexpr (FULL) xr[c][r] = ld16(a.x + (size_t)r * K + kbase + k);
-      else {
-        xr[c][r] = u32x4{0, 0, 0, 0};
-        if (kv_ok && r < a.nrows) xr[c][r] = ld16(a.x + (size_t)r * K + kbase + k);
+      if constexpr (PRO != PRO_GATED) {
+        if constexpr (FULL) xr[c][r] = ld16(a.x + (size_t)r * K + kbase + k);
+        else {
+          xr[c][r] = u32x4{0, 0, 0, 0};
+          if (kv_ok && r < a.nrows) xr[c][r] = ld16(a.x + (size_t)r * K + kbase + k);
+        }
+      }
+      if constexpr (PRO == PRO_GATED) {                    // eight fp32 values: xr = first four, zr = last four
+        if constexpr (FULL) { xr[c][r] = ld16(a.gv + (size_t)r * K + k); zr[c][r] = ld16(a.gv + (size_t)r * K + k + 4); }
+        else {
+          xr[c][r] = u32x4{0, 0, 0, 0}; zr[c][r] = u32x4{0, 0, 0, 0};
+          if (kv_ok && r < a.nrows) { xr[c][r] = ld16(a.gv + (size_t)r * K + k); zr[c][r] = ld16(a.gv + (size_t)r * K + k + 4); }
+        }
       }
     }
     if constexpr (PRO == PRO_LN) {
       lng[c] = u32x4{0, 0, 0, 0}; lnb[c] = u32x4{0, 0, 0, 0};
       if (kv_ok) { lng[c] = ld16(a.ln_w + k); lnb[c] = ld16(a.ln_b + k); }
+    }
+    if constexpr (PRO == PRO_GATED) {
+      lng[c] = u32x4{0, 0, 0, 0};
+      if (kv_ok) lng[c] = ld16(a.ln_w + k);
     }
   }
   WTile<NCH> wt;
@@ -255,6 +271,43 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs a) {
           o.w = pack2((lo_f(v.w) - m) * q * lo_f(g.w) + lo_f(b.w), (hi_f(v.w) - m) * q * hi_f(g.w) + hi_f(b.w));
           xr[c][r] = o;
         }
+      }
+    }
+  }
+
+  if constexpr (PRO == PRO_GATED) {
+    // mamba_ssm RMSNormGated(norm_before_gate=False), one group: v = y * silu(z) arrives in fp32 (mamba_ssm_kernel);
+    // out = bf16(v * rstd * w) with rstd from the mean of v^2 over the row.  KSPLIT == 1: every wave holds whole rows.
+    const float invK = 1.0f / (float)K;
+    float ss[R], rstd[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      ss[r] = 0.f;
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        const u32x4 va = xr[c][r], vb = zr[c][r];
+        const float v[8] = {__uint_as_float(va.x), __uint_as_float(va.y), __uint_as_float(va.z), __uint_as_float(va.w),
+                            __uint_as_float(vb.x), __uint_as_float(vb.y), __uint_as_float(vb.z), __uint_as_float(vb.w)};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ss[r] += v[e] * v[e];
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) rstd[r] = 1.0f / sqrtf(wave_sum(ss[r]) * invK + a.eps);
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const u32x4 g = lng[c];
+      const float wf[8] = {lo_f(g.x), hi_f(g.x), lo_f(g.y), hi_f(g.y), lo_f(g.z), hi_f(g.z), lo_f(g.w), hi_f(g.w)};
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const u32x4 va = xr[c][r], vb = zr[c][r];
+        const float q = rstd[r];
+        u32x4 o;
+        o.x = pack2(__fmul_rn(__fmul_rn(__uint_as_float(va.x), q), wf[0]), __fmul_rn(__fmul_rn(__uint_as_float(va.y), q), wf[1]));
+        o.y = pack2(__fmul_rn(__fmul_rn(__uint_as_float(va.z), q), wf[2]), __fmul_rn(__fmul_rn(__uint_as_float(va.w), q), wf[3]));
+        o.z = pack2(__fmul_rn(__fmul_rn(__uint_as_float(vb.x), q), wf[4]), __fmul_rn(__fmul_rn(__uint_as_float(vb.y), q), wf[5]));
+        o.w = pack2(__fmul_rn(__fmul_rn(__uint_as_float(vb.z), q), wf[6]), __fmul_rn(__fmul_rn(__uint_as_float(vb.w), q), wf[7]));
+        xr[c][r] = o;
       }
     }
   }
@@ -573,6 +626,7 @@ __global__ __launch_bounds__(NWV * 64) void gemm16s_kernel(GemvArgs a) {
 template <int EPI, int NCH, int PRO>      // NCH = 128-wide chunks per wave: K = 8 * 128 * NCH
 __global__ __launch_bounds__(ZN_G16K_NKW * 64) void gemm16k_kernel(GemvArgs a) {
   static_assert(EPI != EPI_SILU, "gemm16k: row-pair epilogues only");
+  static_assert(PRO == PRO_NONE || PRO == PRO_LN, "gemm16k: LayerNorm is the only fused prologue");
   constexpr int NKW = ZN_G16K_NKW, KCH = ZN_G16K_KCH, LDW = KCH + 8, KS = KCH * NCH;
   __shared__ __attribute__((aligned(16))) bf16_t Ws[NKW][16 * LDW];
   __shared__ float Ct[NKW][16][17];

@@ -96,6 +96,7 @@ struct MambaArgs {
   const bf16_t* norm_w;   // [d_inner]
   bf16_t* xbc;            // [rows][conv_dim] activated conv output
   bf16_t* y;              // [rows][d_inner]
+  float* vg;              // [rows][d_inner] fp32 gated value y * silu(z) (RMSNormGated's first step), or NULL
   bf16_t* g;              // [rows][d_inner] gated-normalised
   int d_inner, conv_dim, nheads, d_state, ngroups, d_in_proj, rows;
   float eps;
@@ -137,7 +138,7 @@ __global__ __launch_bounds__(256) void mamba_ssm_kernel(MambaArgs a) {
   const int grp = h / (a.nheads / a.ngroups);
   bf16_t* sp[RW];
   u32x4 sv[RW][NV], bv[RW][NV], cv[RW][NV];
-  float x[RW], dt[RW];
+  float x[RW], dt[RW], zg[RW];
 #pragma unroll
   for (int w = 0; w < RW; ++w) {
     const int r = min(r0 + w, a.rows - 1);            // clamped; a duplicate row recomputes and rewrites identical values
@@ -155,6 +156,7 @@ __global__ __launch_bounds__(256) void mamba_ssm_kernel(MambaArgs a) {
     for (int i = 0; i < NV; ++i) { bv[w][i] = ld16(Bp + i * 8); cv[w][i] = ld16(Cp + i * 8); }
     x[w] = bf2f(xb[h * P + p]);
     dt[w] = __fadd_rn(bf2f(a.zx[(size_t)r * a.d_in_proj + a.d_inner + a.conv_dim + h]), bf2f(a.dt_bias[h]));
+    zg[w] = bf2f(a.zx[(size_t)r * a.d_in_proj + h * P + p]);
   }
   const float A = -expf(bf2f(a.A_log[h]));
   const float Dh = bf2f(a.D[h]);
@@ -184,7 +186,13 @@ __global__ __launch_bounds__(256) void mamba_ssm_kernel(MambaArgs a) {
     // the 4 quarter-row partials of p sit in one quad
     y += dpp_mov<ZN_DPP_XOR1>(y);
     y += dpp_mov<ZN_DPP_XOR2>(y);
-    if (q == 0) a.y[(size_t)(r0 + w) * a.d_inner + h * P + p] = f2bf(__fadd_rn(y, __fmul_rn(x[w], Dh)));
+    if (q == 0) {
+      const bf16_t yb = f2bf(__fadd_rn(y, __fmul_rn(x[w], Dh)));
+      a.y[(size_t)(r0 + w) * a.d_inner + h * P + p] = yb;
+      // first step of RMSNormGated (norm_before_gate=False), once per element here instead of once per consumer: the
+      // fp32 product of the bf16 y and silu(z); the consumer (out_proj's prologue) adds the row statistics and the weight
+      if (a.vg) a.vg[(size_t)(r0 + w) * a.d_inner + h * P + p] = __fmul_rn(bf2f(yb), __fmul_rn(zg[w], 1.0f / (1.0f + expf(-zg[w]))));
+    }
   }
 }
 
