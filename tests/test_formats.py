@@ -90,3 +90,31 @@ def test_from_local_generates_like_direct_build(tmp_path):
     # rows 1026..1031 of the embedding tables differ (zero padding vs synthetic) but are never indexed (codes <= 1025)
     assert torch.equal(a, b)
     assert a.dtype == torch.int64 and a.shape[:2] == (1, 9)
+
+
+def test_wav_writer_and_tensor_cache_files(tmp_path):
+    """Output-side wire formats: a PCM_S 16-bit WAV like utilities/cache_utils.py:380-390 writes, from
+    both the int16 [T, 1] tensor of decode_to_int16 and a float waveform (same clamp / x32767 / truncate conversion,
+    autoencoder.py:142-170), and the `.pt` cache files of cache_utils.py:322-362 (plain torch.save of a tensor, loaded
+    with weights_only=True)."""
+    import wave
+
+    from zonos_amd.utils import load_tensor_cache, save_tensor_cache, save_wav_pcm16
+
+    f = torch.tensor([[0.0, 0.5, -0.5, 1.0, -1.0, 1.5, -2.0, 3.0517578125e-05, 0.99999]])
+    expect = (f.clamp(-1, 1) * 32767.0).to(torch.int16)[0]
+    p1 = save_wav_pcm16(tmp_path / "f.wav", f, 44100)
+    p2 = save_wav_pcm16(tmp_path / "i.wav", expect.unsqueeze(1), 44100)
+    for p in (p1, p2):
+        with wave.open(p, "rb") as w:
+            assert (w.getnchannels(), w.getsampwidth(), w.getframerate(), w.getnframes()) == (1, 2, 44100, f.shape[1])
+            got = np.frombuffer(w.readframes(w.getnframes()), dtype="<i2")
+        assert np.array_equal(got, expect.numpy())
+    emb = synth.conditioning(3, "cache.emb", 1, 1, 128)
+    codes = torch.from_numpy(synth.randint(3, "cache.codes", (1, 9, 40), 1024))
+    for name, t in (("emb", emb), ("codes", codes)):
+        path = save_tensor_cache(tmp_path / f"{name}.pt", t)
+        back = load_tensor_cache(path, device="cpu")
+        assert back.dtype == t.dtype and torch.equal(back, t)
+        assert torch.equal(torch.load(path, map_location="cpu", weights_only=True), t)      # the reference's loader call
+    assert load_tensor_cache(tmp_path / "missing.pt") is None
