@@ -272,6 +272,46 @@ def test_attention_prefill_vs_cpu_sdpa(full, kernel):
         eng.call("zn_debug_tune", 10, 1)
 
 
+@pytest.mark.parametrize("n_kv", [8, 4, 1], ids=["group1", "group2", "group8"])
+def test_attention_other_group_sizes_vs_cpu_sdpa(n_kv):
+    """Head size 128 with GQA groups of 1, 2 and 8 query heads per kv head (the checkpoints use 4): prefill attention on
+    the matrix cores (64 / G positions per workgroup) and decode attention (both launch shapes) against torch CPU SDPA,
+    same bit-equality bar as the group-4 tests."""
+    import torch.nn.functional as F
+    cfg = dict(d_model=1024, n_layer=1, num_heads=8, num_heads_kv=n_kv, d_ff=256)
+    model, _ = build_model(cfg, 5, "cuda:0")
+    eng = model.engine(1)
+    st = _lib.stream_ptr()
+    gen = torch.Generator().manual_seed(3)
+    for S in (37, 300, 700):
+        cap = S + 3
+        q = torch.randn(2, 8, S, 128, generator=gen).to(torch.bfloat16)
+        kv = torch.randn(2, cap, 2, n_kv, 128, generator=gen).to(torch.bfloat16)
+        k, v = kv[:, :S, 0].transpose(1, 2), kv[:, :S, 1].transpose(1, 2)
+        ref = F.scaled_dot_product_attention(q, k, v, is_causal=True, enable_gqa=True)
+        qd = q.transpose(1, 2).reshape(2, S, 1024).contiguous().to("cuda:0")
+        kvd = kv.to("cuda:0")
+        out = torch.full((2, S, 1024), float("nan"), dtype=torch.bfloat16, device="cuda:0")
+        eng.call("zn_op_attn_prefill", qd.data_ptr(), kvd.data_ptr(), cap, out.data_ptr(), S, 2, st)
+        torch.cuda.synchronize()
+        got = out.cpu().view(2, S, 8, 128).transpose(1, 2).contiguous()
+        eq = float((got.view(torch.int16) == ref.contiguous().view(torch.int16)).float().mean())
+        print(f"\n[prefill attn G={8 // n_kv} S={S}] bit-equal {eq:.5f}")
+        assert eq > 0.99, (n_kv, S, eq)
+        # decode: the last position alone over the same keys
+        refd = F.scaled_dot_product_attention(q[:, :, -1:], k, v, enable_gqa=True)[:, :, 0]
+        qd1 = q[:, :, -1].reshape(2, 1024).contiguous().to("cuda:0")
+        lengths = torch.full((2,), S - 1, dtype=torch.int32, device="cuda:0")
+        for fused_limit in (2048, 1):
+            eng.call("zn_debug_tune", 5, fused_limit)
+            o1 = torch.empty(2, 1024, dtype=torch.bfloat16, device="cuda:0")
+            eng.call("zn_op_attn_decode", qd1.data_ptr(), kvd.data_ptr(), cap, lengths.data_ptr(), None, o1.data_ptr(), 2, st)
+            torch.cuda.synchronize()
+            eqd = float((o1.cpu().view(2, 8, 128).view(torch.int16) == refd.contiguous().view(torch.int16)).float().mean())
+            assert eqd > 0.99, (n_kv, S, fused_limit, eqd)
+    eng.call("zn_debug_tune", 5, 704)
+
+
 def test_layer0_decode_vs_reference_block(golden_dir, full):
     """One decode step of block 0 at Zonos-v0.1-transformer dims over a synthetic KV history (L = 1, 17, 900):
     reference TransformerBlock output (golden) vs zn_op_layer_decode."""
