@@ -33,6 +33,9 @@ def main():
     nq, max_new = 9, L0 + n + 64
     eng = model.engine(B)
     eng.call("zn_debug_eos_bias", float("-inf"))
+    for kv_ in filter(None, os.environ.get("ZN_TUNE", "").split(",")):      # e.g. ZN_TUNE=8=1
+        k_, v_ = kv_.split("=")
+        eng.call("zn_debug_tune", int(k_), int(v_))
     ip = model.setup_cache(2 * B, L0 + n + 80)
     nl = cfg["n_layer"]
     for i in cfg["attn_layer_idx"]:
