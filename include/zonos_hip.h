@@ -155,7 +155,8 @@ int zn_debug_eos_bias(zn_handle h, float bias);
 /* ---------------------------------------------------------------- measurement */
 /* Average duration (HIP events on `stream`) of one of the decode step's weight-streaming kernels over `iters`
  * launches that cycle through the layers' weights, and its algorithmic bytes per launch (the weight matrix).
- * which: 0 = LayerNorm+fc1+SiLU-gate, 1 = fc2+residual, 2 = out_proj+residual, 3 = LayerNorm+heads. */
+ * which: 0 = LayerNorm+fc1+SiLU-gate, 1 = fc2+residual, 2 = out_proj+residual, 3 = LayerNorm+heads,
+ * 4 = LayerNorm+in_proj+RoPE+KV-append (into a scratch cache). */
 int zn_bench_kernel(zn_handle h, int32_t which, int32_t rows, int32_t iters, float* ms_per_launch,
                     double* bytes_per_launch, zn_stream stream);
 

@@ -71,8 +71,11 @@ def sweep():
     eng = model.engine(1)
     st = _lib.stream_ptr()
     t, by = C.c_float(0), C.c_double(0)
-    for key, which, name in ((2, 0, "fc1"), (3, 1, "fc2"), (1, 2, "out_proj"), (4, 3, "heads")):
-        for tb in (128, 192, 256, 384, 512, 768, 1024, 1536, 2048):
+    only = sys.argv[2].split(",") if len(sys.argv) > 2 else None
+    for key, which, name in ((0, 4, "in_proj"), (2, 0, "fc1"), (3, 1, "fc2"), (1, 2, "out_proj"), (4, 3, "heads")):
+        if only and name not in only:
+            continue
+        for tb in (96, 128, 192, 256, 384, 512, 768, 1024, 1536, 2048):
             eng.call("zn_debug_tune", key, tb)
             eng.call("zn_bench_kernel", which, 2, 260, C.byref(t), C.byref(by), st)
             print(f"{name:9s} target_blocks {tb:5d}: {t.value * 1e3:7.2f} us  {by.value / t.value / 1e6:7.1f} GB/s", flush=True)

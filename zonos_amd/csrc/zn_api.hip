@@ -57,7 +57,7 @@ struct zn_handle_s {
   int *lengths = nullptr, *codes = nullptr;
   int force_eos_step = -1;
   float eos_bias = 0.f;
-  int tune[12] = {512, 512, 512, 1024, 256, 704, 2, 2, 0, 0, 0, 0};   // target workgroups: in_proj, out_proj, fc1, fc2, heads; [5] longest context of the fused attention launch; [6] > 1: multi-step graphs; [7] > 1: LDS-staged small-M projections; [9]: KV capacity above which the P.V pass splits per block (0 = 1408); [10] = 2: VALU prefill attention; [11] = 2: no in-workgroup-split small-M kernel
+  int tune[12] = {256, 512, 512, 1024, 512, 704, 2, 2, 0, 0, 0, 0};   // target workgroups: in_proj, out_proj, fc1, fc2, heads; [5] longest context of the fused attention launch; [6] > 1: multi-step graphs; [7] > 1: LDS-staged small-M projections; [9]: KV capacity above which the P.V pass splits per block (0 = 1408); [10] = 2: VALU prefill attention; [11] = 2: no in-workgroup-split small-M kernel
   const int* tok_override = nullptr;
   int tok_override_calls = 0;
   hipStream_t cap_stream = nullptr;
@@ -869,7 +869,7 @@ extern "C" int zn_debug_eos_bias(zn_handle h, float bias) { if (!h) return ZN_ER
 extern "C" int zn_bench_kernel(zn_handle h, int32_t which, int32_t rows, int32_t iters, float* ms_per_launch, double* bytes_per_launch,
                                zn_stream stream) {
   if (!h) return ZN_ERR_ARG;
-  if (!ms_per_launch || !bytes_per_launch || iters < 1 || (rows & 0xff) < 1 || (rows & 0xff) > h->max_rows || which < 0 || which > 3)
+  if (!ms_per_launch || !bytes_per_launch || iters < 1 || (rows & 0xff) < 1 || (rows & 0xff) > h->max_rows || which < 0 || which > 4)
     ZN_FAIL(h, ZN_ERR_ARG, "zn_bench_kernel: bad argument");
   const bool same_layer = (rows & 0x100) != 0;   // measurement variant: keep hitting layer 0 (weights stay in the Infinity Cache)
   rows &= 0xff;
@@ -879,6 +879,13 @@ extern "C" int zn_bench_kernel(zn_handle h, int32_t which, int32_t rows, int32_t
   HIPCHK(h, hipMemsetAsync(h->x, 0, (size_t)rows * d * 2, s));
   HIPCHK(h, hipMemsetAsync(h->mbuf, 0, (size_t)rows * c.d_ff * 2, s));
   HIPCHK(h, hipMemsetAsync(h->o1, 0, (size_t)rows * d * 2, s));
+  const int hd = h->hd, nq = c.n_heads * hd, nkv = c.n_heads_kv * hd;
+  bf16_t* tkv = nullptr; int* tlen = nullptr;             // which == 4: a scratch cache of 8 positions per row, all rows at position 0
+  if (which == 4) {
+    HIPCHK(h, hipMalloc(&tkv, (size_t)rows * 8 * 2 * nkv * 2));
+    HIPCHK(h, hipMalloc(&tlen, (size_t)rows * sizeof(int)));
+    HIPCHK(h, hipMemsetAsync(tlen, 0, (size_t)rows * sizeof(int), s));
+  }
   hipEvent_t e0, e1;
   HIPCHK(h, hipEventCreate(&e0));
   HIPCHK(h, hipEventCreate(&e1));
@@ -898,6 +905,11 @@ extern "C" int zn_bench_kernel(zn_handle h, int32_t which, int32_t rows, int32_t
       } else if (which == 2) {
         a.W = (const bf16_t*)lw.out_proj; a.N = d; a.K = c.n_heads * h->hd; a.x = h->o1; a.resid = h->x; a.out = h->x;
         rc = run_gemv<PRO_NONE, EPI_RESID>(h, a, rows, h->tune[1], s);
+      } else if (which == 4) {
+        a.W = (const bf16_t*)lw.in_proj; a.N = nq + 2 * nkv; a.K = d; a.x = h->x; a.ln_w = (const bf16_t*)lw.norm_w; a.ln_b = (const bf16_t*)lw.norm_b;
+        a.lengths = tlen; a.hd = hd; a.n_heads = c.n_heads; a.n_heads_kv = c.n_heads_kv;
+        a.q_out = h->q; a.kv = tkv; a.rope = h->rope; a.max_len = 8; a.rope_positions = c.rope_positions;
+        rc = run_gemv<PRO_LN, EPI_ROPE_KV>(h, a, rows, h->tune[0], s);
       } else {
         rc = heads_logits(h, h->x, rows, s);
       }
@@ -909,9 +921,11 @@ extern "C" int zn_bench_kernel(zn_handle h, int32_t which, int32_t rows, int32_t
   float ms = 0.f;
   HIPCHK(h, hipEventElapsedTime(&ms, e0, e1));
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  if (tkv) (void)hipFree(tkv);
+  if (tlen) (void)hipFree(tlen);
   *ms_per_launch = ms / iters;
   const double wbytes = which == 0 ? 2.0 * c.d_ff * d * 2 : which == 1 ? (double)d * c.d_ff * 2 : which == 2 ? (double)d * c.n_heads * h->hd * 2
-                                   : (double)c.n_codebooks * c.vocab_head * d * 2;
+                        : which == 4 ? (double)(nq + 2 * nkv) * d * 2 : (double)c.n_codebooks * c.vocab_head * d * 2;
   *bytes_per_launch = wbytes;   // algorithmic bytes = the weight matrix, read once (activations are KBs)
   return ZN_OK;
 }
