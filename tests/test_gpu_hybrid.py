@@ -50,13 +50,17 @@ def test_add_layernorm_vs_oracle():
 GROUPS_CFG = dict(synth.HYBRID_TINY_CFG, ssm_cfg={"layer": "Mamba2", "d_state": 64, "ngroups": 2})   # two B/C groups, two heads each
 
 
-@pytest.mark.parametrize("cfg_name", ["tiny", "wide", "groups"])
+# five heads of 64: in_proj has an odd number of rows (2 * 320 + 2 * 64 + 5), its last dt row has no partner in the row pairs
+ODD_CFG = dict(d_model=160, n_layer=2, num_heads=5, num_heads_kv=5, d_ff=320, ssm_cfg={"layer": "Mamba2", "d_state": 64}, attn_layer_idx=[1])
+
+
+@pytest.mark.parametrize("cfg_name", ["tiny", "wide", "groups", "odd"])
 def test_mamba2_step_vs_oracle(cfg_name):
     """Six consecutive tokens through the Mamba2 mixer of layer 0 from random states.  The conv window holds in_proj
     outputs (bf16 GEMV results: fp32 summation order may flip a last bit), SSM state and outputs additionally see libm
     ulp differences in exp/log1p before one bf16 rounding: bit-equal fractions > 0.98 (window, state) / > 0.8 (output),
     max |diff| <= 2^-6 of the output scale."""
-    cfg = {"tiny": synth.HYBRID_TINY_CFG, "wide": WIDE_CFG, "groups": GROUPS_CFG}[cfg_name]
+    cfg = {"tiny": synth.HYBRID_TINY_CFG, "wide": WIDE_CFG, "groups": GROUPS_CFG, "odd": ODD_CFG}[cfg_name]
     model, sd = build_model(cfg, 11, "cuda:0")
     eng = model.engine(1)
     st = _lib.stream_ptr()

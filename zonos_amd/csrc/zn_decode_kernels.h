@@ -95,7 +95,8 @@ ZN_DEVINL void gemv_epilogue(const GemvArgs& a, int r, int rowA, int rowB, bool 
   } else if constexpr (EPI == EPI_MAMBA) {
     // Mamba2.step: zxbcdt = in_proj(x) (bf16), then xBC through the conv window; z and dt are consumed as stored
     const bf16_t xa = f2bf(vA), xb = f2bf(vB);
-    *(unsigned*)(a.out + (size_t)r * a.N + rowA) = (unsigned)xa | ((unsigned)xb << 16);
+    if (b_ok) *(unsigned*)(a.out + (size_t)r * a.N + rowA) = (unsigned)xa | ((unsigned)xb << 16);
+    else a.out[(size_t)r * a.N + rowA] = xa;                 // odd N (odd head count): the last row has no partner
     const int c = rowA - a.d_inner;
     if (c >= 0 && c < a.conv_dim) {
       unsigned s0 = cst.x, s1 = cst.y, s2 = cst.z, s3 = cst.w;
