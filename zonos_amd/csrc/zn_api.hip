@@ -214,7 +214,7 @@ static int launch_gemv_rows(const GemvArgs& a, int rgroup, int ks, int nch, int 
     if (rgroup <= 2) return launch_gemv_nch<2, 1, PRO, EPI>(a, nch, blocks, full && rgroup == 2, s);
     return launch_gemv_nch<4, 1, PRO, EPI>(a, nch, blocks, full && rgroup == 4, s);
   }
-  if constexpr (PRO == PRO_NONE) {
+  if constexpr (PRO == PRO_NONE || PRO == PRO_GATED) {
     if (rgroup <= 2) return launch_gemv_nch<2, 4, PRO, EPI>(a, nch, blocks, full && rgroup == 2, s);
     return launch_gemv_nch<4, 4, PRO, EPI>(a, nch, blocks, full && rgroup == 4, s);
   }
@@ -265,7 +265,7 @@ static void run_gemm16k(const GemvArgs& g, hipStream_t s) {
   if constexpr (EPI != EPI_SILU) {
     const int tiles = (g.N + 15) / 16;
     if (g.K / (ZN_G16K_NKW * ZN_G16K_KCH) == 2) hipLaunchKernelGGL((gemm16k_kernel<EPI, 2, PRO>), dim3(tiles), dim3(ZN_G16K_NKW * 64), 0, s, g);
-    else hipLaunchKernelGGL((gemm16k_kernel<EPI, 4, PRO>), dim3(tiles), dim3(ZN_G16K_NKW * 64), 0, s, g);
+    else if constexpr (PRO == PRO_NONE) hipLaunchKernelGGL((gemm16k_kernel<EPI, 4, PRO>), dim3(tiles), dim3(ZN_G16K_NKW * 64), 0, s, g);   // (the LayerNorm prologue at K = 4096 would not fit the register file: the caller keeps it a launch)
   }
 }
 
@@ -290,7 +290,7 @@ static int run_gemm16(zn_handle h, GemvArgs a, int rows, hipStream_t s) {
     const bool k16 = gemm16k_fits(h, EPI, a.N, K);
     // that kernel normalises its rows itself when at most one workgroup per CU repeats the statistics (in_proj: 8.7 us vs
     // 4.8 + 6.2; the heads' 577 tiles: 21.8 vs 5.0 + 11.9)
-    const bool k16_ln = k16 && PRO == PRO_LN && tiles <= 256;
+    const bool k16_ln = k16 && PRO == PRO_LN && tiles <= 256 && K == 2 * ZN_G16K_NKW * ZN_G16K_KCH;
     if (PRO == PRO_LN && !k16_ln) {
       hipLaunchKernelGGL(layernorm_kernel, dim3(nr), dim3(64), 0, s, a.x + (size_t)r0 * K, a.ln_w, a.ln_b, h->nbuf, K, a.eps);
       g.x = h->nbuf;
@@ -329,7 +329,7 @@ static int run_gemv(zn_handle h, GemvArgs a, int rows, int target_blocks, hipStr
   if (rows > 4) return run_gemm16<PRO, EPI>(h, a, rows, s);
   const int K = a.K;
   int ks = 1;
-  if (PRO == PRO_NONE && K >= 4096 && K % 2048 == 0) ks = 4;
+  if ((PRO == PRO_NONE || PRO == PRO_GATED) && K >= 4096 && K % 2048 == 0) ks = 4;
   const int kw = K / ks;
   int nch = (kw + 511) / 512;
   nch = nch <= 1 ? 1 : nch <= 2 ? 2 : nch <= 4 ? 4 : nch <= 8 ? 8 : 99;

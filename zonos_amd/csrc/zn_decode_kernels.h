@@ -205,10 +205,10 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs a) {
         }
       }
       if constexpr (PRO == PRO_GATED) {                    // eight fp32 values: xr = first four, zr = last four
-        if constexpr (FULL) { xr[c][r] = ld16(a.gv + (size_t)r * K + k); zr[c][r] = ld16(a.gv + (size_t)r * K + k + 4); }
+        if constexpr (FULL) { xr[c][r] = ld16(a.gv + (size_t)r * K + kbase + k); zr[c][r] = ld16(a.gv + (size_t)r * K + kbase + k + 4); }
         else {
           xr[c][r] = u32x4{0, 0, 0, 0}; zr[c][r] = u32x4{0, 0, 0, 0};
-          if (kv_ok && r < a.nrows) { xr[c][r] = ld16(a.gv + (size_t)r * K + k); zr[c][r] = ld16(a.gv + (size_t)r * K + k + 4); }
+          if (kv_ok && r < a.nrows) { xr[c][r] = ld16(a.gv + (size_t)r * K + kbase + k); zr[c][r] = ld16(a.gv + (size_t)r * K + kbase + k + 4); }
         }
       }
     }
@@ -218,7 +218,7 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs a) {
     }
     if constexpr (PRO == PRO_GATED) {
       lng[c] = u32x4{0, 0, 0, 0};
-      if (kv_ok) lng[c] = ld16(a.ln_w + k);
+      if (kv_ok) lng[c] = ld16(a.ln_w + kbase + k);
     }
   }
   WTile<NCH> wt;
@@ -278,9 +278,11 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs a) {
 
   if constexpr (PRO == PRO_GATED) {
     // mamba_ssm RMSNormGated(norm_before_gate=False), one group: v = y * silu(z) arrives in fp32 (mamba_ssm_kernel);
-    // out = bf16(v * rstd * w) with rstd from the mean of v^2 over the row.  KSPLIT == 1: every wave holds whole rows.
+    // out = bf16(v * rstd * w) with rstd from the mean of v^2 over the row.  KSPLIT == 1: every wave holds whole rows;
+    // KSPLIT == 4: a quarter each, the four partial sums meet in LDS in wave order.
     const float invK = 1.0f / (float)K;
     float ss[R], rstd[R];
+    __shared__ float red_pro[4][R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       ss[r] = 0.f;
@@ -293,8 +295,16 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs a) {
         for (int e = 0; e < 8; ++e) ss[r] += v[e] * v[e];
       }
     }
+    if constexpr (KSPLIT == 1) {
 #pragma unroll
-    for (int r = 0; r < R; ++r) rstd[r] = 1.0f / sqrtf(wave_sum(ss[r]) * invK + a.eps);
+      for (int r = 0; r < R; ++r) rstd[r] = 1.0f / sqrtf(wave_sum(ss[r]) * invK + a.eps);
+    } else {
+#pragma unroll
+      for (int r = 0; r < R; ++r) { const float t = wave_sum(ss[r]); if (lane == 0) red_pro[wave][r] = t; }
+      __syncthreads();
+#pragma unroll
+      for (int r = 0; r < R; ++r) rstd[r] = 1.0f / sqrtf((((red_pro[0][r] + red_pro[1][r]) + red_pro[2][r]) + red_pro[3][r]) * invK + a.eps);
+    }
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
       const u32x4 g = lng[c];
