@@ -1,4 +1,5 @@
-"""Ad-hoc op-level HIP-vs-oracle mismatch report (run on the GPU box: python tools/gpu_debug.py)."""
+"""Ad-hoc op-level HIP-vs-oracle mismatch report (checker tooling, lives with the tests because only they may use the
+oracle; run on the GPU box: python tests/debug_op_report.py).  Not collected by pytest (no test_ prefix)."""
 import ctypes as C
 import os
 import sys
