@@ -1,5 +1,8 @@
+"""Weight-streaming kernels of the decode step, cold (cycling through the 26 layers' weights: every launch streams from
+HBM) vs hot (the same layer every launch: weights come from L2 / the Infinity Cache) - the bound on what any scheme that
+prefetches weights beside the dependent chain could give.  python tools/hotcold.py"""
 import ctypes as C, os, sys, torch
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from zonos_amd import _lib, synth
 from zonos_amd.testing import build_model
 model, _ = build_model(synth.FULL_CFG, 1234, "cuda:0")
