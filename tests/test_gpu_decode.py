@@ -383,6 +383,34 @@ def test_full_dims_free_running(golden_dir, full):
     assert agree > 0.95 and dec, (agree, dec)
 
 
+def test_baseline_length_generation_properties(full):
+    """BASELINE config 2 at full size (B = 1, L_c = 24, 861 new tokens, EOS suppressed: 868 decode steps through the fused
+    and the two-pass attention launch shapes, 8-step and single-step graphs), checked through size-independent
+    properties, since the oracle needs minutes for it: output shape and code range; run-to-run determinism; causality
+    (a 200-token run of the same utterance reproduces the long run's frames, up to its last 8: there the upper codebooks'
+    delayed columns are cut off by the end of the loop, the reference's own tail behaviour); the replayed multi-step graphs
+    give the codes of single-step launches."""
+    model, _ = full
+    eng = model.engine(1)
+    cond = synth.conditioning(1234, "cond", 2, 24, 2048).to("cuda:0")
+    eng.call("zn_debug_eos_bias", float("-inf"))
+    try:
+        a = model.generate(cond, max_new_tokens=861, sampling_params=GREEDY)
+        b = model.generate(cond, max_new_tokens=861, sampling_params=GREEDY)
+        short = model.generate(cond, max_new_tokens=200, sampling_params=GREEDY)
+        eng.call("zn_debug_tune", 6, 1)                      # single-step launches only
+        c = model.generate(cond, max_new_tokens=861, sampling_params=GREEDY)
+    finally:
+        eng.call("zn_debug_tune", 6, 2)
+        eng.call("zn_debug_eos_bias", 0.0)
+    assert tuple(a.shape) == (1, 9, 861) and a.dtype == torch.int64
+    assert int(a.min()) >= 0 and int(a.max()) <= 1023
+    assert torch.equal(a, b)
+    assert tuple(short.shape) == (1, 9, 200) and torch.equal(a[..., :192], short[..., :192])
+    assert torch.equal(a[:, 0, :200], short[:, 0])       # codebook 0 is not delayed: equal to the end
+    assert torch.equal(a, c)
+
+
 def test_sampler_transforms_vs_oracle(tiny):
     """Deterministic part of sample_from_logits (repetition penalty, softmax/T, unified, top-p, top-k, min-p) vs the
     oracle on seeded logits; tolerance 2e-6 absolute on probabilities (fp32, different exp/log implementations)."""
