@@ -1400,26 +1400,39 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
   __shared__ int sidx[ZN_SAMPLE_MAXV];
   __shared__ float sv[4];
   __shared__ int si[4];
+  // every input is requested before the first use (clamped indices, masked use): the kernel sits on the step's
+  // launch-bound tail, where one memory round trip per loop iteration used to cost several microseconds
   const int o = a.st ? a.st->offset : 0;
+  const float st_bias = a.st ? a.st->eos_bias : 0.f;
+  const bool st_force = a.st ? (a.st->force_eos_step == a.st->step) : false;
+  constexpr int IT = ZN_SAMPLE_MAXV / 256;
+  float cc[IT], uu[IT];
+  const float* rc = a.raw + ((size_t)b * a.n_q + cb) * V;
+  const float* ru = a.raw + ((size_t)(b + (a.mix ? a.batch : 0)) * a.n_q + cb) * V;
+#pragma unroll
+  for (int it = 0; it < IT; ++it) {
+    const int i = min(tid + it * 256, V - 1);
+    cc[it] = rc[i];
+    uu[it] = ru[i];
+  }
   // ---- logits: CFG mix (model.py:231-232), logit bias (model.py:433-437,476)
-  for (int i = tid; i < V; i += 256) {
-    float l;
-    if (a.mix) {
-      const float c = a.raw[((size_t)b * a.n_q + cb) * V + i];
-      const float u = a.raw[((size_t)(b + a.batch) * a.n_q + cb) * V + i];
-      l = __fadd_rn(u, __fmul_rn(__fsub_rn(c, u), a.cfg_scale));
-    } else l = a.raw[((size_t)b * a.n_q + cb) * V + i];
-    if (a.apply_bias && i == a.eos_id) {
-      if (cb == 0) {
-        l = __fadd_rn(l, -0.6931471824645996f);  // -log(2) in fp32
-        if (a.st) {
-          l += a.st->eos_bias;
-          if (a.st->force_eos_step == a.st->step) l = 1.0e4f;
-        }
-      } else l = -INFINITY;
+#pragma unroll
+  for (int it = 0; it < IT; ++it) {
+    const int i = tid + it * 256;
+    if (i < V) {
+      float l = a.mix ? __fadd_rn(uu[it], __fmul_rn(__fsub_rn(cc[it], uu[it]), a.cfg_scale)) : cc[it];
+      if (a.apply_bias && i == a.eos_id) {
+        if (cb == 0) {
+          l = __fadd_rn(l, -0.6931471824645996f);  // -log(2) in fp32
+          if (a.st) {
+            l += st_bias;
+            if (st_force) l = 1.0e4f;
+          }
+        } else l = -INFINITY;
+      }
+      if (a.logits_out) a.logits_out[((size_t)b * a.n_q + cb) * V + i] = l;
+      sp[i] = l;
     }
-    if (a.logits_out) a.logits_out[((size_t)b * a.n_q + cb) * V + i] = l;
-    sp[i] = l;
   }
   __syncthreads();
   // ---- repetition penalty (sampling.py:159-163): factor = penalty^(#occurrences in the last `window` tokens)
@@ -1432,17 +1445,22 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
       nw = avail < a.pen_window ? avail : a.pen_window;
       hist = a.codes + ((size_t)b * a.n_q + cb) * a.t_total + (o + 1 - nw);
     }
+    // the window's tokens are fetched once, together, into LDS (the default window is 2); longer windows re-read memory
+    constexpr int HW = 16;
+    __shared__ int s_hist[HW];
+    if (tid < HW && tid < nw) s_hist[tid] = hist[tid];
+    __syncthreads();
     if (tid == 0) {
+      auto tokat = [&](int w) -> int { const int g = w < HW ? s_hist[w] : hist[w]; return g > V - 1 ? V - 1 : g; };
       for (int w = 0; w < nw; ++w) {
-        int g = hist[w];
-        g = g > V - 1 ? V - 1 : g;
+        const int g = tokat(w);
         if (g < 0) continue;
         // scatter_reduce(prod) builds the factor first; apply once per distinct token
         bool seen = false;
-        for (int w2 = 0; w2 < w; ++w2) { int g2 = hist[w2]; g2 = g2 > V - 1 ? V - 1 : g2; if (g2 == g) seen = true; }
+        for (int w2 = 0; w2 < w; ++w2) if (tokat(w2) == g) seen = true;
         if (seen) continue;
         float f = 1.f;
-        for (int w2 = w; w2 < nw; ++w2) { int g2 = hist[w2]; g2 = g2 > V - 1 ? V - 1 : g2; if (g2 == g) f = __fmul_rn(f, a.penalty); }
+        for (int w2 = w; w2 < nw; ++w2) if (tokat(w2) == g) f = __fmul_rn(f, a.penalty);
         const float l = sp[g];
         sp[g] = (l <= 0.f) ? __fmul_rn(l, f) : __fdiv_rn(l, f);
       }
