@@ -1,31 +1,37 @@
 """bench.py — headline benchmark of the Zonos hot path on MI355X (contract: task brief ④).
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
-One "step" = one pass of the hot path over one synthetic utterance per GPU (BASELINE.json configs[1]):
-Zonos-v0.1-transformer dims, bf16, batch 1, L_c = 24 synthetic conditioning positions, 861 new tokens (10 s of
-audio) with EOS suppressed so that the prefill and all 868 decode steps run, then DAC decode of the [1, 9, 861]
-codes.  Weights are seeded synthetic (no checkpoint exists offline).  Utterances shard over ranks with no data-path
-collective (weak scaling); the optional gather of the output codes (RCCL all_gather) is inside the timed region.
-Rank 0 prints ONE JSON line.
+N > 1 without a launcher environment: this process spawns the N ranks itself (`python -m torch.distributed.run
+--nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...`) BEFORE anything touches the GPU, relays rank 0's JSON line
+and exits with the children's status.  Under an external `torch.distributed.run` (RANK/WORLD_SIZE set) it is a rank.
+
+One "step" = one pass of the hot path over `--batch-per-gpu` synthetic utterances per GPU (default 1 = BASELINE.json
+configs[1]): Zonos-v0.1-transformer dims, bf16, L_c = 24 synthetic conditioning positions, 861 new tokens (10 s of
+audio) with EOS suppressed so that the prefill and all 868 decode steps run, then DAC decode of the [B, 9, 861] codes.
+Weights are seeded synthetic (no checkpoint exists offline).  Utterances shard over ranks through
+zonos_amd/parallel.py (utterance i -> rank i mod N, no data-path collective: weak scaling); the optional gather of
+the output codes (RCCL all_gather) is inside the timed region.  Rank 0 prints ONE JSON line.
 """
 from __future__ import annotations
 
 import argparse
 import ctypes as C
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FRAME_RATE = 44100 / 512          # 86.1328 DAC frames per second of audio
 HBM_PEAK = 8.0e12                 # B/s, MI355X spec (MI355X_MICROARCH.md)
+PMC_FILE = os.path.join(ROOT, "profiles", "pmc_fc1.json")
+KERNEL_SOURCES = ("zonos_amd/csrc/zn_decode_kernels.h", "zonos_amd/csrc/zn_common.h")
 
 
 def algorithmic_bytes_per_step(cfg, B, L):
@@ -38,12 +44,7 @@ def algorithmic_bytes_per_step(cfg, B, L):
     return W + 2 * B * L * kv_pos + 2 * B * kv_pos
 
 
-def main():
-    # Libraries (RCCL prints a version banner) write to fd 1; the contract is ONE JSON line on stdout, so keep a private
-    # copy of stdout for that line and point fd 1 at stderr for everything else.
-    sys.stdout.flush()
-    json_fd = os.dup(1)
-    os.dup2(2, 1)
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
@@ -52,78 +53,142 @@ def main():
     ap.add_argument("--batch-per-gpu", type=int, default=1, help="utterances per GPU (default 1 = BASELINE config 2; 8 = config 3's share)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dac", action="store_true")
-    args = ap.parse_args()
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launcher/sharding rehearsal on CPU over gloo with a stand-in generate(); the line carries dry_run=true and no measurement")
+    return ap.parse_args(argv)
+
+
+def log(msg):
+    print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
+# ------------------------------------------------------------------------------------------------ launcher
+def spawn_ranks(n: int, argv: list[str]) -> int:
+    """Start the N ranks as children (no GPU call has happened in this process), pass rank 0's JSON line through."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *argv]
+    log("spawning: " + " ".join(cmd))
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    line = None
+    for ln in p.stdout:
+        ln = ln.strip()
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+    rc = p.wait()
+    if rc != 0:
+        log(f"ranks exited with status {rc}")
+        return rc
+    if line is None:
+        log("no JSON line from rank 0")
+        return 1
+    print(line, flush=True)
+    return 0
+
+
+# ------------------------------------------------------------------------------------------------ rank
+def run_rank(args) -> int:
+    # Libraries (RCCL prints a version banner) write to fd 1; the contract is ONE JSON line on stdout, so keep a private
+    # copy of stdout for that line and point fd 1 at stderr for everything else.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+    import torch
+    from zonos_amd import parallel
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py --gpus N ...")
-        args.gpus = world
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    args.gpus = world
+    dry = args.dry_run
+    if dry:
+        dev = torch.device("cpu")
+    else:
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1 or os.environ.get("ZN_BENCH_FORCE_DIST") == "1":      # the env var rehearses the RCCL path on one rank
+    if world > 1 or os.environ.get("ZN_BENCH_FORCE_DIST") == "1":      # the env var rehearses the collective path on one rank
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
         os.environ.setdefault("RANK", str(rank))
         os.environ.setdefault("WORLD_SIZE", str(world))
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-
-    from zonos_amd import _lib, synth
-    from zonos_amd.autoencoder import DACAutoencoder
-    from zonos_amd.testing import build_model
-
-    cfg, seed = synth.FULL_CFG, 1234
-    max_new = int(round(args.seconds * FRAME_RATE))             # 861 for 10 s
-    l_c, B = 24, args.batch_per_gpu
-    t0 = time.time()
-    dac = None
-    if not args.no_dac:
-        dac = DACAutoencoder(synth.dac_state_dict(4321), device=dev)
-    model, w_cpu = build_model(cfg, seed, dev, dac=dac)
-    setup_s = time.time() - t0
-    log(f"rank {rank}: model built in {setup_s:.1f} s")
-    eng = model.engine(B)
-    eng.call("zn_debug_eos_bias", float("-inf"))                 # suppress EOS: all max_new+7 steps run
-    cond = torch.cat([synth.conditioning(seed + rank * 64 + i, "cond", 2, l_c, cfg["d_model"])[j:j + 1] for j in (0, 1) for i in range(B)], 0).to(dev)
-    steps_per_utt = max_new + 7
-
-    use_dac = dac is not None
-    if use_dac:
-        try:
-            dac.decode(torch.zeros(1, 9, 4, dtype=torch.int64, device=dev))
-        except _lib.ZonosHipError as e:
-            if rank == 0:
-                print(f"[bench] DAC decode unavailable ({e}); timing the AR path only", file=sys.stderr)
-            use_dac = False
-
-    def one_step():
-        codes = model.generate(cond, max_new_tokens=max_new, cfg_scale=2.0, batch_size=B, sampling_params={"temperature": 0.0})
-        wav = dac.decode(codes) if use_dac else None
-        if dist is not None:
-            out = [torch.empty_like(codes) for _ in range(world)]
-            dist.all_gather(out, codes)                          # C1: optional gather of the output codes
-        return codes, wav
+        if dry:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     def fence():
         if dist is not None:
-            dist.barrier(device_ids=[local_rank])
-        torch.cuda.synchronize()
+            if dry:
+                dist.barrier()
+            else:
+                dist.barrier(device_ids=[local_rank])
+        if not dry:
+            torch.cuda.synchronize()
+
+    max_new = int(round(args.seconds * FRAME_RATE))             # 861 for 10 s
+    l_c, B = 24, args.batch_per_gpu
+    n_utt = world * B
+    steps_per_utt = max_new + 7
+    t0 = time.time()
+    if dry:
+        cfg, seed, model, dac, eng, w_cpu = {"d_model": 8}, 1234, None, None, None, None
+        if os.environ.get("ZN_BENCH_DRYRUN_FAIL_RANK") == str(rank):   # test hook: a dying rank must fail the whole job
+            raise SystemExit(3)
+
+        def gen(cond, b=1):                                     # stand-in: ragged-free deterministic codes of the right shape
+            g = torch.Generator().manual_seed(int(cond.abs().sum().item() * 1000) % 9973)
+            return torch.randint(0, 1024, (b, 9, max_new), generator=g, dtype=torch.int64)
+        conds = [torch.full((2, l_c, 8), float(i + 1)) for i in range(n_utt)]
+        use_dac = False
+    else:
+        from zonos_amd import _lib, synth
+        from zonos_amd.autoencoder import DACAutoencoder
+        from zonos_amd.testing import build_model
+        cfg, seed = synth.FULL_CFG, 1234
+        dac = None if args.no_dac else DACAutoencoder(synth.dac_state_dict(4321), device=dev)
+        model, w_cpu = build_model(cfg, seed, dev, dac=dac)
+        eng = model.engine(B)
+        eng.call("zn_debug_eos_bias", float("-inf"))             # suppress EOS: all max_new+7 steps run
+        conds = [synth.conditioning(seed + i, "cond", 2, l_c, cfg["d_model"]).to(dev) for i in range(n_utt)]
+
+        def gen(cond, b=1):
+            return model.generate(cond, max_new_tokens=max_new, cfg_scale=2.0, batch_size=b, sampling_params={"temperature": 0.0})
+        use_dac = dac is not None
+        if use_dac:
+            try:
+                dac.decode(torch.zeros(1, 9, 4, dtype=torch.int64, device=dev))
+            except _lib.ZonosHipError as e:
+                if rank == 0:
+                    log(f"DAC decode unavailable ({e}); timing the AR path only")
+                use_dac = False
+    setup_s = time.time() - t0
+    log(f"rank {rank}/{world}: ready in {setup_s:.1f} s ({'dry run, cpu/gloo' if dry else str(dev)})")
+
+    def one_step():
+        mine = parallel.generate_sharded(gen, conds, gather=False, batch_size=B)      # this rank's utterances (i mod world == rank)
+        wav = dac.decode(torch.stack(mine)) if use_dac else None
+        if dist is not None:
+            parallel.gather_codes(mine, n_utt)                   # C1: optional gather of the output codes (all_gather)
+        return mine, wav
 
     for i in range(args.warmup):
         one_step()
-        torch.cuda.synchronize()
+        if not dry:
+            torch.cuda.synchronize()
         log(f"rank {rank}: warmup {i} done")
     fence()
-    t_ar = 0.0
     t0 = time.perf_counter()
     frames = 0
     for _ in range(args.steps):
-        codes, wav = one_step()
-        frames += codes.shape[-1] * codes.shape[0]
+        mine, wav = one_step()
+        frames += sum(int(c.shape[-1]) for c in mine)
     fence()
     elapsed = time.perf_counter() - t0
     log(f"rank {rank}: {args.steps} timed steps in {elapsed:.3f} s")
@@ -134,14 +199,7 @@ def main():
         fr = torch.tensor([frames], dtype=torch.float64, device=dev)
         dist.all_reduce(fr, op=dist.ReduceOp.SUM)
         frames = int(fr.item())
-    assert codes.shape[-1] == max_new, codes.shape
-
-    # AR-only time of one utterance (reported beside the whole-job value)
-    torch.cuda.synchronize()
-    ta = time.perf_counter()
-    model.generate(cond, max_new_tokens=max_new, cfg_scale=2.0, batch_size=B, sampling_params={"temperature": 0.0})
-    torch.cuda.synchronize()
-    t_ar = time.perf_counter() - ta
+    assert all(c.shape[-1] == max_new for c in mine), [c.shape for c in mine]
 
     audio_s = frames / FRAME_RATE
     value = audio_s / elapsed
@@ -155,18 +213,33 @@ def main():
                    "codes_all_gather_in_timed_region": dist is not None, "parallelism": f"dp{world} (utterance sharding, no data-path collective)"},
         "dac_tokens_per_sec": round(world * B * args.steps * steps_per_utt * 9 / elapsed, 1),
         "frames_per_sec": round(frames / elapsed, 1),
-        "ar_only": {"s_per_utterance": round(t_ar, 4), "ms_per_decode_step": round(1e3 * t_ar / (steps_per_utt + 1), 4),
-                    "audio_sec_per_sec": round(B * max_new / FRAME_RATE / t_ar, 3)},
-        "setup_s": round(setup_s, 1), "hipgraph_step": bool(eng.lib.zn_graph_active(eng.h)),
+        "setup_s": round(setup_s, 1),
     }
-    if rank == 0:
-        # ---- roofline of the dominant kernel (LayerNorm + fc1 GEMV + SiLU gate: 67 MB of the 123 MB per layer)
+    if dry:
+        result["dry_run"] = True
+        result["value"] = None
+    else:
+        # AR-only time of one generate() call (reported beside the whole-job value)
+        cond = torch.cat([c[0:1] for c in conds[rank::world]] + [c[1:2] for c in conds[rank::world]], 0)
+        torch.cuda.synchronize()
+        ta = time.perf_counter()
+        gen(cond, B)
+        torch.cuda.synchronize()
+        t_ar = time.perf_counter() - ta
+        result["ar_only"] = {"s_per_utterance": round(t_ar, 4), "ms_per_decode_step": round(1e3 * t_ar / (steps_per_utt + 1), 4),
+                             "audio_sec_per_sec": round(B * max_new / FRAME_RATE / t_ar, 3)}
+        result["hipgraph_step"] = bool(eng.lib.zn_graph_active(eng.h))
+    if rank == 0 and not dry:
+        from zonos_amd import _lib
+        # ---- roofline of the dominant kernel (LayerNorm + fc1 GEMV + SiLU gate: 67 MB of the 123 MB per layer), HIP events
+        # on the launch stream; the launches cycle over the 26 layers' weights so that each streams from HBM
         ms, by = C.c_float(0), C.c_double(0)
         eng.call("zn_bench_kernel", 0, 2 * B, 260, C.byref(ms), C.byref(by), _lib.stream_ptr())
         ach = by.value / (ms.value * 1e-3)
+        traffic, traffic_note = pmc_traffic()
         result["roofline"] = {"bound": "hbm", "kernel": "gemv_kernel<R=2,NCH=4,KSPLIT=1,PRO_LN,EPI_SILU> (LayerNorm+fc1+SiLU-gate)",
                               "achieved": round(ach / 1e9, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": round(ach / HBM_PEAK, 4),
-                              "traffic": pmc_traffic(), "bytes_per_launch": by.value, "us_per_launch": round(ms.value * 1e3, 3)}
+                              "traffic": traffic, "traffic_note": traffic_note, "bytes_per_launch": by.value, "us_per_launch": round(ms.value * 1e3, 3)}
         Lavg = l_c + 1 + steps_per_utt / 2
         step_bytes = algorithmic_bytes_per_step(cfg, B, Lavg)
         step_s = t_ar / (steps_per_utt + 1)
@@ -178,17 +251,22 @@ def main():
             others[name] = {"us_per_launch": round(ms.value * 1e3, 3), "GB/s": round(by.value / (ms.value * 1e-3) / 1e9, 1)}
         result["other_kernels"] = others
         if world == 1 and B == 1 and not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline(w_cpu, cfg, seed, l_c)
+            result["cpu_baseline"] = cpu_baseline(w_cpu, cfg, seed, l_c, max_new)
+    if rank == 0:
         os.write(json_fd, (json.dumps(result) + "\n").encode())
     if dist is not None:
-        dist.barrier(device_ids=[local_rank])
+        fence()
         dist.destroy_process_group()
+    return 0
 
 
-def cpu_baseline(w_cpu, cfg, seed, l_c, max_steps: int = 24, budget_s: float = 25.0):
+def cpu_baseline(w_cpu, cfg, seed, l_c, max_new, ar_steps: int = 128, budget_s: float = 40.0):
     """The CPU oracle (restatement of the reference's torch CPU path, pinned bit-exact against the reference in the
-    build container) timed on this box's host cores on a bounded sample of the same workload: the prefill plus up to
-    `max_steps` decode steps of the same utterance, stopped after `budget_s` seconds."""
+    build container) timed on this box's host cores on a bounded sample of the same workload (SURVEY.md §8d,
+    BASELINE.md §3): the prefill plus `ar_steps` decode steps of the same utterance (stopped early past `budget_s`),
+    then the DAC decode of a [1, 9, max_new] code tensor.  `value` extrapolates the per-step median to the whole
+    utterance: max_new / 86.13 s of audio over (prefill + (max_new + 7) steps + DAC decode)."""
+    import torch
     from oracle import zonos_oracle as zo
     from zonos_amd import synth
     cores = os.cpu_count() or 1
@@ -204,29 +282,58 @@ def cpu_baseline(w_cpu, cfg, seed, l_c, max_steps: int = 24, budget_s: float = 2
 
     def cb(frame, step, max_s):
         stamps.append(time.perf_counter())
-        return len(stamps) <= max_steps and (stamps[-1] - t_start) < budget_s
-    zo.generate(w_cpu, cfg, cond, max_new_tokens=max_steps + 8, sampling_params={"temperature": 0.0}, callback=cb)
+        return len(stamps) <= ar_steps and (stamps[-1] - t_start) < budget_s
+    zo.generate(w_cpu, cfg, cond, max_new_tokens=ar_steps + 8, sampling_params={"temperature": 0.0}, callback=cb)
     deltas = sorted(b - a for a, b in zip(stamps[:-1], stamps[1:])) or [stamps[0] - t_start]
     s_per_step = deltas[len(deltas) // 2]
+    prefill_s = stamps[0] - t_start - s_per_step if len(stamps) > 1 else 0.0
     log(f"cpu baseline: {len(stamps)} decode steps, median {s_per_step * 1e3:.1f} ms/step on {cores} threads")
-    return {"value": round(1.0 / s_per_step / FRAME_RATE, 4), "unit": "audio-sec/sec", "cores": cores, "kind": "port",
+    dac_s, dac_note = None, "DAC decode leg skipped (AR leg used the wall budget)"
+    if time.perf_counter() - t_start < budget_s:
+        dw = synth.dac_state_dict(4321)
+        codes = torch.randint(0, 1024, (1, 9, max_new), generator=torch.Generator().manual_seed(7), dtype=torch.int64)
+        td = time.perf_counter()
+        with torch.no_grad():
+            zo.dac_decode(dw, codes)
+        dac_s = time.perf_counter() - td
+        dac_note = f"DAC decode of [1, 9, {max_new}] in {dac_s:.2f} s (fp32)"
+        log("cpu baseline: " + dac_note)
+    total = max(prefill_s, 0.0) + (max_new + 7) * s_per_step + (dac_s or 0.0)
+    return {"value": round(max_new / FRAME_RATE / total, 4), "unit": "audio-sec/sec", "cores": cores, "kind": "port",
             "sample": f"oracle/zonos_oracle.py generate() on the same utterance: prefill + {len(stamps)} decode steps, median step "
-                      f"{s_per_step * 1e3:.1f} ms (torch CPU bf16, {cores} threads, wall budget {budget_s:g} s); DAC decode not included",
-            "s_per_decode_step": round(s_per_step, 5)}
+                      f"{s_per_step * 1e3:.1f} ms (torch CPU bf16, {cores} threads, wall budget {budget_s:g} s), extrapolated to {max_new + 7} steps; {dac_note}",
+            "s_per_decode_step": round(s_per_step, 5), "dac_decode_s": None if dac_s is None else round(dac_s, 3),
+            "ar_only_audio_sec_per_sec": round(1.0 / s_per_step / FRAME_RATE, 4)}
+
+
+def kernel_source_hash() -> str:
+    h = hashlib.sha256()
+    for rel in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, rel), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
 
 
 def pmc_traffic():
     """HBM bytes per launch of the dominant kernel from the PMC passes (FETCH_SIZE x2 + WRITE_SIZE; separate rocprofv3
-    --pmc runs of tools/pmc_kernel.py, summary committed as profiles/r01_d_pmc_fc1.json); None if not collected."""
+    --pmc runs of tools/pmc_kernel.py, summarised by tools/pmc_summary.py into profiles/pmc_fc1.json).  The summary
+    records the kernel's name and a hash of the kernel sources it was measured on: a summary of another kernel state is
+    refused (traffic = null), never reported."""
     try:
-        return json.load(open(os.path.join(ROOT, "profiles", "r01_d_pmc_fc1.json")))["traffic_bytes_per_launch"]
+        rec = json.load(open(PMC_FILE))
     except Exception:
-        return None
+        return None, "no PMC summary (profiles/pmc_fc1.json)"
+    if rec.get("kernel_source_sha256_16") != kernel_source_hash():
+        return None, f"PMC summary is stale: measured on kernel sources {rec.get('kernel_source_sha256_16')}, current {kernel_source_hash()}"
+    return rec["traffic_bytes_per_launch"], f"{rec.get('kernel_name')}; rocprofv3 --pmc passes of {rec.get('date', '?')}"
 
 
-def log(msg):
-    print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+def main() -> int:
+    args = parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return spawn_ranks(args.gpus, sys.argv[1:])
+    return run_rank(args)
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

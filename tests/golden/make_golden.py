@@ -7,7 +7,7 @@ builds `zonos.model.Zonos` around `TorchZonosBackbone` with the build's syntheti
 real `Zonos.generate()`, of `zonos.sampling`, `zonos.codebook_pattern`, `zonos.backbone._torch` and of
 `transformers.models.dac.DacModel.decode`.  Only data (inputs' seeds + expected outputs) is written.
 
-    python tests/golden/make_golden.py [--only tiny,full,ops,sampling,eos,dac,dacenc,spk]
+    python tests/golden/make_golden.py [--only tiny,full,ops,sampling,eos,dac,dacenc,spk,longfull,tinyb]
 """
 import argparse
 import importlib.machinery
@@ -188,6 +188,21 @@ def main():
             out[f"knew_{L}"] = bf16_bits(kv[:, L - 1, 0])
         np.savez_compressed(f"{HERE}/full_layer0.npz", seed=seed, **out)
         print("ops done")
+
+    if "longfull" in only:
+        # BASELINE config 5's prefill at full dims: a 30 s audio prefix (P = 2584 synthetic codes) + 8 new tokens through the
+        # reference's generate(): prefill logits over 24 + 2585 positions (the batched causal SDPA path), the first loop logits,
+        # tokens.  Takes a few minutes on the build container's CPU cores.
+        cfg, seed = synth.FULL_CFG, 1234
+        if "full" not in only and "ops" not in only:
+            model, sd = build_reference_model(zm, cfg, seed)
+        P = int(os.environ.get("ZN_GOLDEN_PREFIX", "2584"))
+        cond = synth.conditioning(seed, "cond", 2, 24, cfg["d_model"])
+        pre = torch.from_numpy(synth.randint(seed, "longprefix", (1, 9, P), 1024))
+        c = gen_case(zm, model, cond, 8, prefix=pre, keep=(0, 1, 2, 8))
+        c["out"] = c["out"][..., -16:]          # the prefix part of the output is the input
+        np.savez_compressed(f"{HERE}/full_gen_longprefix.npz", seed=seed, l_c=24, max_new=8, prefix_len=P, **c)
+        print("longfull done")
 
     if "peaky" in only:
         # decisive-margin ("peaky" head) variants for free-running greedy parity

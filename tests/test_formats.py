@@ -15,7 +15,7 @@ from zonos_amd.config import ZonosConfig
 from zonos_amd.model import Zonos
 
 
-def _write_checkpoint(tmp_path, cfg, seed):
+def _write_checkpoint(tmp_path, cfg, seed, drop=(), extra=None):
     sd = synth.zonos_state_dict(cfg, seed)
     ck = {}
     for k, v in sd.items():
@@ -26,7 +26,11 @@ def _write_checkpoint(tmp_path, cfg, seed):
             ck[k] = v[:1026].clone()                  # checkpoints carry 1026 rows (1024 + EOS + MASK)
         else:
             ck[k] = v.clone()
-    ck["prefix_conditioner.norm.weight"] = torch.ones(cfg["d_model"], dtype=torch.bfloat16)   # ignored until the conditioner row lands
+    ck["prefix_conditioner.norm.weight"] = torch.ones(cfg["d_model"], dtype=torch.bfloat16)
+    ck["prefix_conditioner.norm.bias"] = torch.zeros(cfg["d_model"], dtype=torch.bfloat16)
+    for k in drop:
+        del ck[k]
+    ck.update(extra or {})
     save_file(ck, str(tmp_path / "model.safetensors"))
     conf = {"backbone": {"d_model": cfg["d_model"], "n_layer": cfg["n_layer"], "attn_mlp_d_intermediate": cfg["d_ff"], "d_intermediate": 0,
                          "ssm_cfg": dict(cfg.get("ssm_cfg") or {}), "attn_layer_idx": list(cfg.get("attn_layer_idx", range(cfg["n_layer"]))),
@@ -59,6 +63,20 @@ def test_from_local_key_contract_cpu(tmp_path):
     (tmp_path / "mamba1.json").write_text(json.dumps(other))
     with pytest.raises(Exception, match="Mamba2"):
         Zonos.from_local(str(tmp_path / "mamba1.json"), str(tmp_path / "model.safetensors"), device="cpu")
+
+
+def test_from_local_refuses_mismatched_checkpoints(tmp_path):
+    """A tensor the model does not know (the reference's strict load fails on it, model.py:174 — e.g. the bias tensors of
+    an attention configuration this backbone does not implement) or a tensor the file lacks is an error, never a silent
+    partial load."""
+    from zonos_amd._lib import ZonosHipError
+    cfg = synth.TINY_CFG
+    _write_checkpoint(tmp_path, cfg, 77, extra={"backbone.layers.0.mixer.in_proj.bias": torch.zeros(8, dtype=torch.bfloat16)})
+    with pytest.raises(ZonosHipError, match="unexpected tensors.*in_proj.bias"):
+        Zonos.from_local(str(tmp_path / "config.json"), str(tmp_path / "model.safetensors"), device="cpu")
+    _write_checkpoint(tmp_path, cfg, 77, drop=("backbone.layers.1.mlp.fc2.weight",))
+    with pytest.raises(ZonosHipError, match="missing tensors.*fc2.weight"):
+        Zonos.from_local(str(tmp_path / "config.json"), str(tmp_path / "model.safetensors"), device="cpu")
 
 
 def test_from_local_hybrid_key_contract_cpu(tmp_path):

@@ -13,6 +13,8 @@ import ctypes as C
 import math
 
 import numpy as np
+import threading
+
 import torch
 
 from . import _lib
@@ -58,6 +60,7 @@ class DACAutoencoder:
         self.hop = int(np.prod(self.cfg["upsampling_ratios"]))
         self._weights: dict | None = None
         self._h = None
+        self._lock = threading.Lock()      # one handle = one workspace: concurrent encode/decode calls queue
         self.device = torch.device(device) if device is not None else None
         if state_dict is not None:
             self.load_state_dict(state_dict, device)
@@ -139,7 +142,7 @@ class DACAutoencoder:
             raise ValueError(f"audio length {T} is not a positive multiple of {self.hop}: call preprocess() first (autoencoder.py:99-100)")
         x = wav.to(device=self.device, dtype=torch.float32).contiguous()
         codes = torch.empty(B, self.num_codebooks, T // self.hop, dtype=torch.int32, device=self.device)
-        with torch.cuda.device(self.device):
+        with self._lock, torch.cuda.device(self.device):
             _lib.check_dac(_lib.load().zn_dac_encode(h, x.data_ptr(), B, T, codes.data_ptr(), _lib.stream_ptr()), h, "zn_dac_encode")
         return codes.to(torch.int64)
 
@@ -152,7 +155,7 @@ class DACAutoencoder:
             raise ValueError(f"expected {self.num_codebooks} codebooks, got {nq}")
         c32 = codes.to(device=self.device, dtype=torch.int32).contiguous()
         wav = torch.empty(B, 1, self.hop * T, dtype=torch.float32, device=self.device)
-        with torch.cuda.device(self.device):
+        with self._lock, torch.cuda.device(self.device):
             _lib.check_dac(_lib.load().zn_dac_decode(h, c32.data_ptr(), B, T, wav.data_ptr(), _lib.stream_ptr()), h, "zn_dac_decode")
         return wav
 

@@ -9,6 +9,7 @@ and `forward(hidden_states[R,S,d], inference_params) -> [R,S,d]`, whose paramete
 from __future__ import annotations
 
 import ctypes as C
+import threading
 
 import torch
 import torch.nn as nn
@@ -145,6 +146,10 @@ class HipEngine:
         w.rope_table = self.rope.data_ptr()
         self.max_rows = max_rows
         self.device = dev
+        # One handle carries all per-generation state (KV pointers, captured graphs, tickets) and zn_* forbids overlapping
+        # calls on it: callers that span several calls (Zonos.generate) hold this lock for the whole section; the reference
+        # serves two concurrent requests per model (utilities/app_constants.py:18), here they queue.
+        self.lock = threading.RLock()
         handle = C.c_void_p()
         with torch.cuda.device(dev):
             _lib.check(self.lib.zn_create(C.byref(zc), C.byref(w), max_rows, C.byref(handle)), None, "zn_create")
@@ -159,7 +164,14 @@ class HipEngine:
             pass
 
     def call(self, name: str, *args):
-        _lib.check(getattr(self.lib, name)(self.h, *args), self.h, name)
+        """One library call, serialised per handle, with the handle's device current (launches, streams and workspace
+        allocations inside the library go to the device the weights live on, whatever the caller's current device)."""
+        with self.lock, torch.cuda.device(self.device):
+            _lib.check(getattr(self.lib, name)(self.h, *args), self.h, name)
+
+    def stream(self) -> int:
+        """The caller's current torch stream on this engine's device."""
+        return torch.cuda.current_stream(self.device).cuda_stream
 
 
 class HipZonosBackbone(nn.Module):
@@ -212,7 +224,7 @@ class HipZonosBackbone(nn.Module):
             raise _lib.ZonosHipError("HipZonosBackbone.forward: the hybrid stack runs through Zonos.generate (device-resident loop) only")
         R, S, d = hidden_states.shape
         eng = self.engine(R + (R & 1))
-        st = _lib.stream_ptr()
+        st = eng.stream()
         lengths = inference_params.lengths_per_sample.to(device=hidden_states.device, dtype=torch.int32).clone()
         out = torch.empty_like(hidden_states)
         qb = 256 if S >= 768 else 64 if S >= 192 else 32      # CPU flash-attention query split

@@ -57,7 +57,7 @@ def _engine_call(mod: nn.Module, name: str, *args):
     eng = mod._zn_engine() if hasattr(mod, "_zn_engine") else None
     if eng is None:
         raise _lib.ZonosHipError("conditioner is not attached to a Zonos model (model.prefix_conditioner)")
-    eng.call(name, *args, _lib.stream_ptr())
+    eng.call(name, *args, eng.stream())
 
 
 class Conditioner(nn.Module):

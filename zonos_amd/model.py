@@ -77,6 +77,7 @@ class Zonos(nn.Module):
         backbone_cls = BACKBONES[backbone] if backbone else DEFAULT_BACKBONE_CLS
         model = cls(config, backbone_cls).to(device, torch.bfloat16)
         sd = model.state_dict()
+        expected, seen = set(sd), set()
         with safetensors.safe_open(model_path, framework="pt") as f:
             for k in f.keys():
                 t = f.get_tensor(k)
@@ -85,7 +86,16 @@ class Zonos(nn.Module):
                     padded[: t.shape[0]] = t
                     t = padded
                 sd[k] = t
-        model.load_state_dict(sd, strict=False)
+                seen.add("fused_heads.weight" if k.startswith("heads.") and k.endswith(".weight") else k)
+        # The reference loads strictly (model.py:174: a tensor the model does not know is an error).  A tensor the file lacks
+        # would stay at its random initialisation there; here it is an error as well: either way a checkpoint that does not
+        # match the configuration (e.g. bias tensors of an attn_cfg this backbone does not implement) never runs silently.
+        unexpected, missing = sorted(seen - expected), sorted(expected - seen)
+        if unexpected or missing:
+            raise _lib.ZonosHipError(f"checkpoint {model_path} does not match the model built from {config_path}: "
+                                     f"unexpected tensors {unexpected[:8]}{'...' if len(unexpected) > 8 else ''}, "
+                                     f"missing tensors {missing[:8]}{'...' if len(missing) > 8 else ''}")
+        model.load_state_dict(sd, strict=True)
         return model
 
     def _load_from_state_dict(self, state_dict, prefix, *args):
@@ -121,7 +131,7 @@ class Zonos(nn.Module):
         eng = self.engine(1)
         flat = codes.permute(0, 2, 1).reshape(B * T, nq).to(device=self.device, dtype=torch.int32).contiguous()
         out = torch.empty(B * T, self.config.backbone.d_model, dtype=torch.bfloat16, device=self.device)
-        eng.call("zn_op_embed", flat.data_ptr(), out.data_ptr(), B * T, _lib.stream_ptr())
+        eng.call("zn_op_embed", flat.data_ptr(), out.data_ptr(), B * T, eng.stream())
         return out.view(B, T, -1)
 
     @torch.inference_mode()
@@ -132,7 +142,7 @@ class Zonos(nn.Module):
         eng = self.engine(1)
         x = hidden_states.reshape(B * S, d).contiguous()
         out = torch.empty(B * S, nq * 1025, dtype=torch.bfloat16, device=x.device)
-        eng.call("zn_op_linear", x.data_ptr(), None, None, self.fused_heads.weight.data_ptr(), out.data_ptr(), B * S, nq * 1025, d, _lib.stream_ptr())
+        eng.call("zn_op_linear", x.data_ptr(), None, None, self.fused_heads.weight.data_ptr(), out.data_ptr(), B * S, nq * 1025, d, eng.stream())
         return out.view(B, S, nq, 1025).transpose(1, 2)
 
     @torch.inference_mode()
@@ -163,6 +173,18 @@ class Zonos(nn.Module):
         `seed` seeds the device Gumbel-max stream (default: drawn from torch's generator)."""
         assert cfg_scale != 1, "TODO: add support for cfg_scale=1"
         dev = self.device
+        if dev.type != "cuda":
+            raise _lib.ZonosHipError("zonos_amd runs on MI355X only: move the model to a cuda device (no CPU fallback)")
+        B = batch_size
+        eng = self.engine(B)
+        # the engine's handle holds this generation's state: concurrent generate() calls on one model queue here
+        with eng.lock, torch.cuda.device(dev):
+            return self._generate_locked(eng, prefix_conditioning, audio_prefix_codes, max_new_tokens, cfg_scale, B, sampling_params, callback,
+                                         seed, _trace)
+
+    def _generate_locked(self, eng, prefix_conditioning, audio_prefix_codes, max_new_tokens, cfg_scale, batch_size, sampling_params, callback, seed,
+                         _trace):
+        dev = self.device
         B, nq = batch_size, self.config.codebook_dimension
         if prefix_conditioning.shape[0] != 2 * B:
             raise ValueError(f"prefix_conditioning must have 2*batch_size={2 * B} rows, got {prefix_conditioning.shape[0]}")
@@ -177,8 +199,7 @@ class Zonos(nn.Module):
         delayed = apply_delay_pattern(codes, self.masked_token_id).contiguous()       # [B, nq, audio_len + nq]
         t_total = delayed.shape[2]
         offset = P + 1
-        eng = self.engine(B)
-        st = _lib.stream_ptr()
+        st = eng.stream()
         if seed is None:
             seed = int(torch.randint(0, 2 ** 62, (1,)).item())
         sp = _sampling_struct(sampling_params, seed)
@@ -238,7 +259,7 @@ class Zonos(nn.Module):
 
     def _step_logits(self, eng: HipEngine, B: int, nq: int) -> torch.Tensor:
         buf = torch.empty(B, nq, 1025, dtype=torch.float32, device=self.device)
-        eng.call("zn_get_step_outputs", buf.data_ptr(), None, _lib.stream_ptr())
+        eng.call("zn_get_step_outputs", buf.data_ptr(), None, eng.stream())
         return buf
 
 

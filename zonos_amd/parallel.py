@@ -44,9 +44,21 @@ def gather_codes(local_codes: list[torch.Tensor], n_utterances: int, pad_value: 
     return out  # type: ignore[return-value]
 
 
-def generate_sharded(generate_fn, conditionings: list[torch.Tensor], gather: bool = True, group=None):
-    """Run `generate_fn(cond) -> int64 [1, n_q, T]` on this rank's share of `conditionings`; optionally gather."""
+def generate_sharded(generate_fn, conditionings: list[torch.Tensor], gather: bool = True, group=None, batch_size: int = 1):
+    """Run `generate_fn` on this rank's share of `conditionings` (each [2, L_c, d] = [cond ‖ uncond] of one utterance);
+    optionally gather.  batch_size == 1: `generate_fn(cond) -> int64 [1, n_q, T]` per utterance.  batch_size > 1: the
+    share runs in groups of up to `batch_size` utterances, `generate_fn(cond [2b, L_c, d], b) -> int64 [b, n_q, T]`
+    with rows [cond_0..cond_{b-1}, uncond_0..uncond_{b-1}] (Zonos.generate's batch layout)."""
     world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
     rank = dist.get_rank(group) if world > 1 else 0
-    mine = [generate_fn(conditionings[i])[0] for i in shard_indices(len(conditionings), rank, world)]
+    share = shard_indices(len(conditionings), rank, world)
+    if batch_size <= 1:
+        mine = [generate_fn(conditionings[i])[0] for i in share]
+    else:
+        mine = []
+        for j in range(0, len(share), batch_size):
+            grp = [conditionings[i] for i in share[j:j + batch_size]]
+            cond = torch.cat([c[0:1] for c in grp] + [c[1:2] for c in grp], dim=0)
+            codes = generate_fn(cond, len(grp))
+            mine.extend(codes[b] for b in range(len(grp)))
     return gather_codes(mine, len(conditionings), group=group) if gather else mine
