@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define ZN_ABI_VERSION 2
+#define ZN_ABI_VERSION 3
 
 enum zn_status {
   ZN_OK = 0,
@@ -132,6 +132,9 @@ int zn_sample_first(zn_handle h, zn_stream stream);
 int zn_decode_steps(zn_handle h, int32_t n, zn_stream stream);
 /* 1 if the decode step is currently replayed as an instantiated hipGraph, 0 if launched kernel by kernel. */
 int zn_graph_active(zn_handle h);
+/* 1 if the decode steps of the generation begun by zn_gen_begin run the persistent per-block chain kernel (batch 1 on a
+ * model whose shapes it serves), 0 if every op is a launch of its own.  Both paths give bit-identical results. */
+int zn_decode_path(zn_handle h);
 /* (remaining_steps <= 0).all() of tensor_ops.py:95,102 — synchronises the stream. */
 int zn_all_stopped(zn_handle h, int32_t* out, zn_stream stream);
 /* Copies the fp32 logits the sampler last consumed ([B, n_codebooks, vocab_head], after CFG and logit bias) and
@@ -150,6 +153,13 @@ int zn_debug_prefill_mode(zn_handle h, int32_t mode);
 int zn_debug_tune(zn_handle h, int32_t key, int32_t value);
 /* Test/benchmark hook: add `bias` to the codebook-0 EOS logit on every step (-inf suppresses EOS so that all
  * max_new_tokens+7 steps run). */
+/* Diagnostic: workgroup 0 of every persistent chain launch records s_memrealtime (100 MHz) stamps of its phases into
+ * stamps_dev [n_layer][32] (NULL = off).  Stamp order per launch: input ready; then per op: results ready, arrived,
+ * all arrived, next input ready; last: end. */
+int zn_debug_chain_stamps(zn_handle h, uint64_t* stamps_dev);
+/* Diagnostic: every decode step copies, per block, the residual stream after the block, the block's attention output and
+ * its rotated queries into trace_dev [n_layer][3][rows][d_model] bf16 (NULL = off). */
+int zn_debug_trace(zn_handle h, void* trace_dev);
 int zn_debug_eos_bias(zn_handle h, float bias);
 
 /* ---------------------------------------------------------------- measurement */

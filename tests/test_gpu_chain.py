@@ -1,0 +1,78 @@
+"""The persistent per-block decode chain (csrc/zn_chain_kernel.h: out_proj -> out_proj + residual -> LayerNorm + fc1 + SiLU gate
+-> fc2 + residual -> next block's LayerNorm + in_proj + RoPE + KV append in ONE launch, in-kernel hand-offs) against
+(a) the CPU oracle and (b) the launches path, which it must reproduce bit for bit: same tiles, same summation order.
+
+Every batch-1 test of tests/test_gpu_decode.py at the Zonos-v0.1 dimensions runs this path too (it is the default there);
+this file adds the smallest configuration the kernel serves, where the oracle can follow a whole generation."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import zonos_oracle as zo
+from zonos_amd import synth
+from zonos_amd.testing import build_model
+
+pytestmark = pytest.mark.gpu
+GREEDY = {"temperature": 0.0}
+
+
+def _run(model, cond, max_new, toks=None, chain=True, prefix=None):
+    eng = model.engine(1)
+    eng.call("zn_debug_tune", 8, 1 if chain else 2)
+    eng.call("zn_debug_eos_bias", float("-inf"))
+    if toks is not None:
+        tk = torch.from_numpy(toks.astype(np.int32)).to("cuda:0").contiguous()
+        eng.call("zn_debug_token_override", tk.data_ptr(), tk.shape[0])
+    try:
+        tr = {"logits": []}
+        out = model.generate(cond.to("cuda:0"), audio_prefix_codes=prefix, max_new_tokens=max_new, sampling_params=GREEDY, _trace=tr)
+        path = eng.lib.zn_decode_path(eng.h)
+    finally:
+        eng.call("zn_debug_token_override", None, 0)
+        eng.call("zn_debug_eos_bias", 0.0)
+        eng.call("zn_debug_tune", 8, 1)
+    return out.cpu(), torch.stack(tr["logits"]).cpu(), path
+
+
+def test_chain_generate_vs_oracle():
+    """d_model 512, three blocks: prefill (batched) + 48 decode steps through the chain kernel, the oracle's token stream
+    fed through the override hook: codes bit-equal, every call's logits within 0.06, decisive argmax equal."""
+    cfg = synth.CHAIN_CFG
+    model, w = build_model(cfg, 55, "cuda:0")
+    cond = synth.conditioning(55, "cond", 2, 9, cfg["d_model"])
+    pre = torch.from_numpy(synth.randint(55, "prefix", (1, 9, 7), 1024))
+    N = 40
+    otr = zo.GenTrace()
+    noeos = lambda s_, l: l.index_fill(2, torch.tensor([1024]), -float("inf"))
+    ref_out = zo.generate(w, cfg, cond, audio_prefix_codes=pre, max_new_tokens=N, sampling_params=GREEDY, trace=otr, logits_hook=noeos)
+    toks = torch.stack(otr.tokens).numpy()
+    out, logits, path = _run(model, cond, N, toks=toks, prefix=pre.to("cuda:0"))
+    assert path == 1, "the chain kernel did not serve this configuration"
+    assert torch.equal(out, ref_out)
+    worst = 0.0
+    for k in range(len(otr.logits)):
+        a, b = logits[k].numpy(), otr.logits[k].numpy()
+        fin = np.isfinite(b)
+        worst = max(worst, float(np.abs(np.where(fin, a - b, 0.0)).max()))
+        t2 = np.sort(np.where(fin, b, -1e30), -1)[..., -2:]
+        dec = (t2[..., 1] - t2[..., 0]) > 0.15
+        assert (np.where(fin, a, -1e30).argmax(-1) == np.where(fin, b, -1e30).argmax(-1))[dec].all(), k
+    print(f"\n[chain, d 512 x 3 blocks, vs oracle] {len(otr.logits)} calls, worst |dlogit| {worst:.4g}")
+    assert worst <= 0.06
+
+
+@pytest.mark.parametrize("which", ["chain512", "full"])
+def test_chain_is_bit_identical_to_the_launches_path(which):
+    """Free-running greedy generation through the chain kernel and through the per-op launches (zn_debug_tune(8, 2)): equal
+    codes and bit-equal logits at every step - at d_model 512 and at the Zonos-v0.1-transformer dimensions (200 steps:
+    8-step graphs, the fused attention launch, hand-offs replayed 26 x 4 x 200 times)."""
+    cfg, seed, n = (synth.CHAIN_CFG, 55, 60) if which == "chain512" else (synth.FULL_CFG, 1234, 200)
+    model, _ = build_model(cfg, seed, "cuda:0")
+    cond = synth.conditioning(seed, "cond", 2, 24, cfg["d_model"])
+    a, la, pa = _run(model, cond, n, chain=True)
+    b, lb, pb = _run(model, cond, n, chain=False)
+    assert (pa, pb) == (1, 0)
+    assert torch.equal(a, b)
+    assert la.shape == lb.shape and torch.equal(la.view(torch.int32), lb.view(torch.int32))
+    a2, la2, _ = _run(model, cond, n, chain=True)           # replay: no state survives a generation (counters, timeout word)
+    assert torch.equal(a, a2) and torch.equal(la.view(torch.int32), la2.view(torch.int32))

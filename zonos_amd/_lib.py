@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libzonos_hip.so")
 
-ZN_ABI_VERSION = 2
+ZN_ABI_VERSION = 3
 
 
 class ZonosHipError(RuntimeError):
@@ -63,6 +63,7 @@ SIGNATURES = {
     "zn_sample_first": (C.c_int, [C.c_void_p, C.c_void_p]),
     "zn_decode_steps": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
     "zn_graph_active": (C.c_int, [C.c_void_p]),
+    "zn_decode_path": (C.c_int, [C.c_void_p]),
     "zn_all_stopped": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.c_void_p]),
     "zn_get_step_outputs": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "zn_debug_force_eos": (C.c_int, [C.c_void_p, C.c_int32]),
@@ -70,6 +71,8 @@ SIGNATURES = {
     "zn_debug_prefill_mode": (C.c_int, [C.c_void_p, C.c_int32]),
     "zn_debug_tune": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
     "zn_debug_eos_bias": (C.c_int, [C.c_void_p, C.c_float]),
+    "zn_debug_chain_stamps": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "zn_debug_trace": (C.c_int, [C.c_void_p, C.c_void_p]),
     "zn_bench_kernel": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_double), C.c_void_p]),
     "zn_op_linear": (C.c_int, [C.c_void_p] + [C.c_void_p] * 5 + [C.c_int32] * 3 + [C.c_void_p]),
     "zn_op_linear_bias": (C.c_int, [C.c_void_p] * 5 + [C.c_int32] * 3 + [C.c_void_p]),

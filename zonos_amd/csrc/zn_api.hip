@@ -2,6 +2,7 @@
 // workspace, launch geometry, hipGraph capture of one decode step.
 #include "../../include/zonos_hip.h"
 #include "zn_decode_kernels.h"
+#include "zn_chain_kernel.h"
 #include "zn_prefill_kernels.h"
 #include "zn_cond_kernels.h"
 #include "zn_mamba_kernels.h"
@@ -33,6 +34,12 @@ struct zn_handle_s {
   bf16_t *res = nullptr, *hn = nullptr, *m_zx = nullptr, *m_xbc = nullptr, *m_y = nullptr, *m_g = nullptr;
   float* m_vg = nullptr;            // [rows][m_d_inner] fp32 y * silu(z) (mamba_ssm_kernel -> out_proj prologue)
   int m_nheads = 0, m_conv_dim = 0, m_d_in_proj = 0;
+  // persistent post-attention chain (zn_chain_kernel.h): hand-off counters [n_layer][4][ZN_CH_CTR_WORDS], intermediate y1
+  unsigned* ch_ctr = nullptr;
+  bf16_t *ch_y1 = nullptr, *ch_x1 = nullptr, *ch_x2 = nullptr;   // y1, x after the attention half, second residual-stream buffer (blocks alternate h->x / ch_x2)
+  bf16_t* dbg_trace = nullptr;               // diagnostic: [n_layer][2][rows * d] copies of (x after the block, attention output) per decode step
+  unsigned long long* ch_stamps = nullptr;   // diagnostic: [n_layer][32] timeline stamps of workgroup 0 (zn_debug_chain_stamps)
+  int ch_variant = 0;          // 0 = shapes do not fit (launches path), 1 = <4,1,8,4,2> (Zonos-v0.1 dims), 2 = <1,1,2,1,1> (d_model 512)
   float* g16_part = nullptr;   // gemm16s_kernel: split-K partial tiles
   int* g16_tickets = nullptr;
   size_t g16_part_bytes = 0;
@@ -57,7 +64,7 @@ struct zn_handle_s {
   int *lengths = nullptr, *codes = nullptr;
   int force_eos_step = -1;
   float eos_bias = 0.f;
-  int tune[12] = {256, 512, 512, 1024, 512, 704, 2, 2, 0, 0, 0, 0};   // target workgroups: in_proj, out_proj, fc1, fc2, heads; [5] longest context of the fused attention launch; [6] > 1: multi-step graphs; [7] > 1: LDS-staged small-M projections; [9]: KV capacity above which the P.V pass splits per block (0 = 1408); [10] = 2: VALU prefill attention; [11] = 2: no in-workgroup-split small-M kernel
+  int tune[12] = {256, 512, 512, 1024, 512, 704, 2, 2, 0, 0, 0, 0};   // target workgroups: in_proj, out_proj, fc1, fc2, heads; [5] longest context of the fused attention launch; [6] > 1: multi-step graphs; [7] > 1: LDS-staged small-M projections; [8] = 1: persistent chain kernel per block instead of five launches (batch 1); [9]: KV capacity above which the P.V pass splits per block (0 = 1408); [10] = 2: VALU prefill attention; [11] = 2: no in-workgroup-split small-M kernel
   const int* tok_override = nullptr;
   int tok_override_calls = 0;
   hipStream_t cap_stream = nullptr;
@@ -113,12 +120,42 @@ static void free_graph(zn_handle h) {
 extern "C" int zn_destroy(zn_handle h) {
   if (!h) return ZN_OK;
   free_graph(h);
-  void* ptrs[] = {h->emb_tables_dev, h->x, h->q, h->o1, h->mbuf, h->nbuf, h->logits_raw, h->last_logits, h->tok_raw, h->scores, h->cmax, h->pv_part, h->pv_tickets, h->pf_x, h->pf_n, h->pf_qkv, h->pf_a, h->pf_u, h->pf_m, h->st, h->remaining, h->stopping, h->res, h->hn, h->m_zx, h->m_xbc, h->m_y, h->m_g, h->m_vg, h->g16_part, h->g16_tickets};
+  void* ptrs[] = {h->emb_tables_dev, h->x, h->q, h->o1, h->mbuf, h->nbuf, h->logits_raw, h->last_logits, h->tok_raw, h->scores, h->cmax, h->pv_part, h->pv_tickets, h->pf_x, h->pf_n, h->pf_qkv, h->pf_a, h->pf_u, h->pf_m, h->st, h->remaining, h->stopping, h->res, h->hn, h->m_zx, h->m_xbc, h->m_y, h->m_g, h->m_vg, h->g16_part, h->g16_tickets, h->ch_ctr, h->ch_y1, h->ch_x1, h->ch_x2};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (h->done_host) (void)hipHostFree(h->done_host);
   if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
   delete h;
   return ZN_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ persistent chain
+#define ZN_CH_GRID 256
+#define ZN_CH_DYN_LDS (64 * 1024)     // unused dynamic LDS on top of the static 33 KB: never two workgroups on one CU
+template <int NCH, int T_OUT, int T_FC1, int T_FC2, int T_IN>
+static bool chain_resident(int n_cus) {
+  int per_cu = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, chain_kernel<NCH, T_OUT, T_FC1, T_FC2, T_IN>, ZN_CH_THREADS, ZN_CH_DYN_LDS) != hipSuccess) {
+    (void)hipGetLastError();
+    return false;
+  }
+  return per_cu >= 1 && n_cus >= ZN_CH_GRID;       // every workgroup of the grid is resident at once (the hand-offs wait on all of them)
+}
+// Which instantiation of chain_kernel serves this model at batch 1 (0 = none: the launches path).
+static int chain_variant_for(const zn_config& c) {
+  if (c.arch != 0 || !c.double_out_proj || c.d_ff != 4 * c.d_model) return 0;
+
+  int dev = 0, n_cus = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) { (void)hipGetLastError(); return 0; }
+  const int G = ZN_CH_GRID, hd = c.d_model / c.n_heads, nqkv = (c.n_heads + 2 * c.n_heads_kv) * hd;
+  if ((c.d_model / 2) % G || c.d_ff % G || (nqkv / 2) % G || nqkv % 2) return 0;
+  const int p_out = c.d_model / 2 / G, p_fc1 = c.d_ff / G, p_in = nqkv / 2 / G;
+  if (p_fc1 * 2 > 64 || p_out * 2 > 64 || p_in * 2 > 64) return 0;                 // one communication-wave lane per (unit, row)
+  auto fits = [&](int t_out, int t_fc1, int t_fc2, int t_in) {
+    return p_out <= ZN_CH_CWAVES * t_out && p_fc1 <= ZN_CH_CWAVES * t_fc1 && p_out <= (ZN_CH_CWAVES / 4) * t_fc2 && p_in <= ZN_CH_CWAVES * t_in;
+  };
+  if (c.d_model == 2048 && fits(1, 8, 4, 2) && chain_resident<4, 1, 8, 4, 2>(n_cus) && chain_resident<4, 1, 8, 4, 0>(n_cus)) return 1;
+  if (c.d_model == 512 && fits(1, 2, 1, 1) && chain_resident<1, 1, 2, 1, 1>(n_cus) && chain_resident<1, 1, 2, 1, 0>(n_cus)) return 2;
+  return 0;
 }
 
 extern "C" int zn_create(const zn_config* cfg, const zn_weights* w, int32_t max_rows, zn_handle* out) {
@@ -172,6 +209,13 @@ extern "C" int zn_create(const zn_config* cfg, const zn_weights* w, int32_t max_
   ZC(hipMalloc(&h->remaining, (R / 2) * sizeof(int)));
   ZC(hipMalloc(&h->stopping, (R / 2) * sizeof(int)));
   ZC(hipHostMalloc(&h->done_host, sizeof(int) * 4));
+  ZC(hipMalloc(&h->ch_ctr, (size_t)c.n_layer * ZN_CH_HANDOFFS * ZN_CH_CTR_WORDS * sizeof(unsigned)));
+  ZC(hipMemset(h->ch_ctr, 0, (size_t)c.n_layer * ZN_CH_HANDOFFS * ZN_CH_CTR_WORDS * sizeof(unsigned)));
+  ZC(hipMalloc(&h->ch_y1, R * c.d_model * 2));
+  ZC(hipMalloc(&h->ch_x1, R * c.d_model * 2));
+  ZC(hipMalloc(&h->ch_x2, R * c.d_model * 2));
+  h->ch_variant = chain_variant_for(c);
+  if (const char* e = getenv("ZN_CHAIN")) if (atoi(e) == 1) h->tune[8] = 1;
   if (max_rows > 4) {
     ZC(hipMalloc(&h->g16_part, ZN_G16_PART_BYTES));
     ZC(hipMalloc(&h->g16_tickets, ZN_G16_MAX_GROUPS * sizeof(int)));
@@ -417,24 +461,26 @@ static int run_attention(zn_handle h, const bf16_t* q, const bf16_t* kv, int max
   return ZN_OK;
 }
 
-// One decode step of block `li` on x [rows][d] in place (_torch.py:307-328).
-static int layer_decode(zn_handle h, int li, bf16_t* x, bf16_t* kv, int max_len, const int* lengths, const int* ext,
-                        int ext_scalar, int rows, hipStream_t s) {
+// LayerNorm -> in_proj -> split -> RoPE(q,k) -> KV append of block `li` (q in h->q, k/v in the cache row lengths[r])
+static int layer_in_proj(zn_handle h, int li, bf16_t* x, bf16_t* kv, int max_len, const int* lengths, int rows, hipStream_t s) {
   const zn_config& c = h->cfg;
   const zn_layer_weights& lw = h->layers[li];
   const int d = c.d_model, hd = h->hd, nq = c.n_heads * hd, nkv = c.n_heads_kv * hd;
+  GemvArgs a{};
+  a.W = (const bf16_t*)lw.in_proj; a.N = nq + 2 * nkv; a.K = d; a.x = x;
+  a.ln_w = (const bf16_t*)lw.norm_w; a.ln_b = (const bf16_t*)lw.norm_b; a.eps = c.norm_eps;
+  a.lengths = lengths; a.hd = hd; a.n_heads = c.n_heads; a.n_heads_kv = c.n_heads_kv;
+  a.q_out = h->q; a.kv = kv; a.rope = h->rope; a.max_len = max_len; a.rope_positions = c.rope_positions;
+  return run_gemv<PRO_LN, EPI_ROPE_KV>(h, a, rows, h->tune[0], s);
+}
+
+// out_proj (-> out_proj again, _torch.py:419-420) -> residual -> LayerNorm -> fc1 -> y * silu(gate) -> fc2 -> residual
+static int layer_post_attention(zn_handle h, int li, bf16_t* x, int rows, hipStream_t s) {
+  const zn_config& c = h->cfg;
+  const zn_layer_weights& lw = h->layers[li];
+  const int d = c.d_model, nq = c.n_heads * h->hd;
   int rc;
-  {  // LayerNorm -> in_proj -> split -> RoPE(q,k) -> KV append
-    GemvArgs a{};
-    a.W = (const bf16_t*)lw.in_proj; a.N = nq + 2 * nkv; a.K = d; a.x = x;
-    a.ln_w = (const bf16_t*)lw.norm_w; a.ln_b = (const bf16_t*)lw.norm_b; a.eps = c.norm_eps;
-    a.lengths = lengths; a.hd = hd; a.n_heads = c.n_heads; a.n_heads_kv = c.n_heads_kv;
-    a.q_out = h->q; a.kv = kv; a.rope = h->rope; a.max_len = max_len; a.rope_positions = c.rope_positions;
-    if ((rc = run_gemv<PRO_LN, EPI_ROPE_KV>(h, a, rows, h->tune[0], s))) return rc;
-  }
-  // KV-cached GQA attention over keys [0, lengths+1) (_torch.py:413-417) -> attention output in h->o1
-  if ((rc = run_attention(h, h->q, kv, max_len, lengths, ext, ext_scalar, h->o1, rows, s))) return rc;
-  {  // out_proj (-> out_proj again, _torch.py:419-420) -> residual
+  {
     GemvArgs a{};
     a.W = (const bf16_t*)lw.out_proj; a.N = d; a.K = nq; a.x = h->o1;
     if (c.double_out_proj) {
@@ -459,6 +505,90 @@ static int layer_decode(zn_handle h, int li, bf16_t* x, bf16_t* kv, int max_len,
     a.W = (const bf16_t*)lw.fc2; a.N = d; a.K = c.d_ff; a.x = h->mbuf; a.resid = x; a.out = x;
     if ((rc = run_gemv<PRO_NONE, EPI_RESID>(h, a, rows, h->tune[3], s))) return rc;
   }
+  return ZN_OK;
+}
+
+// One decode step of block `li` on x [rows][d] in place (_torch.py:307-328), as launches.
+static int layer_decode(zn_handle h, int li, bf16_t* x, bf16_t* kv, int max_len, const int* lengths, const int* ext,
+                        int ext_scalar, int rows, hipStream_t s) {
+  int rc;
+  if ((rc = layer_in_proj(h, li, x, kv, max_len, lengths, rows, s))) return rc;
+  // KV-cached GQA attention over keys [0, lengths+1) (_torch.py:413-417) -> attention output in h->o1
+  if ((rc = run_attention(h, h->q, kv, max_len, lengths, ext, ext_scalar, h->o1, rows, s))) return rc;
+  return layer_post_attention(h, li, x, rows, s);
+}
+
+// The persistent chain serves the step when the model fits an instantiation, at batch 1 (two rows), when selected
+// (zn_debug_tune(8, 1) or ZN_CHAIN=1 in the environment at zn_create; default: the launches path, which is faster today).
+static bool chain_active(zn_handle h, int rows) { return h->ch_variant != 0 && rows == 2 && h->tune[8] == 1; }
+
+// The chain never updates the residual stream in place (zn_chain_kernel.h): block li reads it from one buffer and leaves it
+// in the other.
+static bf16_t* chain_x(zn_handle h, int li) { return (li & 1) ? h->ch_x2 : h->x; }
+
+// Post-attention chain of block `li` plus the in_proj of block li + 1 in ONE launch (zn_chain_kernel.h); x = h->x, the
+// attention output in h->o1, the next block's q in h->q.  The hand-off counters of the layer must be zero.
+static int launch_chain(zn_handle h, int li, const std::vector<const void*>& kv_layers, int max_len, const int* lengths, hipStream_t s) {
+  const zn_config& c = h->cfg;
+  const zn_layer_weights& lw = h->layers[li];
+  const bool last = li + 1 >= c.n_layer;
+  ChainArgs a{};
+  a.W_out = (const bf16_t*)lw.out_proj; a.W_fc1 = (const bf16_t*)lw.fc1; a.W_fc2 = (const bf16_t*)lw.fc2;
+  a.ln2_w = (const bf16_t*)lw.norm2_w; a.ln2_b = (const bf16_t*)lw.norm2_b; a.eps = c.norm_eps; a.F = c.d_ff;
+  a.a = h->o1; a.xin = chain_x(h, li); a.xout = chain_x(h, li + 1); a.x1 = h->ch_x1; a.y1 = h->ch_y1; a.m = h->mbuf;
+  a.ctr = h->ch_ctr + (size_t)li * ZN_CH_HANDOFFS * ZN_CH_CTR_WORDS; a.tmo = &h->st->pad[0];
+  a.stamps = h->ch_stamps ? h->ch_stamps + (size_t)li * 32 : nullptr;
+  if (!last) {
+    const zn_layer_weights& nx = h->layers[li + 1];
+    a.W_in = (const bf16_t*)nx.in_proj; a.lnn_w = (const bf16_t*)nx.norm_w; a.lnn_b = (const bf16_t*)nx.norm_b;
+    a.nqkv = (c.n_heads + 2 * c.n_heads_kv) * h->hd;
+    a.q_out = h->q; a.kv = (bf16_t*)kv_layers[li + 1]; a.rope = h->rope; a.lengths = lengths;
+    a.max_len = max_len; a.hd = h->hd; a.n_heads = c.n_heads; a.n_heads_kv = c.n_heads_kv; a.rope_positions = c.rope_positions;
+  }
+  const dim3 grid(ZN_CH_GRID), block(ZN_CH_THREADS);
+  if (h->ch_variant == 1) {
+    if (last) hipLaunchKernelGGL((chain_kernel<4, 1, 8, 4, 0>), grid, block, ZN_CH_DYN_LDS, s, a);
+    else hipLaunchKernelGGL((chain_kernel<4, 1, 8, 4, 2>), grid, block, ZN_CH_DYN_LDS, s, a);
+  } else {
+    if (last) hipLaunchKernelGGL((chain_kernel<1, 1, 2, 1, 0>), grid, block, ZN_CH_DYN_LDS, s, a);
+    else hipLaunchKernelGGL((chain_kernel<1, 1, 2, 1, 1>), grid, block, ZN_CH_DYN_LDS, s, a);
+  }
+  return ZN_OK;
+}
+
+// All blocks of one decode step on h->x (transformer): launches per op, or in_proj(0) + (attention, chain) per block.
+static int decode_blocks(zn_handle h, const int* ext, int ext_scalar, hipStream_t s) {
+  const zn_config& c = h->cfg;
+  int rc;
+  const size_t tb = (size_t)h->rows * c.d_model * 2;
+  const bool chain = chain_active(h, h->rows);
+  auto trace = [&](int li) {
+    if (!h->dbg_trace) return;
+    (void)hipMemcpyAsync((char*)h->dbg_trace + (size_t)(3 * li) * tb, chain ? chain_x(h, li + 1) : h->x, tb, hipMemcpyDeviceToDevice, s);
+    (void)hipMemcpyAsync((char*)h->dbg_trace + (size_t)(3 * li + 1) * tb, h->o1, tb, hipMemcpyDeviceToDevice, s);
+  };
+  auto trace_q = [&](int li) {      // q of block li, as the attention launch reads it
+    if (h->dbg_trace) (void)hipMemcpyAsync((char*)h->dbg_trace + (size_t)(3 * li + 2) * tb, h->q, tb, hipMemcpyDeviceToDevice, s);
+  };
+  if (!chain) {
+    for (int li = 0; li < c.n_layer; ++li) {
+      if ((rc = layer_in_proj(h, li, h->x, (bf16_t*)h->kv_layers[li], h->max_len, h->lengths, h->rows, s))) return rc;
+      trace_q(li);
+      if ((rc = run_attention(h, h->q, (bf16_t*)h->kv_layers[li], h->max_len, h->lengths, ext, ext_scalar, h->o1, h->rows, s))) return rc;
+      if ((rc = layer_post_attention(h, li, h->x, h->rows, s))) return rc;
+      trace(li);
+    }
+    return ZN_OK;
+  }
+  HIPCHK(h, hipMemsetAsync(h->ch_ctr, 0, (size_t)c.n_layer * ZN_CH_HANDOFFS * ZN_CH_CTR_WORDS * sizeof(unsigned), s));
+  if ((rc = layer_in_proj(h, 0, h->x, (bf16_t*)h->kv_layers[0], h->max_len, h->lengths, h->rows, s))) return rc;
+  for (int li = 0; li < c.n_layer; ++li) {
+    trace_q(li);
+    if ((rc = run_attention(h, h->q, (bf16_t*)h->kv_layers[li], h->max_len, h->lengths, ext, ext_scalar, h->o1, h->rows, s))) return rc;
+    if ((rc = launch_chain(h, li, h->kv_layers, h->max_len, h->lengths, s))) return rc;
+    trace(li);
+  }
+  if (c.n_layer & 1) HIPCHK(h, hipMemcpyAsync(h->x, h->ch_x2, tb, hipMemcpyDeviceToDevice, s));   // odd depth: the stream ends in the second buffer
   return ZN_OK;
 }
 
@@ -593,8 +723,7 @@ static int enqueue_step(zn_handle h, hipStream_t s) {
   if (c.arch == 1) {
     if ((rc = hybrid_token(h, true, s))) return rc;
   } else {
-    for (int li = 0; li < c.n_layer; ++li)
-      if ((rc = layer_decode(h, li, h->x, (bf16_t*)h->kv_layers[li], h->max_len, h->lengths, nullptr, 0, h->rows, s))) return rc;
+    if ((rc = decode_blocks(h, nullptr, 0, s))) return rc;
     if ((rc = heads_logits(h, h->x, h->rows, s))) return rc;
   }
   SampleArgs a = make_sample_args(h, h->sp);
@@ -765,8 +894,7 @@ extern "C" int zn_prefill(zn_handle h, const void* hidden_dev, int32_t S, zn_str
       if (c.arch == 1) {
         if ((rc = hybrid_token(h, p == S - 1, s))) return rc;
       } else {
-        for (int li = 0; li < c.n_layer; ++li)
-          if ((rc = layer_decode(h, li, h->x, (bf16_t*)h->kv_layers[li], h->max_len, h->lengths, nullptr, ext, h->rows, s))) return rc;
+        if ((rc = decode_blocks(h, nullptr, ext, s))) return rc;
       }
       hipLaunchKernelGGL(add_lengths_kernel, dim3(1), dim3(64 > h->rows ? 64 : h->rows), 0, s, h->lengths, h->rows, 1);
     }
@@ -828,14 +956,18 @@ extern "C" int zn_decode_steps(zn_handle h, int32_t n, zn_stream stream) {
   return ZN_OK;
 }
 
+extern "C" int zn_decode_path(zn_handle h) { return (h && h->gen_active && h->cfg.arch == 0 && chain_active(h, h->rows)) ? 1 : 0; }
 extern "C" int zn_graph_active(zn_handle h) { return (h && (h->graph_exec[0] || h->graph_exec[1] || h->graph_exec[2] || h->graph_exec[3])) ? 1 : 0; }
 
 extern "C" int zn_all_stopped(zn_handle h, int32_t* out, zn_stream stream) {
   if (!h || !out) return ZN_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
-  HIPCHK(h, hipMemcpyAsync(h->done_host, &h->st->all_done, sizeof(int), hipMemcpyDeviceToHost, s));
+  // all_done, force_eos_step, eos_bias, pad[0] = the persistent chain's sticky timeout word: one 16-byte copy
+  HIPCHK(h, hipMemcpyAsync(h->done_host, &h->st->all_done, 4 * sizeof(int), hipMemcpyDeviceToHost, s));
   HIPCHK(h, hipStreamSynchronize(s));
   *out = h->done_host[0];
+  if (h->done_host[3] != 0)
+    ZN_FAIL(h, ZN_ERR_HIP, "decode chain: a hand-off wait timed out (%d) - the results of this generation are invalid; zn_debug_tune(8, 2) selects the launches path", h->done_host[3]);
   return ZN_OK;
 }
 
@@ -858,6 +990,16 @@ extern "C" int zn_debug_token_override(zn_handle h, const int32_t* tokens_dev, i
 extern "C" int zn_debug_tune(zn_handle h, int32_t key, int32_t value) {
   if (!h || key < 0 || key >= 12 || value < 1) return ZN_ERR_ARG;
   h->tune[key] = value; free_graph(h);
+  return ZN_OK;
+}
+extern "C" int zn_debug_trace(zn_handle h, void* trace_dev) {
+  if (!h) return ZN_ERR_ARG;
+  h->dbg_trace = (bf16_t*)trace_dev; free_graph(h);
+  return ZN_OK;
+}
+extern "C" int zn_debug_chain_stamps(zn_handle h, uint64_t* stamps_dev) {
+  if (!h) return ZN_ERR_ARG;
+  h->ch_stamps = (unsigned long long*)stamps_dev; free_graph(h);
   return ZN_OK;
 }
 extern "C" int zn_debug_eos_bias(zn_handle h, float bias) { if (!h) return ZN_ERR_ARG; h->eos_bias = bias; return ZN_OK; }

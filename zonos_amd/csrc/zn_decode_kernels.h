@@ -121,6 +121,31 @@ ZN_DEVINL void gemv_epilogue(const GemvArgs& a, int r, int rowA, int rowB, bool 
   }
 }
 
+// nn.LayerNorm pieces with every multiply-add spelled out (fused where written, nowhere else): left to the compiler, the
+// same source line is contracted or packed (v_pk_mul + v_pk_add vs v_fmac) differently from one kernel to the next, and
+// the persistent chain kernel (zn_chain_kernel.h) must reproduce gemv_kernel's statistics bit for bit.
+ZN_DEVINL float ln_sum8(const u32x4 v) {
+  return lo_f(v.x) + hi_f(v.x) + lo_f(v.y) + hi_f(v.y) + lo_f(v.z) + hi_f(v.z) + lo_f(v.w) + hi_f(v.w);
+}
+ZN_DEVINL float ln_sq8(const u32x4 v, float mean, float ss) {
+  float d;
+  d = __fsub_rn(lo_f(v.x), mean); ss = __fmaf_rn(d, d, ss); d = __fsub_rn(hi_f(v.x), mean); ss = __fmaf_rn(d, d, ss);
+  d = __fsub_rn(lo_f(v.y), mean); ss = __fmaf_rn(d, d, ss); d = __fsub_rn(hi_f(v.y), mean); ss = __fmaf_rn(d, d, ss);
+  d = __fsub_rn(lo_f(v.z), mean); ss = __fmaf_rn(d, d, ss); d = __fsub_rn(hi_f(v.z), mean); ss = __fmaf_rn(d, d, ss);
+  d = __fsub_rn(lo_f(v.w), mean); ss = __fmaf_rn(d, d, ss); d = __fsub_rn(hi_f(v.w), mean); ss = __fmaf_rn(d, d, ss);
+  return ss;
+}
+ZN_DEVINL float ln_one(float x, float m, float q, float g, float b) { return __fmaf_rn(__fmul_rn(__fsub_rn(x, m), q), g, b); }
+ZN_DEVINL u32x4 ln_norm8(const u32x4 v, float m, float q, const u32x4 g, const u32x4 b) {
+  u32x4 o;
+  o.x = pack2(ln_one(lo_f(v.x), m, q, lo_f(g.x), lo_f(b.x)), ln_one(hi_f(v.x), m, q, hi_f(g.x), hi_f(b.x)));
+  o.y = pack2(ln_one(lo_f(v.y), m, q, lo_f(g.y), lo_f(b.y)), ln_one(hi_f(v.y), m, q, hi_f(g.y), hi_f(b.y)));
+  o.z = pack2(ln_one(lo_f(v.z), m, q, lo_f(g.z), lo_f(b.z)), ln_one(hi_f(v.z), m, q, hi_f(g.z), hi_f(b.z)));
+  o.w = pack2(ln_one(lo_f(v.w), m, q, lo_f(g.w), lo_f(b.w)), ln_one(hi_f(v.w), m, q, hi_f(g.w), hi_f(b.w)));
+  return o;
+}
+ZN_DEVINL float ln_rstd(float sumsq, float invK, float eps) { return 1.0f / sqrtf(__fmaf_rn(sumsq, invK, eps)); }
+
 // Weight tile of one work unit (two weight rows) held in registers.
 template <int NCH> struct WTile {
   u32x4 a[NCH], b[NCH];
@@ -232,46 +257,26 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs a) {
     for (int r = 0; r < R; ++r) {
       s[r] = 0.f;
 #pragma unroll
-      for (int c = 0; c < NCH; ++c) {
-        const u32x4 v = xr[c][r];
-        s[r] += lo_f(v.x) + hi_f(v.x) + lo_f(v.y) + hi_f(v.y) + lo_f(v.z) + hi_f(v.z) + lo_f(v.w) + hi_f(v.w);
-      }
+      for (int c = 0; c < NCH; ++c) s[r] += ln_sum8(xr[c][r]);
     }
 #pragma unroll
-    for (int r = 0; r < R; ++r) mean[r] = wave_sum(s[r]) * invK;
+    for (int r = 0; r < R; ++r) mean[r] = __fmul_rn(wave_sum(s[r]), invK);
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       ss[r] = 0.f;
 #pragma unroll
       for (int c = 0; c < NCH; ++c) {
-        if (FULL || (c * 64 + lane) * 8 < kw) {
-          const u32x4 v = xr[c][r];
-          float d;
-          d = lo_f(v.x) - mean[r]; ss[r] += d * d; d = hi_f(v.x) - mean[r]; ss[r] += d * d;
-          d = lo_f(v.y) - mean[r]; ss[r] += d * d; d = hi_f(v.y) - mean[r]; ss[r] += d * d;
-          d = lo_f(v.z) - mean[r]; ss[r] += d * d; d = hi_f(v.z) - mean[r]; ss[r] += d * d;
-          d = lo_f(v.w) - mean[r]; ss[r] += d * d; d = hi_f(v.w) - mean[r]; ss[r] += d * d;
-        }
+        if (FULL || (c * 64 + lane) * 8 < kw) ss[r] = ln_sq8(xr[c][r], mean[r], ss[r]);
       }
     }
 #pragma unroll
-    for (int r = 0; r < R; ++r) rstd[r] = 1.0f / sqrtf(wave_sum(ss[r]) * invK + a.eps);
+    for (int r = 0; r < R; ++r) rstd[r] = ln_rstd(wave_sum(ss[r]), invK, a.eps);
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
       const int k = (c * 64 + lane) * 8;
       if (FULL || k < kw) {
-        const u32x4 g = lng[c], b = lnb[c];
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-          const u32x4 v = xr[c][r];
-          const float m = mean[r], q = rstd[r];
-          u32x4 o;
-          o.x = pack2((lo_f(v.x) - m) * q * lo_f(g.x) + lo_f(b.x), (hi_f(v.x) - m) * q * hi_f(g.x) + hi_f(b.x));
-          o.y = pack2((lo_f(v.y) - m) * q * lo_f(g.y) + lo_f(b.y), (hi_f(v.y) - m) * q * hi_f(g.y) + hi_f(b.y));
-          o.z = pack2((lo_f(v.z) - m) * q * lo_f(g.z) + lo_f(b.z), (hi_f(v.z) - m) * q * hi_f(g.z) + hi_f(b.z));
-          o.w = pack2((lo_f(v.w) - m) * q * lo_f(g.w) + lo_f(b.w), (hi_f(v.w) - m) * q * hi_f(g.w) + hi_f(b.w));
-          xr[c][r] = o;
-        }
+        for (int r = 0; r < R; ++r) xr[c][r] = ln_norm8(xr[c][r], mean[r], rstd[r], lng[c], lnb[c]);
       }
     }
   }

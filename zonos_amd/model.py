@@ -246,6 +246,7 @@ class Zonos(nn.Module):
                 break
         if pending:
             eng.call("zn_decode_steps", pending, st)
+        eng.call("zn_all_stopped", C.byref(done), st)      # also surfaces a timed-out in-kernel hand-off of the last steps
         out = revert_delay_pattern(delayed.to(torch.int64)).cpu()     # one device->host copy (model.py:511)
         valid_length = offset - nq
         window = min(50, valid_length // 4)

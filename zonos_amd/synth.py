@@ -169,6 +169,9 @@ HYBRID_TINY_CFG = dict(d_model=128, n_layer=4, num_heads=4, num_heads_kv=2, d_ff
 HYBRID_FULL_CFG = dict(d_model=2048, n_layer=46, num_heads=16, num_heads_kv=4, d_ff=8192, ssm_cfg={"layer": "Mamba2"},
                        attn_layer_idx=[9, 19, 29, 39])
 TINY_CFG = dict(d_model=128, n_layer=2, num_heads=4, num_heads_kv=2, d_ff=256)
+# smallest shape the persistent decode chain (csrc/zn_chain_kernel.h) serves: d_model 512 = one 512-column chunk per weight
+# row, d_ff = 4 d_model, head size 128; three blocks = first, middle (with the next block's in_proj) and last chain launch
+CHAIN_CFG = dict(d_model=512, n_layer=3, num_heads=4, num_heads_kv=2, d_ff=2048)
 FULL_CFG = dict(d_model=2048, n_layer=26, num_heads=16, num_heads_kv=4, d_ff=8192)
 
 
