@@ -59,6 +59,13 @@ typedef struct zn_config {
   int32_t m_d_state;       /* 64 or 128 */
   int32_t m_ngroups;       /* 1 */
   int32_t m_d_conv;        /* 4 */
+  /* ABI 3 - remaining BackboneConfig switches of the hybrid stack (zonos/config.py:80-84, create_block arguments at
+   * _mamba_ssm.py:45-58); arch 0 ignores them (the torch backbone reads none of them). */
+  int32_t rms_norm;         /* 1: every block norm and the final norm are RMSNorm (no mean; the final norm keeps its bias) */
+  int32_t residual_in_fp32; /* 1: the residual stream between blocks is fp32 */
+  int32_t rope_mode;        /* attention layers (mamba_ssm MHA, attn_cfg): 0 = interleaved pairs over the whole head,
+                               1 = half-split (rotary_emb_interleaved = False, the library default and the Zonos-v0.1-hybrid
+                               checkpoint's), 2 = no rotary (rotary_emb_dim = 0) */
 } zn_config;
 
 typedef struct zn_layer_weights { /* bf16; names = _torch.py:278-281,373-374,453-454 */
@@ -76,6 +83,9 @@ typedef struct zn_layer_weights { /* bf16; names = _torch.py:278-281,373-374,453
   const void *m_dt_bias, *m_A_log, *m_D;   /* [nheads], nheads = d_inner / headdim */
   const void *m_norm_w;            /* mixer.norm.weight [d_inner] (RMSNormGated) */
   const void *m_out_proj;          /* [d, d_inner] */
+  /* ABI 3: optional nn.Linear biases of a mamba_ssm MHA layer (attn_cfg qkv_proj_bias / out_proj_bias; NULL = none) */
+  const void *in_proj_bias;        /* [(H+2Hkv)*hd] */
+  const void *out_proj_bias;       /* [d] */
 } zn_layer_weights;
 
 typedef struct zn_weights {
@@ -162,6 +172,15 @@ int zn_debug_chain_stamps(zn_handle h, uint64_t* stamps_dev);
 int zn_debug_trace(zn_handle h, void* trace_dev);
 int zn_debug_eos_bias(zn_handle h, float bias);
 
+/* The backbone plugin seam (zonos/backbone/__init__.py:24-36; TorchZonosBackbone.forward _torch.py:213-238,
+ * MambaSSMZonosBackbone.forward _mamba_ssm.py:88-119): hidden [rows][S][d] -> out [rows][S][d] after the final norm, the
+ * caches advanced by S positions.  caches_dev: host array [n_layer] of device pointers (KV cache of an attention layer,
+ * conv+SSM state buffer of a Mamba2 layer); every row holds `base` keys already (InferenceParams.seqlen_offset ==
+ * lengths_per_sample in every reference call site).  S = 1 runs the decode kernels, S > 1 the batched prefill kernels
+ * (Mamba2 layers: sequence conv + selective scan).  Needs no zn_gen_begin. */
+int zn_op_backbone_forward(zn_handle h, const void* hidden_dev, void* out_dev, const void* const* caches_dev, int32_t max_len,
+                           int32_t base, int32_t S, int32_t rows, zn_stream stream);
+
 /* ---------------------------------------------------------------- measurement */
 /* Average duration (HIP events on `stream`) of one of the decode step's weight-streaming kernels over `iters`
  * launches that cycle through the layers' weights, and its algorithmic bytes per launch (the weight matrix).
@@ -201,9 +220,10 @@ int zn_op_attn_decode(zn_handle h, const void* q_dev, const void* kv_dev, int32_
 int zn_op_attn_prefill(zn_handle h, const void* q_dev, const void* kv_dev, int32_t max_len, void* out_dev, int32_t positions,
                        int32_t rows, zn_stream stream);
 /* mamba_ssm layer_norm_fn(prenorm=True) of the hybrid Block: s = h + res (fp32), res <- bf16(s) in place (res NULL:
- * s = h), out = bf16(LayerNorm(s)).  h/res/out bf16 [rows, d]. */
+ * s = h), out = bf16(LayerNorm(s)).  h/out bf16 [rows, d].  flags bit 0: RMSNorm instead of LayerNorm (rms_norm; b may be
+ * NULL), bit 1: res is float [rows, d] and keeps the unrounded sum (residual_in_fp32). */
 int zn_op_add_layernorm(zn_handle h, const void* hidden, void* res, const void* w, const void* b, void* out, int32_t rows,
-                        int32_t d, float eps, zn_stream stream);
+                        int32_t d, float eps, int32_t flags, zn_stream stream);
 /* One token through the Mamba2 mixer of hybrid layer `layer` (mamba_ssm Mamba2.step): x bf16 [rows, d] (already
  * normalised), state = the layer's zn_mamba_state_bytes_per_layer buffer (updated), out bf16 [rows, d]. */
 int zn_op_mamba_step(zn_handle h, int32_t layer, const void* x, void* state, void* out, int32_t rows, zn_stream stream);

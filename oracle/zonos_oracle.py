@@ -161,11 +161,41 @@ def hybrid_setup_cache(cfg: dict, rows: int, max_len: int) -> Cache:
     return Cache(kv, max_len, 0, torch.zeros(rows, dtype=torch.int32), rope_table(16384, hd))
 
 
-def add_norm(h: torch.Tensor, res, wgt: torch.Tensor, bias: torch.Tensor, eps: float):
-    """Fused residual-add + LayerNorm (mamba_ssm layer_norm_fn, prenorm=True, residual_in_fp32=False): the sum is
-    formed and normalised in fp32; the residual stream keeps its bf16 rounding, the norm sees the unrounded sum."""
+def add_norm(h: torch.Tensor, res, wgt: torch.Tensor, bias, eps: float, rms: bool = False, res32: bool = False):
+    """Fused residual-add + norm (mamba_ssm layer_norm_fn, prenorm=True; _mamba_ssm.py:45-58,111-119): the sum is formed and
+    normalised in fp32; the residual stream keeps its bf16 rounding unless residual_in_fp32 (config.py:83), the norm sees the
+    unrounded sum.  rms (config.py:82): RMSNorm, y = s * rsqrt(mean(s^2) + eps) * w (+ b when the module has one)."""
     s = h.float() if res is None else h.float() + res.float()
-    return F.layer_norm(s, (s.shape[-1],), wgt.float(), bias.float(), eps).to(h.dtype), s.to(h.dtype)
+    if rms:
+        y = s * torch.rsqrt(s.pow(2).mean(-1, keepdim=True) + eps) * wgt.float()
+        if bias is not None:
+            y = y + bias.float()
+    else:
+        y = F.layer_norm(s, (s.shape[-1],), wgt.float(), bias.float(), eps)
+    return y.to(h.dtype), (s if res32 else s.to(h.dtype))
+
+
+def attn_options(cfg: dict) -> dict:
+    """attn_cfg as mamba_ssm's MHA reads it (defaults: rotary_emb_dim 0, rotary_emb_interleaved False, biases True); a hybrid
+    configuration without an "attn_cfg" entry keeps the first restatement's form (interleaved rotary, no biases)."""
+    hd = cfg["d_model"] // cfg["num_heads"]
+    if "attn_cfg" not in cfg:
+        return dict(mode=0, qkv_bias=False, out_bias=False)
+    ac = cfg["attn_cfg"]
+    rot = int(ac.get("rotary_emb_dim", 0))
+    assert rot in (0, hd)
+    mode = 2 if rot == 0 else (0 if ac.get("rotary_emb_interleaved", False) else 1)
+    return dict(mode=mode, qkv_bias=bool(ac.get("qkv_proj_bias", True)), out_bias=bool(ac.get("out_proj_bias", True)))
+
+
+def rotary_half(x: torch.Tensor, cs: torch.Tensor) -> torch.Tensor:
+    """flash_attn apply_rotary with interleaved=False (what mamba_ssm's MHA calls): pairs (i, i + hd/2), cos / sin cached in
+    the activations' dtype (bf16), fp32 arithmetic, one rounding.  x [R, 1, H, hd], cs [R, 1, hd/2, 2] fp32 table rows."""
+    hh = x.shape[-1] // 2
+    cos = cs[..., 0].to(torch.bfloat16).float()[:, :, None, :]
+    sin = cs[..., 1].to(torch.bfloat16).float()[:, :, None, :]
+    x1, x2 = x[..., :hh].float(), x[..., hh:].float()
+    return torch.cat([x1 * cos - x2 * sin, x2 * cos + x1 * sin], dim=-1).to(x.dtype)
 
 
 def mamba2_step(w: dict, p: str, n: torch.Tensor, conv_state: torch.Tensor, ssm_state: torch.Tensor, m: dict, eps: float = 1e-5):
@@ -210,6 +240,9 @@ def hybrid_backbone_forward(w: dict, x: torch.Tensor, cache: Cache, cfg: dict) -
     hd = d // H
     R, S, _ = x.shape
     m = mamba2_dims(cfg)
+    ao = attn_options(cfg)
+    rms, res32 = bool(cfg.get("rms_norm")), bool(cfg.get("residual_in_fp32"))
+    rot = (lambda t, c: rope_apply(t, c)) if ao["mode"] == 0 else (lambda t, c: rotary_half(t, c)) if ao["mode"] == 1 else (lambda t, c: t)
     outs = []
     for s_i in range(S):
         h, res = x[:, s_i], None
@@ -218,26 +251,26 @@ def hybrid_backbone_forward(w: dict, x: torch.Tensor, cache: Cache, cfg: dict) -
         t0 = cache.seqlen_offset + s_i
         for li in range(cfg["n_layer"]):
             p = f"backbone.layers.{li}."
-            n, res = add_norm(h, res, w[p + "norm.weight"], w[p + "norm.bias"], eps)
+            n, res = add_norm(h, res, w[p + "norm.weight"], w.get(p + "norm.bias"), eps, rms, res32)
             if li in cfg["attn_layer_idx"]:
-                # mamba_ssm MHA with interleaved rotary (the convention _torch.py:57-68 shares), single out_proj
-                qkv = F.linear(n, w[p + "mixer.in_proj.weight"])
+                # mamba_ssm MHA (rotary form and biases per attn_cfg), single out_proj
+                qkv = F.linear(n, w[p + "mixer.in_proj.weight"], w.get(p + "mixer.in_proj.bias") if ao["qkv_bias"] else None)
                 q, k, v = qkv.split([H * hd, Hkv * hd, Hkv * hd], dim=-1)
-                q = rope_apply(q.view(R, 1, H, hd), cs)
-                k = rope_apply(k.view(R, 1, Hkv, hd), cs)
+                q = rot(q.view(R, 1, H, hd), cs)
+                k = rot(k.view(R, 1, Hkv, hd), cs)
                 kvc = cache.kv[li]
                 kvc[:R, t0, 0] = k[:, 0]
                 kvc[:R, t0, 1] = v.view(R, Hkv, hd)
                 kk, vv = kvc[:R, :t0 + 1].unbind(dim=-3)
                 a = F.scaled_dot_product_attention(q.transpose(1, 2), kk.transpose(1, 2), vv.transpose(1, 2), enable_gqa=True)
-                h = F.linear(a.transpose(1, 2).reshape(R, H * hd), w[p + "mixer.out_proj.weight"])
-                n2, res = add_norm(h, res, w[p + "norm2.weight"], w[p + "norm2.bias"], eps)
+                h = F.linear(a.transpose(1, 2).reshape(R, H * hd), w[p + "mixer.out_proj.weight"], w.get(p + "mixer.out_proj.bias") if ao["out_bias"] else None)
+                n2, res = add_norm(h, res, w[p + "norm2.weight"], w.get(p + "norm2.bias"), eps, rms, res32)
                 val, gate = F.linear(n2, w[p + "mlp.fc1.weight"]).chunk(2, dim=-1)
                 h = F.linear(val * F.silu(gate), w[p + "mlp.fc2.weight"])
             else:
                 conv_state, ssm_state = cache.kv[li]
                 h = mamba2_step(w, p + "mixer.", n, conv_state[:R], ssm_state[:R], m, eps)
-        out, _ = add_norm(h, res, w["backbone.norm_f.weight"], w["backbone.norm_f.bias"], eps)
+        out, _ = add_norm(h, res, w["backbone.norm_f.weight"], w["backbone.norm_f.bias"], eps, rms, res32)      # norm_f keeps its bias
         outs.append(out)
     return torch.stack(outs, dim=1)
 

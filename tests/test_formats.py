@@ -11,6 +11,7 @@ import torch
 from safetensors.torch import save_file
 
 from zonos_amd import synth
+from zonos_amd.testing import _attn_cfg
 from zonos_amd.config import ZonosConfig
 from zonos_amd.model import Zonos
 
@@ -34,8 +35,9 @@ def _write_checkpoint(tmp_path, cfg, seed, drop=(), extra=None):
     save_file(ck, str(tmp_path / "model.safetensors"))
     conf = {"backbone": {"d_model": cfg["d_model"], "n_layer": cfg["n_layer"], "attn_mlp_d_intermediate": cfg["d_ff"], "d_intermediate": 0,
                          "ssm_cfg": dict(cfg.get("ssm_cfg") or {}), "attn_layer_idx": list(cfg.get("attn_layer_idx", range(cfg["n_layer"]))),
-                         "attn_cfg": {"num_heads": cfg["num_heads"], "num_heads_kv": cfg["num_heads_kv"], "causal": True, "rotary_emb_dim": 32},
-                         "rms_norm": False, "residual_in_fp32": False, "norm_epsilon": 1e-5},
+                         "attn_cfg": ({"num_heads": cfg["num_heads"], "num_heads_kv": cfg["num_heads_kv"], "causal": True, "rotary_emb_dim": 32}
+                                      if not cfg.get("ssm_cfg") else _attn_cfg(cfg)),
+                         "rms_norm": bool(cfg.get("rms_norm", False)), "residual_in_fp32": bool(cfg.get("residual_in_fp32", False)), "norm_epsilon": 1e-5},
             "prefix_conditioner": {"conditioners": [], "projection": "none"},
             "eos_token_id": 1024, "masked_token_id": 1025, "pad_vocab_to_multiple_of": 8}
     (tmp_path / "config.json").write_text(json.dumps(conf))
@@ -63,6 +65,31 @@ def test_from_local_key_contract_cpu(tmp_path):
     (tmp_path / "mamba1.json").write_text(json.dumps(other))
     with pytest.raises(Exception, match="Mamba2"):
         Zonos.from_local(str(tmp_path / "mamba1.json"), str(tmp_path / "model.safetensors"), device="cpu")
+
+
+def test_from_local_hybrid_attn_cfg_forms_cpu(tmp_path):
+    """attn_cfg goes to mamba_ssm's MHA in the reference (_mamba_ssm.py:45-58): its defaults (biases on, no rotary) apply to
+    the keys config.json leaves out.  A checkpoint written for those defaults loads (bias tensors and all); the same
+    checkpoint against a config that switches the biases off is refused; unsupported forms are refused at construction."""
+    from zonos_amd._lib import ZonosHipError
+    cfg = dict(synth.HYBRID_TINY_CFG, attn_cfg={"causal": True}, rms_norm=True, residual_in_fp32=True)    # library defaults otherwise
+    sd = _write_checkpoint(tmp_path, cfg, 79)
+    assert "backbone.layers.2.mixer.in_proj.bias" in sd and "backbone.layers.2.norm.bias" not in sd and "backbone.layers.0.norm.bias" not in sd
+    model = Zonos.from_local(str(tmp_path / "config.json"), str(tmp_path / "model.safetensors"), device="cpu")
+    got = model.state_dict()
+    assert torch.equal(got["backbone.layers.2.mixer.in_proj.bias"], sd["backbone.layers.2.mixer.in_proj.bias"])
+    assert torch.equal(got["backbone.layers.2.mixer.out_proj.bias"], sd["backbone.layers.2.mixer.out_proj.bias"])
+    conf = json.load(open(tmp_path / "config.json"))
+    conf["backbone"]["attn_cfg"]["qkv_proj_bias"] = False
+    (tmp_path / "nobias.json").write_text(json.dumps(conf))
+    with pytest.raises(ZonosHipError, match="unexpected tensors.*in_proj.bias"):
+        Zonos.from_local(str(tmp_path / "nobias.json"), str(tmp_path / "model.safetensors"), device="cpu")
+    for bad in ({"rotary_emb_dim": 16}, {"causal": False}, {"softmax_scale": 0.5}, {"d_conv": 4}, {"window_size": 3}):
+        conf = json.load(open(tmp_path / "config.json"))
+        conf["backbone"]["attn_cfg"].update(bad)
+        (tmp_path / "bad.json").write_text(json.dumps(conf))
+        with pytest.raises(ZonosHipError):
+            Zonos.from_local(str(tmp_path / "bad.json"), str(tmp_path / "model.safetensors"), device="cpu")
 
 
 def test_from_local_refuses_mismatched_checkpoints(tmp_path):

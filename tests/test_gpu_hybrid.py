@@ -38,13 +38,26 @@ def test_add_layernorm_vs_oracle():
             ref_n, ref_res = zo.add_norm(h, res if use_res else None, w, b, 1e-5)
             hd, rd, wd, bd = h.cuda(), res.clone().cuda(), w.cuda(), b.cuda()
             out = torch.empty_like(hd)
-            eng.call("zn_op_add_layernorm", hd.data_ptr(), rd.data_ptr() if use_res else None, wd.data_ptr(), bd.data_ptr(), out.data_ptr(), 4, d, 1e-5, st)
+            eng.call("zn_op_add_layernorm", hd.data_ptr(), rd.data_ptr() if use_res else None, wd.data_ptr(), bd.data_ptr(), out.data_ptr(), 4, d, 1e-5, 0, st)
             torch.cuda.synchronize()
             eq = float((_bits(out.cpu()) == _bits(ref_n)).float().mean())
             print(f"\n[add+LN d={d} res={use_res}] normalised bit-equal {eq:.5f}")
             assert eq > 0.995
             if use_res:
                 assert torch.equal(_bits(rd.cpu()), _bits(ref_res))          # the residual stream is exact (one fp32 add, one rounding)
+        # BackboneConfig.rms_norm / residual_in_fp32 (config.py:82-83): RMSNorm with and without a bias, fp32 residual stream
+        for rms, res32, with_b in ((1, 0, False), (1, 1, True), (0, 1, True)):
+            r32 = res.float() * 1.0009765625 if res32 else res
+            ref_n, ref_res = zo.add_norm(h, r32, w, b if with_b else None, 1e-5, rms=bool(rms), res32=bool(res32))
+            hd, rd, wd, bd = h.cuda(), r32.clone().cuda(), w.cuda(), b.cuda()
+            out = torch.empty_like(hd)
+            eng.call("zn_op_add_layernorm", hd.data_ptr(), rd.data_ptr(), wd.data_ptr(), bd.data_ptr() if with_b else None, out.data_ptr(), 4, d, 1e-5,
+                     rms | (res32 << 1), st)
+            torch.cuda.synchronize()
+            eq = float((_bits(out.cpu()) == _bits(ref_n)).float().mean())
+            print(f"[add+norm d={d} rms={rms} res32={res32} bias={with_b}] normalised bit-equal {eq:.5f}")
+            assert eq > 0.995
+            assert torch.equal(rd.cpu().view(torch.int32) if res32 else _bits(rd.cpu()), ref_res.view(torch.int32) if res32 else _bits(ref_res))
 
 
 GROUPS_CFG = dict(synth.HYBRID_TINY_CFG, ssm_cfg={"layer": "Mamba2", "d_state": 64, "ngroups": 2})   # two B/C groups, two heads each
@@ -101,6 +114,38 @@ def _trace_run(model, cond, max_new, inputs):
     tr["after_step"] = hook
     model.generate(cond.to("cuda:0"), max_new_tokens=max_new, sampling_params=GREEDY, _trace=tr)
     return torch.stack(tr["logits"]).cpu()
+
+
+def test_hybrid_generate_checkpoint_attention_form_batched_prefill():
+    """generate() on the hybrid stack with the attention form recalled for the Zonos-v0.1-hybrid checkpoint (half-split rotary,
+    no biases), a 30-code audio prefix (prefill of 38 positions: sequence conv + selective scan + batched projections) and
+    24 decode steps, teacher-forced on the restatement's inputs: logits within 0.06, decisive argmax equal."""
+    cfg = dict(synth.HYBRID_TINY_CFG, attn_cfg=dict(synth.HYBRID_CKPT_ATTN))
+    model, sd = build_model(cfg, 25, "cuda:0")
+    cond = synth.conditioning(25, "cond", 2, 7, cfg["d_model"])
+    pre = torch.from_numpy(synth.randint(25, "prefix", (1, 9, 30), 1024))
+    max_new = 16
+    tr = zo.GenTrace()
+    zo.generate(sd, dict(cfg), cond, audio_prefix_codes=pre, max_new_tokens=max_new, cfg_scale=2.0, sampling_params=GREEDY, trace=tr)
+    ref = torch.stack(tr.logits).numpy()
+    inp = torch.from_numpy(torch.stack(tr.inputs).numpy().astype(np.int32)).to("cuda:0")
+    rec = {"logits": []}
+
+    def hook(step_idx, delayed, col):
+        k = step_idx + 1
+        if k < inp.shape[0]:
+            delayed[:, :, col] = inp[k]
+    rec["after_step"] = hook
+    model.generate(cond.to("cuda:0"), audio_prefix_codes=pre.to("cuda:0"), max_new_tokens=max_new, sampling_params=GREEDY, _trace=rec)
+    got = torch.stack(rec["logits"]).cpu().numpy()[: len(ref)]
+    fin = np.isfinite(ref)
+    diff = np.abs(np.where(fin, got - ref, 0.0))
+    srt = np.sort(np.where(fin, ref, -np.inf), axis=-1)
+    margin = srt[..., -1] - srt[..., -2]
+    ga, ra = np.where(fin, got, -np.inf).argmax(-1), np.where(fin, ref, -np.inf).argmax(-1)
+    print(f"\n[hybrid, checkpoint attention form, prefix 30] {len(ref)} calls: max|diff| {diff.max():.4g}, argmax equal {float((ga == ra).mean()):.4f}")
+    assert diff.max() <= 0.06
+    assert np.array_equal(ga[margin > 0.12], ra[margin > 0.12])
 
 
 @pytest.mark.parametrize("peaky", [False, True])

@@ -21,12 +21,12 @@ class ZonosHipError(RuntimeError):
 class zn_config(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("d_model", "n_layer", "n_heads", "n_heads_kv", "d_ff", "n_codebooks", "vocab_head",
                                           "vocab_embed", "eos_id", "mask_id", "rope_positions", "double_out_proj")] + [("norm_eps", C.c_float)] + \
-               [(n, C.c_int32) for n in ("arch", "m_d_inner", "m_headdim", "m_d_state", "m_ngroups", "m_d_conv")]
+               [(n, C.c_int32) for n in ("arch", "m_d_inner", "m_headdim", "m_d_state", "m_ngroups", "m_d_conv", "rms_norm", "residual_in_fp32", "rope_mode")]
 
 
 class zn_layer_weights(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("norm_w", "norm_b", "in_proj", "out_proj", "norm2_w", "norm2_b", "fc1", "fc2")] + [("kind", C.c_int32)] + \
-               [(n, C.c_void_p) for n in ("m_in_proj", "m_conv_w", "m_conv_b", "m_dt_bias", "m_A_log", "m_D", "m_norm_w", "m_out_proj")]
+               [(n, C.c_void_p) for n in ("m_in_proj", "m_conv_w", "m_conv_b", "m_dt_bias", "m_A_log", "m_D", "m_norm_w", "m_out_proj", "in_proj_bias", "out_proj_bias")]
 
 
 class zn_weights(C.Structure):
@@ -81,10 +81,11 @@ SIGNATURES = {
     "zn_op_silu": (C.c_int, [C.c_void_p] * 3 + [C.c_int64, C.c_void_p]),
     "zn_op_layernorm": (C.c_int, [C.c_void_p] * 5 + [C.c_int32, C.c_int32, C.c_void_p]),
     "zn_op_layer_decode": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
+    "zn_op_backbone_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "zn_op_attn_prefill": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "zn_op_attn_decode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
     "zn_op_embed": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
-    "zn_op_add_layernorm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_void_p]),
+    "zn_op_add_layernorm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_int32, C.c_void_p]),
     "zn_op_mamba_step": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
     "zn_op_sample": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(zn_sampling), C.c_uint64, C.c_void_p, C.c_void_p,
                                C.c_int32, C.c_void_p]),

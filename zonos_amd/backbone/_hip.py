@@ -28,13 +28,48 @@ def rope_table(n_pos: int, head_dim: int, base: float = 10000.0) -> torch.Tensor
     return torch.stack([z.real, z.imag], dim=-1).contiguous()
 
 
+def attention_options(cfg: BackboneConfig) -> dict:
+    """What `attn_cfg` means for this backbone.  The torch backbone reads only num_heads / num_heads_kv (_torch.py:139-152):
+    interleaved-pair RoPE over the whole head, no biases.  The hybrid stack hands attn_cfg to mamba_ssm's MHA
+    (create_block(..., attn_cfg=config.attn_cfg), _mamba_ssm.py:45-58), whose defaults apply to every key the
+    checkpoint's config.json leaves out: rotary_emb_dim 0 (no rotary), rotary_emb_interleaved False (half-split pairs),
+    qkv_proj_bias / out_proj_bias True.  Forms the kernels do not implement are refused here, never run differently."""
+    ac = dict(cfg.attn_cfg)
+    h, hkv = int(ac["num_heads"]), int(ac.get("num_heads_kv") or ac["num_heads"])
+    hd = cfg.d_model // h
+    if not cfg.ssm_cfg:
+        return dict(num_heads=h, num_heads_kv=hkv, head_dim=hd, rope_mode=0, qkv_bias=False, out_bias=False)
+    known = {"num_heads", "num_heads_kv", "head_dim", "mlp_dim", "qkv_proj_bias", "out_proj_bias", "softmax_scale", "causal", "d_conv",
+             "rotary_emb_dim", "rotary_emb_base", "rotary_emb_interleaved"}
+    unknown = set(ac) - known
+    if unknown:
+        raise _lib.ZonosHipError(f"attn_cfg keys {sorted(unknown)} are not arguments of mamba_ssm's MHA")
+    if ac.get("head_dim") not in (None, hd):
+        raise _lib.ZonosHipError(f"attn_cfg head_dim {ac['head_dim']} != d_model / num_heads = {hd} is not supported")
+    if ac.get("mlp_dim", 0) or ac.get("d_conv", 0):
+        raise _lib.ZonosHipError("attn_cfg mlp_dim / d_conv (MHA with a fused MLP or a conv on qkv) are not supported")
+    if not ac.get("causal", False):
+        raise _lib.ZonosHipError("attn_cfg causal must be true (mamba_ssm's default is false: the decode path has no non-causal form)")
+    scale = ac.get("softmax_scale")
+    if scale is not None and abs(float(scale) - hd ** -0.5) > 1e-9:
+        raise _lib.ZonosHipError("attn_cfg softmax_scale other than 1/sqrt(head_dim) is not supported")
+    rot = int(ac.get("rotary_emb_dim", 0))
+    if rot not in (0, hd):
+        raise _lib.ZonosHipError(f"attn_cfg rotary_emb_dim {rot}: only 0 or head_dim ({hd}) are supported (no partial rotary)")
+    if float(ac.get("rotary_emb_base", 10000.0)) != 10000.0:
+        raise _lib.ZonosHipError("attn_cfg rotary_emb_base other than 10000 is not supported")
+    mode = 2 if rot == 0 else (0 if ac.get("rotary_emb_interleaved", False) else 1)
+    return dict(num_heads=h, num_heads_kv=hkv, head_dim=hd, rope_mode=mode, qkv_bias=bool(ac.get("qkv_proj_bias", True)),
+                out_bias=bool(ac.get("out_proj_bias", True)))
+
+
 class _Mixer(nn.Module):
     def __init__(self, cfg: BackboneConfig):
         super().__init__()
-        h, hkv = cfg.attn_cfg["num_heads"], cfg.attn_cfg["num_heads_kv"]
-        hd = cfg.d_model // h
-        self.in_proj = nn.Linear(cfg.d_model, (h + 2 * hkv) * hd, bias=False)
-        self.out_proj = nn.Linear(h * hd, cfg.d_model, bias=False)
+        o = attention_options(cfg)
+        h, hkv, hd = o["num_heads"], o["num_heads_kv"], o["head_dim"]
+        self.in_proj = nn.Linear(cfg.d_model, (h + 2 * hkv) * hd, bias=o["qkv_bias"])
+        self.out_proj = nn.Linear(h * hd, cfg.d_model, bias=o["out_bias"])
 
 
 class _Mlp(nn.Module):
@@ -78,7 +113,9 @@ class _Block(nn.Module):
     """Parameter container only (names = _torch.py:278-281 / mamba_ssm Block); the math is the HIP kernels'."""
     def __init__(self, cfg: BackboneConfig, layer_idx: int = 0):
         super().__init__()
-        self.norm = nn.LayerNorm(cfg.d_model, eps=cfg.norm_epsilon)
+        rms = bool(cfg.ssm_cfg) and cfg.rms_norm          # mamba_ssm RMSNorm: a weight, no bias (create_block's norm_cls)
+        mk_norm = (lambda: _RmsWeight(cfg.d_model)) if rms else (lambda: nn.LayerNorm(cfg.d_model, eps=cfg.norm_epsilon))
+        self.norm = mk_norm()
         self.is_mamba = bool(cfg.ssm_cfg) and layer_idx not in cfg.attn_layer_idx
         if self.is_mamba:
             self.mixer = _Mamba2Mixer(cfg)
@@ -86,7 +123,7 @@ class _Block(nn.Module):
                 raise _lib.ZonosHipError("Mamba2 layers with an MLP (d_intermediate > 0) are not supported")
         else:
             self.mixer = _Mixer(cfg)
-            self.norm2 = nn.LayerNorm(cfg.d_model, eps=cfg.norm_epsilon)
+            self.norm2 = mk_norm()
             self.mlp = _Mlp(cfg)
 
 
@@ -104,15 +141,21 @@ class HipEngine:
             if p.dtype != torch.bfloat16:
                 raise _lib.ZonosHipError("weights must be bfloat16 (zonos/model.py:158)")
         self.lib = _lib.load()
-        h, hkv = cfg.attn_cfg["num_heads"], cfg.attn_cfg["num_heads_kv"]
+        ao = attention_options(cfg)
+        h, hkv = ao["num_heads"], ao["num_heads_kv"]
         self.head_dim = cfg.d_model // h
-        self.rope = rope_table(ROPE_POSITIONS, self.head_dim).to(dev)
+        rope = rope_table(ROPE_POSITIONS, self.head_dim)
+        if cfg.ssm_cfg and ao["rope_mode"] == 1:
+            # flash_attn's RotaryEmbedding (what mamba_ssm's MHA applies) caches cos / sin in the activations' dtype
+            rope = rope.to(torch.bfloat16).float()
+        self.rope = rope.to(dev)
         zc = _lib.zn_config(d_model=cfg.d_model, n_layer=cfg.n_layer, n_heads=h, n_heads_kv=hkv, d_ff=cfg.attn_mlp_d_intermediate,
                             n_codebooks=n_codebooks, vocab_head=vocab_head, vocab_embed=vocab_embed, eos_id=eos_id, mask_id=mask_id,
                             rope_positions=ROPE_POSITIONS, double_out_proj=int(double_out_proj), norm_eps=cfg.norm_epsilon)
         if cfg.ssm_cfg:   # hybrid: mamba_ssm Block semantics, Mamba2 mixers outside attn_layer_idx
             m = mamba2_dims(cfg)
             zc.arch, zc.double_out_proj = 1, 0
+            zc.rms_norm, zc.residual_in_fp32, zc.rope_mode = int(cfg.rms_norm), int(cfg.residual_in_fp32), ao["rope_mode"]
             zc.m_d_inner, zc.m_headdim, zc.m_d_state, zc.m_ngroups, zc.m_d_conv = m["d_inner"], m["headdim"], m["d_state"], m["ngroups"], m["d_conv"]
         self.zc = zc
         self._keep = [self.rope]
@@ -120,20 +163,30 @@ class HipEngine:
         for i, blk in enumerate(backbone.layers):
             if blk.is_mamba:
                 mx = blk.mixer
-                ts = [blk.norm.weight, blk.norm.bias, mx.in_proj.weight, mx.conv1d.weight, mx.conv1d.bias, mx.dt_bias, mx.A_log, mx.D, mx.norm.weight,
+                nb = getattr(blk.norm, "bias", None)
+                ts = [blk.norm.weight, nb if nb is not None else blk.norm.weight, mx.in_proj.weight, mx.conv1d.weight, mx.conv1d.bias, mx.dt_bias, mx.A_log, mx.D, mx.norm.weight,
                       mx.out_proj.weight]
                 for t in ts:
                     assert t.is_contiguous()
                 lw[i].kind = 1
                 (lw[i].norm_w, lw[i].norm_b, lw[i].m_in_proj, lw[i].m_conv_w, lw[i].m_conv_b, lw[i].m_dt_bias, lw[i].m_A_log, lw[i].m_D, lw[i].m_norm_w,
                  lw[i].m_out_proj) = [t.data_ptr() for t in ts]
+                if nb is None:
+                    lw[i].norm_b = None                      # RMSNorm: no bias
                 self._keep += ts
                 continue
-            ts = [blk.norm.weight, blk.norm.bias, blk.mixer.in_proj.weight, blk.mixer.out_proj.weight, blk.norm2.weight, blk.norm2.bias,
-                  blk.mlp.fc1.weight, blk.mlp.fc2.weight]
+            nb, nb2 = getattr(blk.norm, "bias", None), getattr(blk.norm2, "bias", None)
+            ts = [blk.norm.weight, nb if nb is not None else blk.norm.weight, blk.mixer.in_proj.weight, blk.mixer.out_proj.weight, blk.norm2.weight,
+                  nb2 if nb2 is not None else blk.norm2.weight, blk.mlp.fc1.weight, blk.mlp.fc2.weight]
             for t in ts:
                 assert t.is_contiguous()
             (lw[i].norm_w, lw[i].norm_b, lw[i].in_proj, lw[i].out_proj, lw[i].norm2_w, lw[i].norm2_b, lw[i].fc1, lw[i].fc2) = [t.data_ptr() for t in ts]
+            if nb is None:
+                lw[i].norm_b, lw[i].norm2_b = None, None
+            for name, lin in (("in_proj_bias", blk.mixer.in_proj), ("out_proj_bias", blk.mixer.out_proj)):
+                if lin.bias is not None:
+                    setattr(lw[i], name, lin.bias.data_ptr())
+                    ts.append(lin.bias)
             self._keep += ts
         w = _lib.zn_weights()
         if embeddings is not None:
@@ -180,8 +233,10 @@ class HipZonosBackbone(nn.Module):
     def __init__(self, config: BackboneConfig):
         if config.ssm_cfg and config.ssm_cfg.get("layer", "Mamba1") != "Mamba2":
             raise _lib.ZonosHipError("only ssm_cfg layer = 'Mamba2' is supported (the Zonos hybrid checkpoints' mixer)")
-        if config.rms_norm or config.residual_in_fp32:
-            raise _lib.ZonosHipError("rms_norm / residual_in_fp32 backbones are not supported (Zonos checkpoints use neither)")
+        if not config.ssm_cfg and (config.rms_norm or config.residual_in_fp32):
+            # the torch backbone never reads these fields (_torch.py:130-156 builds nn.LayerNorm blocks unconditionally)
+            pass
+        attention_options(config)          # refuses attn_cfg forms the kernels do not implement
         super().__init__()
         self.config = config
         self.layers = nn.ModuleList(_Block(config, i) for i in range(config.n_layer))
@@ -218,25 +273,27 @@ class HipZonosBackbone(nn.Module):
 
     @torch.inference_mode()
     def forward(self, hidden_states: torch.Tensor, inference_params: InferenceParams) -> torch.Tensor:
-        """_torch.py:213-238.  Position by position through the decode kernels; KV is appended at
-        lengths_per_sample + s (== seqlen_offset + s in every reference call site)."""
-        if self.config.ssm_cfg:
-            raise _lib.ZonosHipError("HipZonosBackbone.forward: the hybrid stack runs through Zonos.generate (device-resident loop) only")
+        """_torch.py:213-238 / _mamba_ssm.py:88-119: hidden [R, S, d] -> [R, S, d] after the final norm, the caches advanced by S
+        positions written at inference_params.seqlen_offset (== lengths_per_sample in every reference call site).  S > 1
+        runs the batched prefill kernels (Mamba2 layers: sequence conv + selective scan), S == 1 the decode kernels."""
         R, S, d = hidden_states.shape
         eng = self.engine(R + (R & 1))
-        st = eng.stream()
-        lengths = inference_params.lengths_per_sample.to(device=hidden_states.device, dtype=torch.int32).clone()
-        out = torch.empty_like(hidden_states)
-        qb = 256 if S >= 768 else 64 if S >= 192 else 32      # CPU flash-attention query split (DESIGN.md)
         base = int(inference_params.seqlen_offset)
-        for s in range(S):
-            x = hidden_states[:, s].contiguous()
-            ext = torch.full((R,), base + min((s // qb) * qb + qb, S), dtype=torch.int32, device=x.device)
-            for li in range(self.config.n_layer):
-                kv = inference_params.key_value_memory_dict[li][0]
-                eng.call("zn_op_layer_decode", li, x.data_ptr(), kv.data_ptr(), kv.shape[1], lengths.data_ptr(), ext.data_ptr(), R, st)
-            y = torch.empty_like(x)
-            eng.call("zn_op_layernorm", x.data_ptr(), self.norm_f.weight.data_ptr(), self.norm_f.bias.data_ptr(), y.data_ptr(), R, d, st)
-            out[:, s] = y
-            lengths += 1
+        lens = inference_params.lengths_per_sample
+        if lens is not None and not bool((lens == base).all()):
+            raise _lib.ZonosHipError("HipZonosBackbone.forward: lengths_per_sample must equal seqlen_offset for every row")
+        caches, max_len = [], int(inference_params.max_seqlen)
+        for li, blk in enumerate(self.layers):
+            c0 = inference_params.key_value_memory_dict[li][0]
+            caches.append(c0.data_ptr())           # KV cache, or the start of the Mamba2 layer's (conv, ssm) state buffer
+            if not blk.is_mamba:
+                max_len = c0.shape[1]
+                if c0.shape[0] != R:
+                    raise _lib.ZonosHipError(f"KV cache holds {c0.shape[0]} rows, hidden_states {R}")
+            elif c0.shape[0] != R:
+                raise _lib.ZonosHipError(f"Mamba2 state holds {c0.shape[0]} rows, hidden_states {R}")
+        ptrs = (C.c_void_p * len(caches))(*caches)
+        x = hidden_states.to(torch.bfloat16).contiguous()
+        out = torch.empty_like(x)
+        eng.call("zn_op_backbone_forward", x.data_ptr(), out.data_ptr(), ptrs, max_len, base, S, R, eng.stream())
         return out

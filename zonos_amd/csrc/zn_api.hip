@@ -49,7 +49,11 @@ struct zn_handle_s {
   float* pv_part = nullptr;    // split P.V pass: partials per (row, kv head, slice, block)
   int* pv_tickets = nullptr;
   bf16_t *pf_x = nullptr, *pf_n = nullptr, *pf_qkv = nullptr, *pf_a = nullptr, *pf_u = nullptr, *pf_m = nullptr;   // batched-prefill workspace
+  // hybrid batched prefill: residual stream (bf16, or fp32 with residual_in_fp32), in_proj output, conv output, scan output, gated-normalised
+  bf16_t *pf_res = nullptr, *pf_zx = nullptr, *pf_xbc = nullptr, *pf_y = nullptr, *pf_g = nullptr;
   size_t pf_rows = 0;
+  int* fw_lengths = nullptr;   // [max_rows] positions of zn_op_backbone_forward's rows
+  bf16_t* qkv_tmp = nullptr;   // [rows][(H + 2 Hkv) hd]: in_proj output of an attention layer whose RoPE / bias form the fused epilogue does not cover
   int prefill_mode = 1;     // 1 = batched (MFMA GEMMs + tiled attention), 0 = position by position through the decode kernels
   int lcap = 0;
   GenState* st = nullptr;
@@ -120,7 +124,7 @@ static void free_graph(zn_handle h) {
 extern "C" int zn_destroy(zn_handle h) {
   if (!h) return ZN_OK;
   free_graph(h);
-  void* ptrs[] = {h->emb_tables_dev, h->x, h->q, h->o1, h->mbuf, h->nbuf, h->logits_raw, h->last_logits, h->tok_raw, h->scores, h->cmax, h->pv_part, h->pv_tickets, h->pf_x, h->pf_n, h->pf_qkv, h->pf_a, h->pf_u, h->pf_m, h->st, h->remaining, h->stopping, h->res, h->hn, h->m_zx, h->m_xbc, h->m_y, h->m_g, h->m_vg, h->g16_part, h->g16_tickets, h->ch_ctr, h->ch_y1, h->ch_x1, h->ch_x2};
+  void* ptrs[] = {h->emb_tables_dev, h->x, h->q, h->o1, h->mbuf, h->nbuf, h->logits_raw, h->last_logits, h->tok_raw, h->scores, h->cmax, h->pv_part, h->pv_tickets, h->pf_x, h->pf_n, h->pf_qkv, h->pf_a, h->pf_u, h->pf_m, h->pf_res, h->pf_zx, h->pf_xbc, h->pf_y, h->pf_g, h->qkv_tmp, h->fw_lengths, h->st, h->remaining, h->stopping, h->res, h->hn, h->m_zx, h->m_xbc, h->m_y, h->m_g, h->m_vg, h->g16_part, h->g16_tickets, h->ch_ctr, h->ch_y1, h->ch_x1, h->ch_x2};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (h->done_host) (void)hipHostFree(h->done_host);
   if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
@@ -180,15 +184,15 @@ extern "C" int zn_create(const zn_config* cfg, const zn_weights* w, int32_t max_
         c.m_d_inner / c.m_ngroups > 8192)
       ZN_FAIL((zn_handle) nullptr, ZN_ERR_UNSUPPORTED, "Mamba2: d_inner %d / ngroups %d not supported", c.m_d_inner, c.m_ngroups);
   }
+  if (c.rope_mode < 0 || c.rope_mode > 2) ZN_FAIL((zn_handle) nullptr, ZN_ERR_ARG, "zn_create: rope_mode must be 0, 1 or 2");
   zn_handle h = new zn_handle_s();
   h->cfg = c; h->max_rows = max_rows; h->hd = hd; h->G = G;
   if (c.arch == 1) {
     h->m_nheads = c.m_d_inner / c.m_headdim;
     h->m_conv_dim = c.m_d_inner + 2 * c.m_ngroups * c.m_d_state;
     h->m_d_in_proj = 2 * c.m_d_inner + 2 * c.m_ngroups * c.m_d_state + h->m_nheads;
-    h->prefill_mode = 0;   // hybrid: position by position (the library's chunked scan is the same recurrence)
   }
-  if (const char* e = getenv("ZN_PREFILL_MODE")) if (c.arch == 0) h->prefill_mode = atoi(e);
+  if (const char* e = getenv("ZN_PREFILL_MODE")) h->prefill_mode = atoi(e);
   h->layers.assign(w->layers, w->layers + c.n_layer);
   h->heads = w->heads; h->norm_f_w = w->norm_f_w; h->norm_f_b = w->norm_f_b; h->rope = w->rope_table;
 #define ZC(call) do { hipError_t _e = (call); if (_e != hipSuccess) { g_create_err = std::string(#call) + ": " + hipGetErrorString(_e); zn_destroy(h); return ZN_ERR_HIP; } } while (0)
@@ -204,6 +208,7 @@ extern "C" int zn_create(const zn_config* cfg, const zn_weights* w, int32_t max_
   ZC(hipMalloc(&h->logits_raw, R * c.n_codebooks * c.vocab_head * sizeof(float)));
   ZC(hipMalloc(&h->last_logits, (R / 2) * c.n_codebooks * c.vocab_head * sizeof(float)));
   ZC(hipMalloc(&h->tok_raw, (R / 2) * c.n_codebooks * sizeof(int)));
+  ZC(hipMalloc(&h->fw_lengths, R * sizeof(int)));
   ZC(hipMalloc(&h->st, sizeof(GenState)));
   ZC(hipMemset(h->st, 0, sizeof(GenState)));
   ZC(hipMalloc(&h->remaining, (R / 2) * sizeof(int)));
@@ -223,7 +228,8 @@ extern "C" int zn_create(const zn_config* cfg, const zn_weights* w, int32_t max_
     h->g16_part_bytes = ZN_G16_PART_BYTES;
   }
   if (c.arch == 1) {
-    ZC(hipMalloc(&h->res, R * c.d_model * 2));
+    ZC(hipMalloc(&h->res, R * c.d_model * 4));     // bf16, or fp32 with residual_in_fp32
+    ZC(hipMalloc(&h->qkv_tmp, R * (size_t)(c.n_heads + 2 * c.n_heads_kv) * hd * 2));
     ZC(hipMalloc(&h->hn, R * c.d_model * 2));
     ZC(hipMalloc(&h->m_zx, R * h->m_d_in_proj * 2));
     ZC(hipMalloc(&h->m_xbc, R * h->m_conv_dim * 2));
@@ -601,11 +607,12 @@ static int heads_logits(zn_handle h, const bf16_t* x, int rows, hipStream_t s) {
 }
 
 // ------------------------------------------------------------------------------------------------ hybrid backbone
-static void launch_add_ln(const bf16_t* hid, bf16_t* res, int has_res, int write_res, const void* w, const void* b, bf16_t* out, int rows,
-                          int d, float eps, hipStream_t s) {
+// fused residual add + norm of the mamba_ssm Block over `rows` rows; the norm kind and the residual's type follow the config
+static void launch_add_ln(zn_handle h, const bf16_t* hid, bf16_t* res, int has_res, int write_res, const void* w, const void* b, bf16_t* out, int rows,
+                          hipStream_t s) {
   AddLnArgs a{};
-  a.h = hid; a.res = res; a.w = (const bf16_t*)w; a.b = (const bf16_t*)b; a.out = out; a.d = d; a.has_res = has_res; a.write_res = write_res;
-  a.eps = eps;
+  a.h = hid; a.res = res; a.w = (const bf16_t*)w; a.b = (const bf16_t*)b; a.out = out; a.d = h->cfg.d_model; a.has_res = has_res; a.write_res = write_res;
+  a.eps = h->cfg.norm_eps; a.rms = h->cfg.rms_norm; a.res32 = h->cfg.residual_in_fp32;
   hipLaunchKernelGGL(add_ln_kernel, dim3(rows), dim3(256), 0, s, a);
 }
 
@@ -659,22 +666,28 @@ static int hybrid_layer(zn_handle h, int li, void* cache, int max_len, const int
   int rc;
   // (the add + LayerNorm as a prologue of the GEMV that consumes it - every workgroup repeating it, the residual
   // ping-ponging between two buffers - was measured slower than this launch: batch-1 step 1.17 -> 1.24 ms)
-  launch_add_ln(h->x, h->res, li > 0, 1, lw.norm_w, lw.norm_b, h->hn, rows, d, c.norm_eps, s);
+  launch_add_ln(h, h->x, h->res, li > 0, 1, lw.norm_w, lw.norm_b, h->hn, rows, s);
   if (lw.kind == 1) return mamba_mixer(h, li, h->hn, cache, h->x, rows, s);
-  {  // MHA: in_proj -> split -> interleaved RoPE(q,k) -> KV append
+  if (c.rope_mode == 0 && !lw.in_proj_bias) {  // MHA: in_proj -> split -> interleaved RoPE(q,k) -> KV append, one launch
     GemvArgs a{};
     a.W = (const bf16_t*)lw.in_proj; a.N = nq + 2 * nkv; a.K = d; a.x = h->hn;
     a.lengths = lengths; a.hd = hd; a.n_heads = c.n_heads; a.n_heads_kv = c.n_heads_kv;
     a.q_out = h->q; a.kv = (bf16_t*)cache; a.rope = h->rope; a.max_len = max_len; a.rope_positions = c.rope_positions;
     if ((rc = run_gemv<PRO_NONE, EPI_ROPE_KV>(h, a, rows, h->tune[0], s))) return rc;
+  } else {   // the other attn_cfg forms (half-split or no rotary, qkv bias): projection (+ bias), then rotation + KV append
+    GemvArgs a{};
+    a.W = (const bf16_t*)lw.in_proj; a.N = nq + 2 * nkv; a.K = d; a.x = h->hn; a.out = h->qkv_tmp; a.bias = (const bf16_t*)lw.in_proj_bias;
+    if ((rc = run_gemv<PRO_NONE, EPI_STORE>(h, a, rows, h->tune[0], s))) return rc;
+    hipLaunchKernelGGL(rope_kv_any_kernel, dim3(1, rows), dim3(256), 0, s, h->qkv_tmp, h->q, nq, (bf16_t*)cache, h->rope, 1, 0, lengths, max_len,
+                       c.n_heads, c.n_heads_kv, hd, c.rope_positions, c.rope_mode);
   }
   if ((rc = run_attention(h, h->q, (const bf16_t*)cache, max_len, lengths, nullptr, 0, h->o1, rows, s))) return rc;
   {
     GemvArgs a{};
-    a.W = (const bf16_t*)lw.out_proj; a.N = d; a.K = nq; a.x = h->o1; a.out = h->x;
+    a.W = (const bf16_t*)lw.out_proj; a.N = d; a.K = nq; a.x = h->o1; a.out = h->x; a.bias = (const bf16_t*)lw.out_proj_bias;
     if ((rc = run_gemv<PRO_NONE, EPI_STORE>(h, a, rows, h->tune[1], s))) return rc;
   }
-  launch_add_ln(h->x, h->res, 1, 1, lw.norm2_w, lw.norm2_b, h->hn, rows, d, c.norm_eps, s);
+  launch_add_ln(h, h->x, h->res, 1, 1, lw.norm2_w, lw.norm2_b, h->hn, rows, s);
   {
     GemvArgs a{};
     a.W = (const bf16_t*)lw.fc1; a.N = 2 * c.d_ff; a.K = d; a.x = h->hn; a.out = h->mbuf;
@@ -688,14 +701,22 @@ static int hybrid_layer(zn_handle h, int li, void* cache, int max_len, const int
   return ZN_OK;
 }
 
-// All layers for the token in h->x, then the final add + LayerNorm (_mamba_ssm.py:111-119) and the heads.
+// final add + norm (_mamba_ssm.py:111-119) of the token in h->x / h->res, then the heads
+static int hybrid_heads(zn_handle h, hipStream_t s);
+
+// All layers for the token in h->x, then the final add + LayerNorm and the heads.
 static int hybrid_token(zn_handle h, bool want_logits, hipStream_t s) {
   const zn_config& c = h->cfg;
   int rc;
   for (int li = 0; li < c.n_layer; ++li)
     if ((rc = hybrid_layer(h, li, (void*)h->kv_layers[li], h->max_len, h->lengths, h->rows, s))) return rc;
   if (!want_logits) return ZN_OK;
-  launch_add_ln(h->x, h->res, 1, 0, h->norm_f_w, h->norm_f_b, h->hn, h->rows, c.d_model, c.norm_eps, s);
+  return hybrid_heads(h, s);
+}
+
+static int hybrid_heads(zn_handle h, hipStream_t s) {
+  const zn_config& c = h->cfg;
+  launch_add_ln(h, h->x, h->res, 1, 0, h->norm_f_w, h->norm_f_b, h->hn, h->rows, s);
   GemvArgs a{};
   a.W = (const bf16_t*)h->heads; a.N = c.n_codebooks * c.vocab_head; a.K = c.d_model; a.x = h->hn; a.out_f32 = h->logits_raw;
   return run_gemv<PRO_NONE, EPI_F32>(h, a, h->rows, h->tune[4], s);
@@ -780,7 +801,8 @@ extern "C" int zn_gen_begin(zn_handle h, int32_t batch, const void* const* kv_la
 static int ensure_prefill_ws(zn_handle h, size_t M) {
   if (M <= h->pf_rows) return ZN_OK;
   const zn_config& c = h->cfg;
-  for (bf16_t** p : {&h->pf_x, &h->pf_n, &h->pf_qkv, &h->pf_a, &h->pf_u, &h->pf_m}) if (*p) { (void)hipFree(*p); *p = nullptr; }
+  for (bf16_t** p : {&h->pf_x, &h->pf_n, &h->pf_qkv, &h->pf_a, &h->pf_u, &h->pf_m, &h->pf_res, &h->pf_zx, &h->pf_xbc, &h->pf_y, &h->pf_g})
+    if (*p) { (void)hipFree(*p); *p = nullptr; }
   h->pf_rows = 0;
   const size_t nqkv = (size_t)(c.n_heads + 2 * c.n_heads_kv) * h->hd;
   HIPCHK(h, hipMalloc(&h->pf_x, M * c.d_model * 2));
@@ -789,12 +811,20 @@ static int ensure_prefill_ws(zn_handle h, size_t M) {
   HIPCHK(h, hipMalloc(&h->pf_a, M * (size_t)c.n_heads * h->hd * 2));
   HIPCHK(h, hipMalloc(&h->pf_u, M * 2 * (size_t)c.d_ff * 2));
   HIPCHK(h, hipMalloc(&h->pf_m, M * (size_t)c.d_ff * 2));
+  if (c.arch == 1) {
+    HIPCHK(h, hipMalloc(&h->pf_res, M * c.d_model * 4));
+    HIPCHK(h, hipMalloc(&h->pf_zx, M * (size_t)h->m_d_in_proj * 2));
+    HIPCHK(h, hipMalloc(&h->pf_xbc, M * (size_t)h->m_conv_dim * 2));
+    HIPCHK(h, hipMalloc(&h->pf_y, M * (size_t)c.m_d_inner * 2));
+    HIPCHK(h, hipMalloc(&h->pf_g, M * (size_t)c.m_d_inner * 2));
+  }
   h->pf_rows = M;
   return ZN_OK;
 }
 
-static void launch_gemm(const bf16_t* A, int lda, const bf16_t* W, bf16_t* out, int ldo, const bf16_t* resid, int M, int N, int K, hipStream_t s) {
-  GemmArgs g{A, W, out, resid, M, N, K, lda, ldo};
+static void launch_gemm(const bf16_t* A, int lda, const bf16_t* W, bf16_t* out, int ldo, const bf16_t* resid, int M, int N, int K, hipStream_t s,
+                        const bf16_t* bias = nullptr) {
+  GemmArgs g{A, W, out, resid, M, N, K, lda, ldo, bias};
   dim3 grid((N + 127) / 128, (M + 127) / 128);
   if (M >= 256 && K % ZN_PG_KC == 0 && lda % 8 == 0) {   // long prompts: LDS-staged panels (coalesced row pieces)
     if (resid) hipLaunchKernelGGL((gemm_bf16s_kernel<1>), grid, dim3(256), 0, s, g);
@@ -831,11 +861,11 @@ static int qsplit(int S) { return S >= 768 ? 256 : S >= 192 ? 64 : 32; }   // qu
 // All S positions at once: row-wise kernels over M = R*S rows, MFMA GEMMs, tiled exact causal attention.
 // causal attention of S prefill positions over the keys already written for them (SDPA is_causal=True, _torch.py:415)
 static int prefill_attention(zn_handle h, const bf16_t* q, int ldq, const bf16_t* kv, int max_len, bf16_t* out, int ldo, int S, int R,
-                             hipStream_t s) {
+                             hipStream_t s, int base = 0) {
   const zn_config& c = h->cfg;
   const int hd = h->hd;
   PrefillAttnArgs pa{};
-  pa.q = q; pa.ldq = ldq; pa.kv = kv; pa.out = out; pa.ldo = ldo; pa.S = S; pa.base = 0; pa.max_len = max_len;
+  pa.q = q; pa.ldq = ldq; pa.kv = kv; pa.out = out; pa.ldo = ldo; pa.S = S; pa.base = base; pa.max_len = max_len;
   pa.n_heads = c.n_heads; pa.n_heads_kv = c.n_heads_kv; pa.qsplit = qsplit(S); pa.scale = (float)(1.0 / std::sqrt((double)hd));
   const bool mfma = h->tune[10] != 2;   // tune[10] = 2: the VALU kernel at every head size
   int r2 = hd == 128 ? launch_prefill_attn<128>(pa, h->G, R, mfma, s) : hd == 64 ? launch_prefill_attn<64>(pa, h->G, R, mfma, s) : launch_prefill_attn<32>(pa, h->G, R, mfma, s);
@@ -843,19 +873,21 @@ static int prefill_attention(zn_handle h, const bf16_t* q, int ldq, const bf16_t
   return ZN_OK;
 }
 
-static int prefill_batched(zn_handle h, const bf16_t* hidden, int S, hipStream_t s) {
+// Transformer blocks over all S positions of R rows (hidden [R][S][d]) with `base` keys already cached per row: the
+// residual stream of every position ends in h->pf_x.
+static int transformer_prefill_core(zn_handle h, const bf16_t* hidden, int S, int R, const void* const* kv_layers, int max_len, int base, hipStream_t s) {
   const zn_config& c = h->cfg;
-  const int R = h->rows, M = R * S, d = c.d_model, hd = h->hd, nq = c.n_heads * hd, nkv = c.n_heads_kv * hd, nqkv = nq + 2 * nkv, F = c.d_ff;
+  const int M = R * S, d = c.d_model, hd = h->hd, nq = c.n_heads * hd, nkv = c.n_heads_kv * hd, nqkv = nq + 2 * nkv, F = c.d_ff;
   int rc = ensure_prefill_ws(h, (size_t)M);
   if (rc) return rc;
   HIPCHK(h, hipMemcpyAsync(h->pf_x, hidden, (size_t)M * d * 2, hipMemcpyDeviceToDevice, s));
   for (int li = 0; li < c.n_layer; ++li) {
     const zn_layer_weights& lw = h->layers[li];
-    bf16_t* kv = (bf16_t*)h->kv_layers[li];
+    bf16_t* kv = (bf16_t*)kv_layers[li];
     hipLaunchKernelGGL(layernorm_kernel, dim3(M), dim3(64), 0, s, h->pf_x, (const bf16_t*)lw.norm_w, (const bf16_t*)lw.norm_b, h->pf_n, d, c.norm_eps);
     launch_gemm(h->pf_n, d, (const bf16_t*)lw.in_proj, h->pf_qkv, nqkv, nullptr, M, nqkv, d, s);
-    hipLaunchKernelGGL(rope_kv_rows_kernel, dim3(S, R), dim3(256), 0, s, h->pf_qkv, kv, h->rope, S, 0, h->max_len, c.n_heads, c.n_heads_kv, hd, c.rope_positions);
-    rc = prefill_attention(h, h->pf_qkv, nqkv, kv, h->max_len, h->pf_a, nq, S, R, s);
+    hipLaunchKernelGGL(rope_kv_rows_kernel, dim3(S, R), dim3(256), 0, s, h->pf_qkv, kv, h->rope, S, base, max_len, c.n_heads, c.n_heads_kv, hd, c.rope_positions);
+    rc = prefill_attention(h, h->pf_qkv, nqkv, kv, max_len, h->pf_a, nq, S, R, s, base);
     if (rc) return rc;
     if (c.double_out_proj) {
       launch_gemm(h->pf_a, nq, (const bf16_t*)lw.out_proj, h->pf_n, d, nullptr, M, d, nq, s);
@@ -866,8 +898,79 @@ static int prefill_batched(zn_handle h, const bf16_t* hidden, int S, hipStream_t
     hipLaunchKernelGGL(silu_mul_rows_kernel, dim3(M), dim3(256), 0, s, h->pf_u, h->pf_m, F);
     launch_gemm(h->pf_m, F, (const bf16_t*)lw.fc2, h->pf_x, d, h->pf_x, M, d, F, s);
   }
+  return ZN_OK;
+}
+
+static int prefill_batched(zn_handle h, const bf16_t* hidden, int S, hipStream_t s) {
+  const zn_config& c = h->cfg;
+  const int R = h->rows, d = c.d_model;
+  int rc = transformer_prefill_core(h, hidden, S, R, h->kv_layers.data(), h->max_len, 0, s);
+  if (rc) return rc;
   hipLaunchKernelGGL(gather_last_kernel, dim3(R), dim3(256), 0, s, h->pf_x, h->x, S, d);
   hipLaunchKernelGGL(add_lengths_kernel, dim3(1), dim3(64 > R ? 64 : R), 0, s, h->lengths, R, S);
+  return ZN_OK;
+}
+
+// A projection over M rows of the hybrid prefill: out [M][N] = A [M][K] W^T (+ bias).  exact: row by row through the decode
+// step's GEMV (same summation order as a single step: lets tests compare a prefill with single steps bit for bit).
+static int proj_rows(zn_handle h, const bf16_t* A, int lda, const void* W, const void* bias, bf16_t* out, int ldo, int M, int N, int K, bool exact,
+                     hipStream_t s) {
+  if (exact) {
+    for (int m = 0; m < M; ++m) {
+      GemvArgs g{};
+      g.W = (const bf16_t*)W; g.N = N; g.K = K; g.x = A + (size_t)m * lda; g.out = out + (size_t)m * ldo; g.bias = (const bf16_t*)bias;
+      int rc = run_gemv<PRO_NONE, EPI_STORE>(h, g, 1, h->tune[1], s);
+      if (rc) return rc;
+    }
+    return ZN_OK;
+  }
+  launch_gemm(A, lda, (const bf16_t*)W, out, ldo, nullptr, M, N, K, s, (const bf16_t*)bias);
+  return ZN_OK;
+}
+
+// Hybrid blocks over all S positions of R rows (mamba_ssm Block semantics): Mamba2 layers run the sequence conv and the
+// selective scan (zn_mamba_kernels.h), attention layers the batched projections + tiled causal attention.  The mixer
+// output of every position ends in h->pf_x, the residual stream in h->pf_res; caches advance by S positions.
+static int hybrid_prefill_core(zn_handle h, const bf16_t* hidden, int S, int R, const void* const* caches, int max_len, int base, bool exact,
+                               hipStream_t s) {
+  const zn_config& c = h->cfg;
+  const int M = R * S, d = c.d_model, hd = h->hd, nq = c.n_heads * hd, nkv = c.n_heads_kv * hd, nqkv = nq + 2 * nkv, F = c.d_ff;
+  int rc = ensure_prefill_ws(h, (size_t)M);
+  if (rc) return rc;
+  HIPCHK(h, hipMemcpyAsync(h->pf_x, hidden, (size_t)M * d * 2, hipMemcpyDeviceToDevice, s));
+  for (int li = 0; li < c.n_layer; ++li) {
+    const zn_layer_weights& lw = h->layers[li];
+    launch_add_ln(h, h->pf_x, h->pf_res, li > 0, 1, lw.norm_w, lw.norm_b, h->pf_n, M, s);
+    if (lw.kind == 1) {
+      if ((rc = proj_rows(h, h->pf_n, d, lw.m_in_proj, nullptr, h->pf_zx, h->m_d_in_proj, M, h->m_d_in_proj, d, exact, s))) return rc;
+      size_t conv_bytes = 0;
+      (void)zn_mamba_state_bytes_per_layer(&c, R, &conv_bytes);
+      MambaArgs m{};
+      m.zx = h->pf_zx; m.conv_state = (bf16_t*)caches[li]; m.ssm_state = (bf16_t*)((char*)caches[li] + conv_bytes);
+      m.conv_w = (const bf16_t*)lw.m_conv_w; m.conv_b = (const bf16_t*)lw.m_conv_b;
+      m.dt_bias = (const bf16_t*)lw.m_dt_bias; m.A_log = (const bf16_t*)lw.m_A_log; m.D = (const bf16_t*)lw.m_D;
+      m.norm_w = (const bf16_t*)lw.m_norm_w; m.xbc = h->pf_xbc; m.y = h->pf_y; m.g = h->pf_g; m.vg = nullptr;
+      m.d_inner = c.m_d_inner; m.conv_dim = h->m_conv_dim; m.nheads = h->m_nheads; m.d_state = c.m_d_state; m.ngroups = c.m_ngroups;
+      m.d_in_proj = h->m_d_in_proj; m.eps = c.norm_eps; m.rows = R;
+      hipLaunchKernelGGL(mamba_conv_seq_kernel, dim3((h->m_conv_dim + 255) / 256, R), dim3(256), 0, s, m, S);
+      if (c.m_d_state == 128) hipLaunchKernelGGL((mamba_scan_kernel<128>), dim3(h->m_nheads, R), dim3(256), 0, s, m, S);
+      else hipLaunchKernelGGL((mamba_scan_kernel<64>), dim3(h->m_nheads, R), dim3(256), 0, s, m, S);
+      m.rows = M;
+      hipLaunchKernelGGL(mamba_gated_norm_kernel, dim3(c.m_ngroups, M), dim3(256), 0, s, m);
+      if ((rc = proj_rows(h, h->pf_g, c.m_d_inner, lw.m_out_proj, nullptr, h->pf_x, d, M, d, c.m_d_inner, exact, s))) return rc;
+      continue;
+    }
+    bf16_t* kv = (bf16_t*)caches[li];
+    if ((rc = proj_rows(h, h->pf_n, d, lw.in_proj, lw.in_proj_bias, h->pf_qkv, nqkv, M, nqkv, d, exact, s))) return rc;
+    hipLaunchKernelGGL(rope_kv_any_kernel, dim3(S, R), dim3(256), 0, s, h->pf_qkv, h->pf_qkv, nqkv, kv, h->rope, S, base, (const int*)nullptr, max_len,
+                       c.n_heads, c.n_heads_kv, hd, c.rope_positions, c.rope_mode);
+    if ((rc = prefill_attention(h, h->pf_qkv, nqkv, kv, max_len, h->pf_a, nq, S, R, s, base))) return rc;
+    if ((rc = proj_rows(h, h->pf_a, nq, lw.out_proj, lw.out_proj_bias, h->pf_x, d, M, d, nq, exact, s))) return rc;
+    launch_add_ln(h, h->pf_x, h->pf_res, 1, 1, lw.norm2_w, lw.norm2_b, h->pf_n, M, s);
+    if ((rc = proj_rows(h, h->pf_n, d, lw.fc1, nullptr, h->pf_u, 2 * F, M, 2 * F, d, exact, s))) return rc;
+    hipLaunchKernelGGL(silu_mul_rows_kernel, dim3(M), dim3(256), 0, s, h->pf_u, h->pf_m, F);
+    if ((rc = proj_rows(h, h->pf_m, F, lw.fc2, nullptr, h->pf_x, d, M, d, F, exact, s))) return rc;
+  }
   return ZN_OK;
 }
 
@@ -880,7 +983,15 @@ extern "C" int zn_prefill(zn_handle h, const void* hidden_dev, int32_t S, zn_str
   hipStream_t s = (hipStream_t)stream;
   const zn_config& c = h->cfg;
   int rc;
-  if (h->prefill_mode == 1 && S > 1 && c.d_model % 32 == 0 && c.d_ff % 32 == 0) {
+  if (c.arch == 1 && h->prefill_mode >= 1 && S > 1 && c.d_model % 32 == 0 && c.d_ff % 32 == 0 && c.m_d_inner % 32 == 0) {
+    // all positions at once (mode 2: projections row by row through the step's GEMV: bit-comparable with single steps)
+    if ((rc = hybrid_prefill_core(h, (const bf16_t*)hidden_dev, S, h->rows, h->kv_layers.data(), h->max_len, 0, h->prefill_mode == 2, s))) return rc;
+    hipLaunchKernelGGL(gather_last_kernel, dim3(h->rows), dim3(256), 0, s, h->pf_x, h->x, S, c.d_model);
+    hipLaunchKernelGGL(gather_last_bytes_kernel, dim3(h->rows), dim3(256), 0, s, (const void*)h->pf_res, (void*)h->res, S, c.d_model * (c.residual_in_fp32 ? 4 : 2));
+    hipLaunchKernelGGL(add_lengths_kernel, dim3(1), dim3(64 > h->rows ? 64 : h->rows), 0, s, h->lengths, h->rows, S);
+    h->len_hi += S;
+    if ((rc = hybrid_heads(h, s))) return rc;
+  } else if (c.arch == 0 && h->prefill_mode == 1 && S > 1 && c.d_model % 32 == 0 && c.d_ff % 32 == 0) {
     if ((rc = prefill_batched(h, (const bf16_t*)hidden_dev, S, s))) return rc;
     h->len_hi += S;
   } else {
@@ -1156,11 +1267,62 @@ extern "C" int zn_op_layer_decode(zn_handle h, int32_t layer, void* x, void* kv,
   return ZN_OK;
 }
 
-extern "C" int zn_op_add_layernorm(zn_handle h, const void* hidden, void* res, const void* w, const void* b, void* out, int32_t rows,
-                                   int32_t d, float eps, zn_stream stream) {
+extern "C" int zn_op_backbone_forward(zn_handle h, const void* hidden_dev, void* out_dev, const void* const* caches_dev, int32_t max_len,
+                                      int32_t base, int32_t S, int32_t rows, zn_stream stream) {
   if (!h) return ZN_ERR_ARG;
-  if (!hidden || !w || !b || !out || rows < 1 || d < 8 || d % 8 || d > 4096) ZN_FAIL(h, ZN_ERR_ARG, "zn_op_add_layernorm: bad argument");
-  launch_add_ln((const bf16_t*)hidden, (bf16_t*)res, res != nullptr, res != nullptr, w, b, (bf16_t*)out, rows, d, eps, (hipStream_t)stream);
+  const zn_config& c = h->cfg;
+  if (!hidden_dev || !out_dev || !caches_dev || S < 1 || rows < 1 || rows > h->max_rows || base < 0 || max_len < 1 || base + S > max_len)
+    ZN_FAIL(h, ZN_ERR_ARG, "zn_op_backbone_forward: bad argument (rows %d of at most %d, positions %d + %d of %d)", rows, h->max_rows, base, S, max_len);
+  if (base + S > c.rope_positions)
+    ZN_FAIL(h, ZN_ERR_ARG, "sequence length %d exceeds the %d-position RoPE table (zonos/backbone/_torch.py:206)", base + S, c.rope_positions);
+  hipStream_t s = (hipStream_t)stream;
+  int rc = ensure_attn_ws(h, max_len);
+  if (rc) return rc;
+  const int d = c.d_model;
+  const bf16_t* hid = (const bf16_t*)hidden_dev;
+  bf16_t* out = (bf16_t*)out_dev;
+  const bool batched = S > 1 && h->prefill_mode >= 1 && d % 32 == 0 && c.d_ff % 32 == 0 && (c.arch == 0 || c.m_d_inner % 32 == 0);
+  if (batched) {
+    const int M = rows * S;
+    if (c.arch == 1) {
+      if ((rc = hybrid_prefill_core(h, hid, S, rows, caches_dev, max_len, base, h->prefill_mode == 2, s))) return rc;
+      launch_add_ln(h, h->pf_x, h->pf_res, 1, 0, h->norm_f_w, h->norm_f_b, out, M, s);
+    } else {
+      if ((rc = transformer_prefill_core(h, hid, S, rows, caches_dev, max_len, base, s))) return rc;
+      hipLaunchKernelGGL(layernorm_kernel, dim3(M), dim3(64), 0, s, h->pf_x, (const bf16_t*)h->norm_f_w, (const bf16_t*)h->norm_f_b, out, d, c.norm_eps);
+    }
+    HIPCHK(h, hipGetLastError());
+    return ZN_OK;
+  }
+  // position by position through the decode kernels (S = 1: the loop's step).  Attention reproduces the reference's causal
+  // flash-attention blocking through the keys spanned by this position's query block.
+  const int qb = qsplit(S);
+  for (int p = 0; p < S; ++p) {
+    hipLaunchKernelGGL(gather_pos_kernel, dim3(rows), dim3(256), 0, s, hid, h->x, S, p, d);
+    hipLaunchKernelGGL(fill_int_kernel, dim3(1), dim3(64 > rows ? 64 : rows), 0, s, h->fw_lengths, rows, base + p);
+    int ext = (p / qb) * qb + qb; if (ext > S) ext = S;
+    h->attn_fused = attn_fused_for(h, base + p + 1);
+    for (int li = 0; li < c.n_layer; ++li) {
+      if (c.arch == 1) rc = hybrid_layer(h, li, (void*)caches_dev[li], max_len, h->fw_lengths, rows, s);
+      else rc = layer_decode(h, li, h->x, (bf16_t*)caches_dev[li], max_len, h->fw_lengths, nullptr, S > 1 ? base + ext : 0, rows, s);
+      if (rc) return rc;
+    }
+    if (c.arch == 1) launch_add_ln(h, h->x, h->res, 1, 0, h->norm_f_w, h->norm_f_b, h->nbuf, rows, s);
+    else hipLaunchKernelGGL(layernorm_kernel, dim3(rows), dim3(64), 0, s, h->x, (const bf16_t*)h->norm_f_w, (const bf16_t*)h->norm_f_b, h->nbuf, d, c.norm_eps);
+    hipLaunchKernelGGL(scatter_pos_kernel, dim3(rows), dim3(256), 0, s, h->nbuf, out, S, p, d);
+  }
+  HIPCHK(h, hipGetLastError());
+  return ZN_OK;
+}
+
+extern "C" int zn_op_add_layernorm(zn_handle h, const void* hidden, void* res, const void* w, const void* b, void* out, int32_t rows,
+                                   int32_t d, float eps, int32_t flags, zn_stream stream) {
+  if (!h) return ZN_ERR_ARG;
+  if (!hidden || !w || (!b && !(flags & 1)) || !out || rows < 1 || d < 8 || d % 8 || d > 4096) ZN_FAIL(h, ZN_ERR_ARG, "zn_op_add_layernorm: bad argument");
+  AddLnArgs a{};
+  a.h = (const bf16_t*)hidden; a.res = (bf16_t*)res; a.w = (const bf16_t*)w; a.b = (const bf16_t*)b; a.out = (bf16_t*)out; a.d = d;
+  a.has_res = res != nullptr; a.write_res = res != nullptr; a.eps = eps; a.rms = flags & 1; a.res32 = (flags >> 1) & 1;
+  hipLaunchKernelGGL(add_ln_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, a);
   HIPCHK(h, hipGetLastError());
   return ZN_OK;
 }

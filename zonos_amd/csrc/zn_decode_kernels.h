@@ -1284,6 +1284,12 @@ __global__ void gather_pos_kernel(const bf16_t* hidden, bf16_t* x, int S, int s,
   for (int k = threadIdx.x * 8; k < d; k += blockDim.x * 8)
     *(u32x4*)(x + (size_t)r * d + k) = *(const u32x4*)(hidden + ((size_t)r * S + s) * d + k);
 }
+// x [rows][d] -> rows of a [rows][S][d] tensor at position s
+__global__ void scatter_pos_kernel(const bf16_t* x, bf16_t* hidden, int S, int s, int d) {
+  const int r = blockIdx.x;
+  for (int k = threadIdx.x * 8; k < d; k += blockDim.x * 8)
+    *(u32x4*)(hidden + ((size_t)r * S + s) * d + k) = *(const u32x4*)(x + (size_t)r * d + k);
+}
 // standalone nn.LayerNorm: one wave per row; the row (d <= 4096) and the affine parameters are requested once, up
 // front, and stay in registers through both statistics passes (one memory round trip instead of three)
 __global__ __launch_bounds__(64) void layernorm_kernel(const bf16_t* x, const bf16_t* w, const bf16_t* b, bf16_t* out, int d, float eps) {

@@ -17,8 +17,11 @@ struct AddLnArgs {
   bf16_t* out;          // [rows][d] normalised
   int d, has_res, write_res;
   float eps;
+  int rms;              // BackboneConfig.rms_norm (config.py:82): RMSNorm - no mean, out = s * rsqrt(mean(s^2) + eps) * w (+ b when given)
+  int res32;            // BackboneConfig.residual_in_fp32 (config.py:83): `res` is float [rows][d] and keeps the unrounded sum
 };
-// s = h + res in fp32; res <- bf16(s); out <- bf16(LayerNorm_fp32(s)) (biased variance, two passes over registers).
+// s = h + res in fp32; res <- bf16(s) (or s itself, res32); out <- bf16(norm_fp32(s)), norm = LayerNorm (biased variance, two
+// passes over registers) or RMSNorm: the mamba_ssm Block's fused add + norm (layer_norm_fn, _mamba_ssm.py:45-58,111-119).
 // One workgroup per row, 8 elements per thread per sweep (d <= 4096).
 __global__ __launch_bounds__(256) void add_ln_kernel(AddLnArgs a) {
   const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -33,16 +36,28 @@ __global__ __launch_bounds__(256) void add_ln_kernel(AddLnArgs a) {
     if (k < d) {
       const u32x4 hv = ld16(a.h + (size_t)r * d + k);
       float f[8] = {lo_f(hv.x), hi_f(hv.x), lo_f(hv.y), hi_f(hv.y), lo_f(hv.z), hi_f(hv.z), lo_f(hv.w), hi_f(hv.w)};
+      float* res32 = (float*)a.res + (size_t)r * d + k;
       if (a.has_res) {
-        const u32x4 rv = ld16(a.res + (size_t)r * d + k);
-        const float g[8] = {lo_f(rv.x), hi_f(rv.x), lo_f(rv.y), hi_f(rv.y), lo_f(rv.z), hi_f(rv.z), lo_f(rv.w), hi_f(rv.w)};
+        float g[8];
+        if (a.res32) {
+          const f32x4 g0 = *(const f32x4*)res32, g1 = *(const f32x4*)(res32 + 4);
+          g[0] = g0.x; g[1] = g0.y; g[2] = g0.z; g[3] = g0.w; g[4] = g1.x; g[5] = g1.y; g[6] = g1.z; g[7] = g1.w;
+        } else {
+          const u32x4 rv = ld16(a.res + (size_t)r * d + k);
+          g[0] = lo_f(rv.x); g[1] = hi_f(rv.x); g[2] = lo_f(rv.y); g[3] = hi_f(rv.y); g[4] = lo_f(rv.z); g[5] = hi_f(rv.z); g[6] = lo_f(rv.w); g[7] = hi_f(rv.w);
+        }
 #pragma unroll
         for (int e = 0; e < 8; ++e) f[e] = __fadd_rn(f[e], g[e]);
       }
       if (a.write_res) {
-        u32x4 o;
-        o.x = pack2(f[0], f[1]); o.y = pack2(f[2], f[3]); o.z = pack2(f[4], f[5]); o.w = pack2(f[6], f[7]);
-        *(u32x4*)(a.res + (size_t)r * d + k) = o;
+        if (a.res32) {
+          *(f32x4*)res32 = f32x4{f[0], f[1], f[2], f[3]};
+          *(f32x4*)(res32 + 4) = f32x4{f[4], f[5], f[6], f[7]};
+        } else {
+          u32x4 o;
+          o.x = pack2(f[0], f[1]); o.y = pack2(f[2], f[3]); o.z = pack2(f[4], f[5]); o.w = pack2(f[6], f[7]);
+          *(u32x4*)(a.res + (size_t)r * d + k) = o;
+        }
       }
 #pragma unroll
       for (int e = 0; e < 8; ++e) { v[it][e] = f[e]; sum += f[e]; }
@@ -56,7 +71,7 @@ __global__ __launch_bounds__(256) void add_ln_kernel(AddLnArgs a) {
   sum = wave_sum(sum);
   if (lane == 0) red[0][wave] = sum;
   __syncthreads();
-  const float mean = ((red[0][0] + red[0][1]) + (red[0][2] + red[0][3])) / (float)d;
+  const float mean = a.rms ? 0.f : ((red[0][0] + red[0][1]) + (red[0][2] + red[0][3])) / (float)d;
   float ss = 0.f;
 #pragma unroll
   for (int it = 0; it < MAXV; ++it)
@@ -72,7 +87,7 @@ __global__ __launch_bounds__(256) void add_ln_kernel(AddLnArgs a) {
   for (int it = 0; it < MAXV; ++it) {
     const int k = (it * 256 + tid) * 8;
     if (it < nv) {
-      const u32x4 wv = ld16(a.w + k), bv = ld16(a.b + k);
+      const u32x4 wv = ld16(a.w + k), bv = a.b ? ld16(a.b + k) : u32x4{0, 0, 0, 0};     // RMSNorm modules carry no bias
       const float wf[8] = {lo_f(wv.x), hi_f(wv.x), lo_f(wv.y), hi_f(wv.y), lo_f(wv.z), hi_f(wv.z), lo_f(wv.w), hi_f(wv.w)};
       const float bf[8] = {lo_f(bv.x), hi_f(bv.x), lo_f(bv.y), hi_f(bv.y), lo_f(bv.z), hi_f(bv.z), lo_f(bv.w), hi_f(bv.w)};
       float o[8];
@@ -241,4 +256,114 @@ __global__ __launch_bounds__(256) void mamba_gated_norm_kernel(MambaArgs a) {
       *(u32x4*)(a.g + (size_t)r * a.d_inner + grp * gs + k) = ov;
     }
   }
+}
+
+
+// ------------------------------------------------------------------------------------------------ Mamba2 over a sequence
+// Prefill of S positions (the reference calls mamba_chunk_scan_combined there, _mamba_ssm.py:106-119 -> Mamba2.forward; its
+// chunked SSD form computes the same recurrence): rows of every [.][S] operand are position-major inside an utterance
+// row, index r * S + s.  Both kernels repeat the single-step kernels' arithmetic statement for statement, so a prefill of
+// S positions leaves the conv window, the SSM state and every output bit-identical to S single steps on the same inputs.
+
+// causal conv + SiLU along the sequence: one thread per (row, channel) walks the S positions with the window in registers
+__global__ __launch_bounds__(256) void mamba_conv_seq_kernel(MambaArgs a, int S) {
+  const int c = blockIdx.x * 256 + threadIdx.x, r = blockIdx.y;
+  if (c >= a.conv_dim) return;
+  typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
+  bf16_t* sp = a.conv_state + ((size_t)r * a.conv_dim + c) * 4;
+  u32x2_t st = *(const u32x2_t*)sp;
+  const u32x2_t wv = *(const u32x2_t*)(a.conv_w + (size_t)c * 4);
+  const float bias = bf2f(a.conv_b[c]);
+  const bf16_t* xp = a.zx + (size_t)r * S * a.d_in_proj + a.d_inner + c;
+  bf16_t* op = a.xbc + (size_t)r * S * a.conv_dim + c;
+  constexpr int AH = 8;                                   // positions requested ahead
+  bf16_t xq[AH];
+#pragma unroll
+  for (int i = 0; i < AH; ++i) xq[i] = xp[(size_t)min(i, S - 1) * a.d_in_proj];
+  for (int s0 = 0; s0 < S; s0 += AH) {
+    bf16_t xc[AH];
+#pragma unroll
+    for (int i = 0; i < AH; ++i) { xc[i] = xq[i]; xq[i] = xp[(size_t)min(s0 + AH + i, S - 1) * a.d_in_proj]; }
+#pragma unroll
+    for (int i = 0; i < AH; ++i) {
+      if (s0 + i < S) {
+        const bf16_t xn = xc[i];
+        const float e0 = hi_f(st.x), e1 = lo_f(st.y), e2 = hi_f(st.y), e3 = bf2f(xn);
+        u32x2_t ns;
+        ns.x = (st.x >> 16) | (st.y << 16);
+        ns.y = (st.y >> 16) | ((unsigned)xn << 16);
+        st = ns;
+        float acc = bias;
+        acc = __fadd_rn(acc, __fmul_rn(lo_f(wv.x), e0));
+        acc = __fadd_rn(acc, __fmul_rn(hi_f(wv.x), e1));
+        acc = __fadd_rn(acc, __fmul_rn(lo_f(wv.y), e2));
+        acc = __fadd_rn(acc, __fmul_rn(hi_f(wv.y), e3));
+        op[(size_t)(s0 + i) * a.conv_dim] = f2bf(acc / (1.0f + expf(-acc)));
+      }
+    }
+  }
+  *(u32x2_t*)sp = st;
+}
+
+// selective scan: one workgroup per (row, head) keeps its 64 x N state tile in registers (bf16-rounded after every
+// position, as the cache holds it between single steps) and walks the positions; the next position's B, C, x, dt
+// are requested while the current one is computed.
+template <int N>
+__global__ __launch_bounds__(256) void mamba_scan_kernel(MambaArgs a, int S) {
+  constexpr int P = 64, NT = N / 4, NV = NT / 8;
+  const int h = blockIdx.x, r = blockIdx.y, tid = threadIdx.x;
+  const int p = tid >> 2, q = tid & 3;
+  const int grp = h / (a.nheads / a.ngroups);
+  bf16_t* sp = a.ssm_state + (((size_t)r * a.nheads + h) * P + p) * N + q * NT;
+  u32x4 sv[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) sv[i] = ld16(sp + i * 8);
+  const float A = -expf(bf2f(a.A_log[h]));
+  const float Dh = bf2f(a.D[h]);
+  const float dtb = bf2f(a.dt_bias[h]);
+  u32x4 bn[NV], cn[NV];
+  bf16_t xn, dn;
+  auto request = [&](int s) {
+    const size_t rs = (size_t)r * S + min(s, S - 1);
+    const bf16_t* xb = a.xbc + rs * a.conv_dim;
+    const bf16_t* Bp = xb + a.d_inner + grp * N + q * NT;
+    const bf16_t* Cp = Bp + a.ngroups * N;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) { bn[i] = ld16(Bp + i * 8); cn[i] = ld16(Cp + i * 8); }
+    xn = xb[h * P + p];
+    dn = a.zx[rs * a.d_in_proj + a.d_inner + a.conv_dim + h];
+  };
+  request(0);
+  for (int s = 0; s < S; ++s) {
+    u32x4 bv[NV], cv[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) { bv[i] = bn[i]; cv[i] = cn[i]; }
+    const float x = bf2f(xn);
+    float dtv = __fadd_rn(bf2f(dn), dtb);
+    request(s + 1);
+    if (dtv <= 20.0f) dtv = log1pf(expf(dtv));
+    const float dA = expf(__fmul_rn(dtv, A));
+    float y = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const unsigned sw[4] = {sv[i].x, sv[i].y, sv[i].z, sv[i].w};
+      const unsigned bw[4] = {bv[i].x, bv[i].y, bv[i].z, bv[i].w};
+      const unsigned cw[4] = {cv[i].x, cv[i].y, cv[i].z, cv[i].w};
+      unsigned ow[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float n0 = __fadd_rn(__fmul_rn(lo_f(sw[e]), dA), __fmul_rn(__fmul_rn(lo_f(bw[e]), dtv), x));
+        const float n1 = __fadd_rn(__fmul_rn(hi_f(sw[e]), dA), __fmul_rn(__fmul_rn(hi_f(bw[e]), dtv), x));
+        y = fmaf(n0, lo_f(cw[e]), y);
+        y = fmaf(n1, hi_f(cw[e]), y);
+        ow[e] = pack2(n0, n1);
+      }
+      sv[i] = u32x4{ow[0], ow[1], ow[2], ow[3]};
+    }
+    y += dpp_mov<ZN_DPP_XOR1>(y);
+    y += dpp_mov<ZN_DPP_XOR2>(y);
+    if (q == 0) a.y[((size_t)r * S + s) * a.d_inner + h * P + p] = f2bf(__fadd_rn(y, __fmul_rn(x, Dh)));
+  }
+#pragma unroll
+  for (int i = 0; i < NV; ++i) *(u32x4*)(sp + i * 8) = sv[i];
 }

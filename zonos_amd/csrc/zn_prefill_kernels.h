@@ -15,6 +15,7 @@ typedef __attribute__((ext_vector_type(8))) __bf16 zn_bf16x8p;
 struct GemmArgs {
   const bf16_t* A; const bf16_t* W; bf16_t* out; const bf16_t* resid;
   int M, N, K, lda, ldo;   // lda = row stride of A (elements), ldo = row stride of out / resid
+  const bf16_t* bias;      // optional nn.Linear bias [N], added in fp32 before the single bf16 rounding
 };
 template <int EPI>
 __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs a) {
@@ -66,7 +67,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs a) {
         const int m = m0 + i * 16 + 4 * fg + reg;
         if (m >= a.M) continue;
         const size_t o = (size_t)m * a.ldo + n;
-        float v = bfround(acc[i][j][reg]);
+        float v = bfround(a.bias ? acc[i][j][reg] + bf2f(a.bias[n]) : acc[i][j][reg]);
         if constexpr (EPI == 1) v = bf2f(a.resid[o]) + v;
         a.out[o] = f2bf(v);
       }
@@ -143,7 +144,7 @@ __global__ __launch_bounds__(256) void gemm_bf16s_kernel(GemmArgs a) {
         const int m = m0 + i * 16 + 4 * fg + reg;
         if (m >= a.M) continue;
         const size_t o = (size_t)m * a.ldo + n;
-        float v = bfround(acc[i][j][reg]);
+        float v = bfround(a.bias ? acc[i][j][reg] + bf2f(a.bias[n]) : acc[i][j][reg]);
         if constexpr (EPI == 1) v = bf2f(a.resid[o]) + v;
         a.out[o] = f2bf(v);
       }
@@ -174,6 +175,41 @@ __global__ __launch_bounds__(256) void rope_kv_rows_kernel(bf16_t* qkv, bf16_t* 
     }
   }
 }
+// General form for the hybrid stack's attention layers (mamba_ssm MHA, attn_cfg): qkv [R][S][ld] (biases already added) ->
+// q_out [R][S][ldq] rotated (may alias qkv: every thread reads its two elements before it writes them), k (rotated) and v
+// to the cache at position (lengths ? lengths[r] : base) + s.  mode 0: interleaved pairs (2i, 2i+1); mode 1: half-split
+// pairs (i, i + hd/2) (rotary_emb_interleaved = False); mode 2: no rotary.  fp32 products and sums rounded separately.
+__global__ __launch_bounds__(256) void rope_kv_any_kernel(const bf16_t* qkv, bf16_t* q_out, int ldq, bf16_t* kv, const float* rope, int S, int base,
+                                                          const int* lengths, int max_len, int n_heads, int n_heads_kv, int hd, int rope_positions,
+                                                          int mode) {
+  const int s = blockIdx.x, r = blockIdx.y;
+  const int nq = n_heads * hd, nk = n_heads_kv * hd, ld = nq + 2 * nk, hh = hd >> 1;
+  const int pos = (lengths ? lengths[r] : base) + s;
+  const int p = pos < rope_positions ? pos : rope_positions - 1;
+  const bf16_t* row = qkv + ((size_t)r * S + s) * ld;
+  bf16_t* qrow = q_out + ((size_t)r * S + s) * ldq;
+  bf16_t* krow = kv + (((size_t)r * max_len + min(pos, max_len - 1)) * 2 + 0) * nk;
+  bf16_t* vrow = krow + nk;
+  const bool in_cache = pos < max_len;
+  for (int pi = threadIdx.x; pi < ld / 2; pi += 256) {
+    if (pi < (nq + nk) / 2) {
+      const int g = pi / hh, i = pi % hh;
+      const int e0 = (mode == 1) ? g * hd + i : g * hd + 2 * i, e1 = (mode == 1) ? e0 + hh : e0 + 1;
+      const float x0 = bf2f(row[e0]), x1 = bf2f(row[e1]);
+      float o0 = x0, o1 = x1;
+      if (mode != 2) {
+        const float cs = rope[((size_t)p * hh + i) * 2], sn = rope[((size_t)p * hh + i) * 2 + 1];
+        o0 = __fsub_rn(__fmul_rn(x0, cs), __fmul_rn(x1, sn));
+        o1 = __fadd_rn(__fmul_rn(x1, cs), __fmul_rn(x0, sn));
+      }
+      if (e0 < nq) { qrow[e0] = f2bf(o0); qrow[e1] = f2bf(o1); }
+      else if (in_cache) { krow[e0 - nq] = f2bf(o0); krow[e1 - nq] = f2bf(o1); }
+    } else if (in_cache) {
+      const int n = 2 * pi;
+      *(unsigned*)(vrow + (n - nq - nk)) = *(const unsigned*)(row + n);
+    }
+  }
+}
 // m = y * silu(gate) with bf16 roundings after silu and mul (_torch.py:473-474); u [M][2F] -> m [M][F]
 __global__ __launch_bounds__(256) void silu_mul_rows_kernel(const bf16_t* u, bf16_t* m, int F) {
   const size_t row = blockIdx.x;
@@ -184,6 +220,14 @@ __global__ __launch_bounds__(256) void silu_mul_rows_kernel(const bf16_t* u, bf1
     *(unsigned*)(m + row * F + i) = pack2(lo_f(y) * s0, hi_f(y) * s1);
   }
 }
+// row r of dst <- the last of the S positions of row r of src (rows of row_bytes bytes, a multiple of 16)
+__global__ void gather_last_bytes_kernel(const void* src, void* dst, int S, int row_bytes) {
+  const int r = blockIdx.x;
+  const u32x4* sp = (const u32x4*)((const char*)src + ((size_t)r * S + (S - 1)) * row_bytes);
+  u32x4* dp = (u32x4*)((char*)dst + (size_t)r * row_bytes);
+  for (int i = threadIdx.x; i < row_bytes / 16; i += blockDim.x) dp[i] = sp[i];
+}
+__global__ void fill_int_kernel(int* p, int n, int v) { if ((int)threadIdx.x < n) p[threadIdx.x] = v; }
 __global__ void gather_last_kernel(const bf16_t* xP, bf16_t* x, int S, int d) {
   const int r = blockIdx.x;
   for (int k = threadIdx.x * 8; k < d; k += blockDim.x * 8) *(u32x4*)(x + (size_t)r * d + k) = *(const u32x4*)(xP + ((size_t)r * S + S - 1) * d + k);

@@ -118,6 +118,10 @@ def zonos_state_dict(cfg: dict, seed: int = 1234, dtype=torch.bfloat16, peaky: b
         sd["fused_heads.weight"] = torch.cat(
             [_t(uniform(seed, f"heads.{i}.weight", (vh, d), 1.0 / np.sqrt(d)), dtype) for i in range(nq)], 0)
     ssm = cfg.get("ssm_cfg") or {}
+    rms = bool(ssm) and bool(cfg.get("rms_norm"))              # mamba_ssm RMSNorm blocks carry no bias
+    ac = cfg.get("attn_cfg") or {}
+    qkv_bias = bool(ssm) and bool(ac.get("qkv_proj_bias", True)) and "attn_cfg" in cfg      # mamba_ssm MHA defaults (attn_cfg given)
+    out_bias = bool(ssm) and bool(ac.get("out_proj_bias", True)) and "attn_cfg" in cfg
     for l in range(L):
         p = f"backbone.layers.{l}."
         if ssm and l not in cfg["attn_layer_idx"]:
@@ -125,9 +129,14 @@ def zonos_state_dict(cfg: dict, seed: int = 1234, dtype=torch.bfloat16, peaky: b
             continue
         for nm in ("norm", "norm2"):
             sd[p + nm + ".weight"] = _t(1.0 + uniform(seed, p + nm + ".weight", (d,), 0.1), dtype)
-            sd[p + nm + ".bias"] = _t(uniform(seed, p + nm + ".bias", (d,), 0.1), dtype)
+            if not rms:
+                sd[p + nm + ".bias"] = _t(uniform(seed, p + nm + ".bias", (d,), 0.1), dtype)
         sd[p + "mixer.in_proj.weight"] = _t(uniform(seed, p + "mixer.in_proj.weight", ((H + 2 * Hkv) * hd, d), 1.0 / np.sqrt(d)), dtype)
         sd[p + "mixer.out_proj.weight"] = _t(uniform(seed, p + "mixer.out_proj.weight", (d, H * hd), 1.0 / np.sqrt(H * hd)), dtype)
+        if qkv_bias:
+            sd[p + "mixer.in_proj.bias"] = _t(uniform(seed, p + "mixer.in_proj.bias", ((H + 2 * Hkv) * hd,), 0.2), dtype)
+        if out_bias:
+            sd[p + "mixer.out_proj.bias"] = _t(uniform(seed, p + "mixer.out_proj.bias", (d,), 0.2), dtype)
         sd[p + "mlp.fc1.weight"] = _t(uniform(seed, p + "mlp.fc1.weight", (2 * F, d), 1.0 / np.sqrt(d)), dtype)
         sd[p + "mlp.fc2.weight"] = _t(uniform(seed, p + "mlp.fc2.weight", (d, F), 1.0 / np.sqrt(F)), dtype)
     sd["backbone.norm_f.weight"] = _t(1.0 + uniform(seed, "backbone.norm_f.weight", (d,), 0.1), dtype)
@@ -147,7 +156,8 @@ def mamba2_layer_state_dict(cfg: dict, seed: int, p: str, dtype=torch.bfloat16) 
     conv_dim = d_inner + 2 * ngroups * d_state
     sd = {}
     sd[p + "norm.weight"] = _t(1.0 + uniform(seed, p + "norm.weight", (d,), 0.1), dtype)
-    sd[p + "norm.bias"] = _t(uniform(seed, p + "norm.bias", (d,), 0.1), dtype)
+    if not cfg.get("rms_norm"):
+        sd[p + "norm.bias"] = _t(uniform(seed, p + "norm.bias", (d,), 0.1), dtype)
     sd[p + "mixer.in_proj.weight"] = _t(uniform(seed, p + "mixer.in_proj.weight", (2 * d_inner + 2 * ngroups * d_state + H, d), 1.0 / np.sqrt(d)), dtype)
     sd[p + "mixer.conv1d.weight"] = _t(uniform(seed, p + "mixer.conv1d.weight", (conv_dim, 1, d_conv), 1.0 / np.sqrt(d_conv)), dtype)
     sd[p + "mixer.conv1d.bias"] = _t(uniform(seed, p + "mixer.conv1d.bias", (conv_dim,), 1.0 / np.sqrt(d_conv)), dtype)
@@ -164,10 +174,15 @@ def mamba2_layer_state_dict(cfg: dict, seed: int, p: str, dtype=torch.bfloat16) 
 
 # Hybrid configurations: tiny for parity tests; full = the recalled Zonos-v0.1-hybrid dimensions (SURVEY.md 0.8,
 # "lower confidence": the loader reads the real ones from config.json).
+# Without an "attn_cfg" entry the hybrid configurations keep round 1's attention form (interleaved rotary over the whole head,
+# no biases); with one, the entry is what config.json's backbone.attn_cfg would hold beside num_heads / num_heads_kv and
+# mamba_ssm's MHA defaults apply to the keys it leaves out (rotary_emb_dim 0, half-split pairs, biases on).
 HYBRID_TINY_CFG = dict(d_model=128, n_layer=4, num_heads=4, num_heads_kv=2, d_ff=256, ssm_cfg={"layer": "Mamba2", "d_state": 64},
                        attn_layer_idx=[2])
 HYBRID_FULL_CFG = dict(d_model=2048, n_layer=46, num_heads=16, num_heads_kv=4, d_ff=8192, ssm_cfg={"layer": "Mamba2"},
                        attn_layer_idx=[9, 19, 29, 39])
+# the attention form recalled for the Zonos-v0.1-hybrid checkpoint: rotary over the whole head, half-split pairs, no biases
+HYBRID_CKPT_ATTN = dict(causal=True, rotary_emb_dim=32, qkv_proj_bias=False, out_proj_bias=False)
 TINY_CFG = dict(d_model=128, n_layer=2, num_heads=4, num_heads_kv=2, d_ff=256)
 # smallest shape the persistent decode chain (csrc/zn_chain_kernel.h) serves: d_model 512 = one 512-column chunk per weight
 # row, d_ff = 4 d_model, head size 128; three blocks = first, middle (with the next block's in_proj) and last chain launch
