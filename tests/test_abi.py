@@ -50,3 +50,78 @@ def test_bad_arguments_return_status_not_crash(lib):
     assert b"divide" in lib.zn_last_error(None)
     assert lib.zn_decode_steps(None, 1, None) < 0
     assert lib.zn_destroy(None) == 0
+
+
+# ---------------------------------------------------------------------------------------------- emitted hand-off ISA
+# The cross-workgroup hand-offs (split-K combine of gemm16s_kernel, per-block combine of the split P.V pass, the persistent
+# chain's counters) order relaxed agent-scope accesses by instruction selection, not by fences: partial results leave by
+# write-through (sc1) stores, the storing wave drains (s_waitcnt vmcnt(0)) before the workgroup's barrier and the arrival
+# atomic, and every load of handed-off bytes is an sc1 load (MI355X_MICROARCH.md "Valid forms", table row 1;
+# cdna_hip_programming.md Guideline 16 R1).  Nothing in the memory model promises that selection, so the built code object
+# is disassembled and checked.
+OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+
+
+@pytest.fixture(scope="module")
+def kernels_isa(lib, tmp_path_factory):
+    import shutil
+    import subprocess
+    if not os.path.exists(OBJDUMP):
+        pytest.skip("llvm-objdump not available")
+    tmp = tmp_path_factory.mktemp("isa")
+    so = shutil.copy(_lib.LIB_PATH, tmp / "lib.so")
+    subprocess.run([OBJDUMP, "--offloading", str(so)], check=True, capture_output=True, cwd=tmp)       # writes the bundles next to the copy
+    out = {}
+    for co in sorted(tmp.glob("lib.so.*gfx950*")):
+        txt = subprocess.run([OBJDUMP, "-d", str(co)], check=True, capture_output=True, text=True).stdout
+        name = None
+        for line in txt.splitlines():
+            m = re.match(r"^[0-9a-f]+ <(.*)>:", line)
+            if m:
+                name = m.group(1)
+                out[name] = []
+            elif name and line.strip():
+                out[name].append(line.split("//")[0].strip())
+    assert out, "no gfx950 code object found in the library"
+    return out
+
+
+def _check_ticket_kernel(ins):
+    at = [i for i, l in enumerate(ins) if l.startswith("global_atomic_add")]
+    assert len(at) == 1, "one arrival atomic expected"
+    a = at[0]
+    before = ins[max(0, a - 60):a]
+    bar = max(i for i, l in enumerate(before) if l.startswith("s_barrier"))
+    drain = [i for i, l in enumerate(before[:bar]) if l.startswith("s_waitcnt") and "vmcnt(0)" in l]
+    assert drain and bar - drain[-1] <= 3, "the storing waves must drain (vmcnt(0)) right before the barrier in front of the ticket"
+    stores = [l for l in before[:drain[-1]] if l.startswith("global_store")]
+    assert stores and all(" sc1" in l for l in stores), f"partial stores must be write-through: {stores}"
+    after = ins[a:]
+    sc1_loads = [l for l in after if l.startswith("global_load_dword ") and " sc1" in l]
+    assert len(sc1_loads) >= 8, "the last arriver reads the partials with sc1 loads"
+
+
+def test_ticketed_combines_use_write_through_stores_and_sc1_loads(kernels_isa):
+    names = [n for n in kernels_isa if re.match(r"_Z14gemm16s_kernelILi\d+ELi\d+EE", n) or re.match(r"_Z14attn_pv_kernelILi\d+ELi\d+ELi2EE", n)]
+    assert len(names) >= 10
+    for n in names:
+        _check_ticket_kernel(kernels_isa[n])
+
+
+def test_chain_kernel_handoffs_are_sc1_and_drained(kernels_isa):
+    names = [n for n in kernels_isa if n.startswith("_Z12chain_kernel")]
+    assert len(names) == 4
+    for n in names:
+        ins = kernels_isa[n]
+        gathers = [l for l in ins if l.startswith("buffer_load_dwordx4")]
+        assert gathers and all(" sc1" in l for l in gathers), n                      # every gather of handed-off bytes bypasses L1
+        published = [i for i, l in enumerate(ins) if l.startswith("global_store_dword ") and " sc1" in l]
+        assert len(published) >= 3, n
+        arrivals = 0
+        for j in published:                                                           # publish -> drain -> arrival atomic, in that order
+            nxt = next((i for i in range(j + 1, min(len(ins), j + 80)) if ins[i].startswith("global_atomic_add")), None)
+            if nxt is None or any(ins[i].startswith("global_store_dword ") for i in range(j + 1, nxt)):
+                continue
+            assert any(ins[i].startswith("s_waitcnt") and "vmcnt(0)" in ins[i] for i in range(j + 1, nxt)), (n, j)
+            arrivals += 1
+        assert arrivals >= 3, n

@@ -39,18 +39,29 @@ def tokenize_phonemes(phonemes: list[str]) -> tuple[torch.Tensor, list[int]]:
     return torch.tensor([[PAD_ID] * (longest - len(i)) + i for i in ids]), lengths
 
 
+_backends: dict = {}
+
+
+def get_backend(language: str):
+    """conditioning.py:291-304: one EspeakBackend per language, kept (building one starts espeak and loads the voice)."""
+    be = _backends.get(language)
+    if be is None:
+        try:
+            from phonemizer.backend import EspeakBackend
+        except ImportError as e:      # pragma: no cover - dependency absent offline
+            raise _lib.ZonosHipError("text -> phoneme conversion needs `phonemizer` + espeak-ng (as the reference does); "
+                                     "pass espeak=('phonemes', [...]) or ('ids', tensor) instead") from e
+        be = _backends[language] = EspeakBackend(language, preserve_punctuation=True, with_stress=True,   # pragma: no cover
+                                                 punctuation_marks=_VOCAB["punctuation"])
+    return be
+
+
 def phonemize(texts: list[str], languages: list[str]) -> list[str]:
-    """conditioning.py:307-335 — needs the same third-party stack as the reference (phonemizer + espeak-ng)."""
-    try:
-        from phonemizer.backend import EspeakBackend
-    except ImportError as e:      # pragma: no cover - dependency absent offline
-        raise _lib.ZonosHipError("text -> phoneme conversion needs `phonemizer` + espeak-ng (as the reference does); "
-                                 "pass espeak=('phonemes', [...]) or ('ids', tensor) instead") from e
-    out = []
-    for text, lang in zip(texts, languages):   # pragma: no cover
-        be = EspeakBackend(lang, preserve_punctuation=True, with_stress=True, punctuation_marks=_VOCAB["punctuation"])
-        out.append(be.phonemize([text], strip=True)[0])
-    return out
+    """conditioning.py:307-335: clean() (numbers spelled out; Japanese normalised) and then espeak through `phonemizer` — the same
+    third-party stack as the reference."""
+    from .text_cleaning import clean
+    texts = clean(texts, languages)
+    return [get_backend(lang).phonemize([text], strip=True)[0] for text, lang in zip(texts, languages)]   # pragma: no cover
 
 
 def _engine_call(mod: nn.Module, name: str, *args):
