@@ -167,8 +167,9 @@ int zn_debug_tune(zn_handle h, int32_t key, int32_t value);
  * stamps_dev [n_layer][32] (NULL = off).  Stamp order per launch: input ready; then per op: results ready, arrived,
  * all arrived, next input ready; last: end. */
 int zn_debug_chain_stamps(zn_handle h, uint64_t* stamps_dev);
-/* Diagnostic: every decode step copies, per block, the residual stream after the block, the block's attention output and
- * its rotated queries into trace_dev [n_layer][3][rows][d_model] bf16 (NULL = off). */
+/* Diagnostic: every decode step copies, per block, the residual stream after the block, the block's attention output, its
+ * rotated queries, the gated MLP values m [rows][d_ff <= 4 d_model] (slots 3..6) and the residual stream after the attention
+ * half (slot 7) into trace_dev [n_layer][8][rows][d_model] bf16 (NULL = off). */
 int zn_debug_trace(zn_handle h, void* trace_dev);
 int zn_debug_eos_bias(zn_handle h, float bias);
 

@@ -63,9 +63,11 @@ def test_chain_generate_vs_oracle():
 
 @pytest.mark.parametrize("which", ["chain512", "full"])
 def test_chain_is_bit_identical_to_the_launches_path(which):
-    """Free-running greedy generation through the chain kernel and through the per-op launches (zn_debug_tune(8, 2)): equal
-    codes and bit-equal logits at every step - at d_model 512 and at the Zonos-v0.1-transformer dimensions (200 steps:
-    8-step graphs, the fused attention launch, hand-offs replayed 26 x 4 x 200 times)."""
+    """Free-running greedy generation through the chain kernel and through the per-op launches (zn_debug_tune(8, 2)).  At the
+    Zonos-v0.1-transformer dimensions both paths cut every dot product the same way (fc2's K = 8192 in four quarters): equal
+    codes and bit-equal logits at every step (200 steps: 8-step graphs, the fused attention launch, hand-offs replayed
+    26 x 4 x 200 times).  At d_model 512 the launches path keeps fc2's K = 2048 in one wave while the chain splits it in
+    quarters - another summation order: equal codes, logits within one bf16 ulp of a hidden value."""
     cfg, seed, n = (synth.CHAIN_CFG, 55, 60) if which == "chain512" else (synth.FULL_CFG, 1234, 200)
     model, _ = build_model(cfg, seed, "cuda:0")
     cond = synth.conditioning(seed, "cond", 2, 24, cfg["d_model"])
@@ -73,6 +75,14 @@ def test_chain_is_bit_identical_to_the_launches_path(which):
     b, lb, pb = _run(model, cond, n, chain=False)
     assert (pa, pb) == (1, 0)
     assert torch.equal(a, b)
-    assert la.shape == lb.shape and torch.equal(la.view(torch.int32), lb.view(torch.int32))
+    assert la.shape == lb.shape
+    if which == "full":
+        assert torch.equal(la.view(torch.int32), lb.view(torch.int32))
+    else:
+        fin = torch.isfinite(lb)
+        same = float((la.view(torch.int32) == lb.view(torch.int32))[fin].float().mean())
+        worst = float((la - lb)[fin].abs().max())
+        print(f"\n[chain vs launches, d 512] logits bit-equal {same:.5f}, max |d| {worst:.4g}")
+        assert same > 0.995 and worst <= 0.04
     a2, la2, _ = _run(model, cond, n, chain=True)           # replay: no state survives a generation (counters, timeout word)
     assert torch.equal(a, a2) and torch.equal(la.view(torch.int32), la2.view(torch.int32))

@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libzonos_hip.so")
+LIB_PATH = os.environ.get("ZONOS_HIP_LIB") or os.path.join(_HERE, "libzonos_hip.so")   # the override selects an experimental build (A/B runs)
 
 ZN_ABI_VERSION = 3
 

@@ -39,7 +39,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
         src, obj = os.path.join(CSRC, s), os.path.join(CSRC, s.replace(".hip", ".o"))
         objs.append(obj)
         if force or _stale(obj, [src] + hdrs):
-            jobs.append([_hipcc(), *FLAGS, "-c", src, "-o", obj])
+            jobs.append([_hipcc(), *FLAGS, *os.environ.get("ZN_EXTRA_HIPCC_FLAGS", "").split(), "-c", src, "-o", obj])
     if jobs:
         def run(cmd):
             if verbose:

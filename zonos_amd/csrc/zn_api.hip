@@ -221,7 +221,7 @@ extern "C" int zn_create(const zn_config* cfg, const zn_weights* w, int32_t max_
   ZC(hipMalloc(&h->ch_x2, R * c.d_model * 2));
   h->ch_variant = chain_variant_for(c);
   if (const char* e = getenv("ZN_CHAIN")) if (atoi(e) == 1) h->tune[8] = 1;
-  if (max_rows > 4) {
+  {   // split-K partial tiles + tickets of the small-M projections (batches of 3..8 utterances; short-prompt prefill at any batch)
     ZC(hipMalloc(&h->g16_part, ZN_G16_PART_BYTES));
     ZC(hipMalloc(&h->g16_tickets, ZN_G16_MAX_GROUPS * sizeof(int)));
     ZC(hipMemset(h->g16_tickets, 0, ZN_G16_MAX_GROUPS * sizeof(int)));
@@ -481,7 +481,7 @@ static int layer_in_proj(zn_handle h, int li, bf16_t* x, bf16_t* kv, int max_len
 }
 
 // out_proj (-> out_proj again, _torch.py:419-420) -> residual -> LayerNorm -> fc1 -> y * silu(gate) -> fc2 -> residual
-static int layer_post_attention(zn_handle h, int li, bf16_t* x, int rows, hipStream_t s) {
+static int layer_post_attention(zn_handle h, int li, bf16_t* x, int rows, hipStream_t s, bf16_t* x1_copy = nullptr) {
   const zn_config& c = h->cfg;
   const zn_layer_weights& lw = h->layers[li];
   const int d = c.d_model, nq = c.n_heads * h->hd;
@@ -500,6 +500,7 @@ static int layer_post_attention(zn_handle h, int li, bf16_t* x, int rows, hipStr
       if ((rc = run_gemv<PRO_NONE, EPI_RESID>(h, a, rows, h->tune[1], s))) return rc;
     }
   }
+  if (x1_copy) (void)hipMemcpyAsync(x1_copy, x, (size_t)rows * d * 2, hipMemcpyDeviceToDevice, s);      // diagnostic trace
   {  // LayerNorm -> fc1 -> y * silu(gate)
     GemvArgs a{};
     a.W = (const bf16_t*)lw.fc1; a.N = 2 * c.d_ff; a.K = d; a.x = x;
@@ -568,20 +569,24 @@ static int decode_blocks(zn_handle h, const int* ext, int ext_scalar, hipStream_
   int rc;
   const size_t tb = (size_t)h->rows * c.d_model * 2;
   const bool chain = chain_active(h, h->rows);
-  auto trace = [&](int li) {
+  auto trace = [&](int li) {        // slots per block: x after the block, attention output, q, m (first d values per row pair), x after the attention half
     if (!h->dbg_trace) return;
-    (void)hipMemcpyAsync((char*)h->dbg_trace + (size_t)(3 * li) * tb, chain ? chain_x(h, li + 1) : h->x, tb, hipMemcpyDeviceToDevice, s);
-    (void)hipMemcpyAsync((char*)h->dbg_trace + (size_t)(3 * li + 1) * tb, h->o1, tb, hipMemcpyDeviceToDevice, s);
+    (void)hipMemcpyAsync((char*)h->dbg_trace + (size_t)(8 * li) * tb, chain ? chain_x(h, li + 1) : h->x, tb, hipMemcpyDeviceToDevice, s);
+    (void)hipMemcpyAsync((char*)h->dbg_trace + (size_t)(8 * li + 1) * tb, h->o1, tb, hipMemcpyDeviceToDevice, s);
+    (void)hipMemcpyAsync((char*)h->dbg_trace + (size_t)(8 * li + 3) * tb, h->mbuf, (size_t)h->rows * c.d_ff * 2 <= 4 * tb ? (size_t)h->rows * c.d_ff * 2 : 4 * tb, hipMemcpyDeviceToDevice, s);
+    if (chain) (void)hipMemcpyAsync((char*)h->dbg_trace + (size_t)(8 * li + 7) * tb, h->ch_x1, tb, hipMemcpyDeviceToDevice, s);
   };
   auto trace_q = [&](int li) {      // q of block li, as the attention launch reads it
-    if (h->dbg_trace) (void)hipMemcpyAsync((char*)h->dbg_trace + (size_t)(3 * li + 2) * tb, h->q, tb, hipMemcpyDeviceToDevice, s);
+    if (h->dbg_trace) (void)hipMemcpyAsync((char*)h->dbg_trace + (size_t)(8 * li + 2) * tb, h->q, tb, hipMemcpyDeviceToDevice, s);
   };
+  auto trace_x1 = [&]() {};
+  (void)trace_x1;
   if (!chain) {
     for (int li = 0; li < c.n_layer; ++li) {
       if ((rc = layer_in_proj(h, li, h->x, (bf16_t*)h->kv_layers[li], h->max_len, h->lengths, h->rows, s))) return rc;
       trace_q(li);
       if ((rc = run_attention(h, h->q, (bf16_t*)h->kv_layers[li], h->max_len, h->lengths, ext, ext_scalar, h->o1, h->rows, s))) return rc;
-      if ((rc = layer_post_attention(h, li, h->x, h->rows, s))) return rc;
+      if ((rc = layer_post_attention(h, li, h->x, h->rows, s, h->dbg_trace ? (bf16_t*)((char*)h->dbg_trace + (size_t)(8 * li + 7) * tb) : nullptr))) return rc;
       trace(li);
     }
     return ZN_OK;
@@ -873,6 +878,22 @@ static int prefill_attention(zn_handle h, const bf16_t* q, int ldq, const bf16_t
   return ZN_OK;
 }
 
+// Projection of a short prompt (17..64 rows) through the weight-streaming 64-row kernel; false = shape not served.
+template <int EPI>
+static bool run_gemm64s(zn_handle h, const bf16_t* x, const void* W, int N, int K, bf16_t* out, const bf16_t* resid, int M, hipStream_t s) {
+  if (M > 64 || K % 256 || (EPI == EPI_SILU && (N / 2) % 32) || h->tune[7] <= 1) return false;
+  const int groups = (EPI == EPI_SILU) ? (N / 2 + 31) / 32 : (N + 63) / 64;
+  if (groups > ZN_G16_MAX_GROUPS) return false;
+  int ks = 1;
+  while (groups * ks < 256 && ks < 16 && K % (2 * ks * 256) == 0) ks *= 2;
+  if ((size_t)ks * 64 * groups * 64 * sizeof(float) > h->g16_part_bytes) return false;
+  GemvArgs g{};
+  g.W = (const bf16_t*)W; g.N = N; g.K = K; g.x = x; g.out = out; g.resid = resid; g.nrows = M;
+  g.part = h->g16_part; g.tickets = h->g16_tickets; g.ksplit = ks;
+  hipLaunchKernelGGL((gemm64s_kernel<EPI>), dim3(groups, ks), dim3(256), 0, s, g);
+  return true;
+}
+
 // Transformer blocks over all S positions of R rows (hidden [R][S][d]) with `base` keys already cached per row: the
 // residual stream of every position ends in h->pf_x.
 static int transformer_prefill_core(zn_handle h, const bf16_t* hidden, int S, int R, const void* const* kv_layers, int max_len, int base, hipStream_t s) {
@@ -885,18 +906,26 @@ static int transformer_prefill_core(zn_handle h, const bf16_t* hidden, int S, in
     const zn_layer_weights& lw = h->layers[li];
     bf16_t* kv = (bf16_t*)kv_layers[li];
     hipLaunchKernelGGL(layernorm_kernel, dim3(M), dim3(64), 0, s, h->pf_x, (const bf16_t*)lw.norm_w, (const bf16_t*)lw.norm_b, h->pf_n, d, c.norm_eps);
-    launch_gemm(h->pf_n, d, (const bf16_t*)lw.in_proj, h->pf_qkv, nqkv, nullptr, M, nqkv, d, s);
+    // short prompts (<= 64 rows): every projection streams its weights once through gemm64s_kernel (10.7 -> ~2 ms per prefill)
+    if (!run_gemm64s<EPI_STORE>(h, h->pf_n, lw.in_proj, nqkv, d, h->pf_qkv, nullptr, M, s))
+      launch_gemm(h->pf_n, d, (const bf16_t*)lw.in_proj, h->pf_qkv, nqkv, nullptr, M, nqkv, d, s);
     hipLaunchKernelGGL(rope_kv_rows_kernel, dim3(S, R), dim3(256), 0, s, h->pf_qkv, kv, h->rope, S, base, max_len, c.n_heads, c.n_heads_kv, hd, c.rope_positions);
     rc = prefill_attention(h, h->pf_qkv, nqkv, kv, max_len, h->pf_a, nq, S, R, s, base);
     if (rc) return rc;
     if (c.double_out_proj) {
-      launch_gemm(h->pf_a, nq, (const bf16_t*)lw.out_proj, h->pf_n, d, nullptr, M, d, nq, s);
-      launch_gemm(h->pf_n, d, (const bf16_t*)lw.out_proj, h->pf_x, d, h->pf_x, M, d, nq, s);
-    } else launch_gemm(h->pf_a, nq, (const bf16_t*)lw.out_proj, h->pf_x, d, h->pf_x, M, d, nq, s);
+      if (!run_gemm64s<EPI_STORE>(h, h->pf_a, lw.out_proj, d, nq, h->pf_n, nullptr, M, s))
+        launch_gemm(h->pf_a, nq, (const bf16_t*)lw.out_proj, h->pf_n, d, nullptr, M, d, nq, s);
+      if (!run_gemm64s<EPI_RESID>(h, h->pf_n, lw.out_proj, d, nq, h->pf_x, h->pf_x, M, s))
+        launch_gemm(h->pf_n, d, (const bf16_t*)lw.out_proj, h->pf_x, d, h->pf_x, M, d, nq, s);
+    } else if (!run_gemm64s<EPI_RESID>(h, h->pf_a, lw.out_proj, d, nq, h->pf_x, h->pf_x, M, s))
+      launch_gemm(h->pf_a, nq, (const bf16_t*)lw.out_proj, h->pf_x, d, h->pf_x, M, d, nq, s);
     hipLaunchKernelGGL(layernorm_kernel, dim3(M), dim3(64), 0, s, h->pf_x, (const bf16_t*)lw.norm2_w, (const bf16_t*)lw.norm2_b, h->pf_n, d, c.norm_eps);
-    launch_gemm(h->pf_n, d, (const bf16_t*)lw.fc1, h->pf_u, 2 * F, nullptr, M, 2 * F, d, s);
-    hipLaunchKernelGGL(silu_mul_rows_kernel, dim3(M), dim3(256), 0, s, h->pf_u, h->pf_m, F);
-    launch_gemm(h->pf_m, F, (const bf16_t*)lw.fc2, h->pf_x, d, h->pf_x, M, d, F, s);
+    if (!run_gemm64s<EPI_SILU>(h, h->pf_n, lw.fc1, 2 * F, d, h->pf_m, nullptr, M, s)) {
+      launch_gemm(h->pf_n, d, (const bf16_t*)lw.fc1, h->pf_u, 2 * F, nullptr, M, 2 * F, d, s);
+      hipLaunchKernelGGL(silu_mul_rows_kernel, dim3(M), dim3(256), 0, s, h->pf_u, h->pf_m, F);
+    }
+    if (!run_gemm64s<EPI_RESID>(h, h->pf_m, lw.fc2, d, F, h->pf_x, h->pf_x, M, s))
+      launch_gemm(h->pf_m, F, (const bf16_t*)lw.fc2, h->pf_x, d, h->pf_x, M, d, F, s);
   }
   return ZN_OK;
 }

@@ -71,6 +71,25 @@ __device__ __forceinline__ float wave_max(float v) {
   v = group_max<16>(v);
   return fmaxf(fmaxf(readlane_f(v, 0), readlane_f(v, 16)), fmaxf(readlane_f(v, 32), readlane_f(v, 48)));
 }
+// fp64 variants (the exact-accumulation GEMV experiment, ZN_GEMV_F64): a double moves as two DPP / readlane halves
+template <int CTRL> __device__ __forceinline__ double dpp_mov_d(double v) {
+  const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+  const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)u, CTRL, 0xF, 0xF, true);
+  const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(u >> 32), CTRL, 0xF, 0xF, true);
+  return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ double readlane_d(double v, int lane) {
+  const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)u, lane), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(u >> 32), lane);
+  return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+  v += dpp_mov_d<ZN_DPP_XOR1>(v);
+  v += dpp_mov_d<ZN_DPP_XOR2>(v);
+  v += dpp_mov_d<ZN_DPP_HALF_MIRROR>(v);
+  v += dpp_mov_d<ZN_DPP_MIRROR>(v);
+  return (readlane_d(v, 0) + readlane_d(v, 16)) + (readlane_d(v, 32) + readlane_d(v, 48));
+}
 // sum over the lanes of one 16-lane row that share (lane % 4)
 __device__ __forceinline__ float row_stride4_sum(float v) {
   v += dpp_mov<ZN_DPP_ROR4>(v);

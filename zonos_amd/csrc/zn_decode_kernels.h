@@ -328,6 +328,26 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs a) {
     }
   }
 
+  // ZN_GEMV_F64 (experiment): every bf16 x bf16 product is exact in fp64 and so, to 2^-53, is their sum - the
+  // dot product is then correctly rounded like the reference's oneDNN result, instead of carrying the ~2e-7 relative error of
+  // fp32 lane partials + a reduction tree that flips ~2e-4 of the bf16 outputs by one ulp.
+#ifdef ZN_GEMV_F64
+  constexpr bool F64 = (R == 2);
+#else
+  constexpr bool F64 = false;
+#endif
+  double xd[F64 ? NCH : 1][F64 ? R : 1][8];
+  if constexpr (F64) {
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const u32x4 v = xr[c][r];
+        xd[c][r][0] = lo_f(v.x); xd[c][r][1] = hi_f(v.x); xd[c][r][2] = lo_f(v.y); xd[c][r][3] = hi_f(v.y);
+        xd[c][r][4] = lo_f(v.z); xd[c][r][5] = hi_f(v.z); xd[c][r][6] = lo_f(v.w); xd[c][r][7] = hi_f(v.w);
+      }
+  }
+  __shared__ double red_d[F64 && KSPLIT > 1 ? 4 : 1][2][R];
   // ---------------- main loop over work units (next unit's weights are requested before this one is reduced)
   const int F = a.N >> 1;  // EPI_SILU: gate rows start at N/2
   for (int it = 0; it < a.upw; ++it) {
@@ -342,6 +362,41 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs a) {
     for (int r = 0; r < R; ++r) { accA[r] = 0.f; accB[r] = 0.f; }
     WTile<NCH> cur = wt;
     if (it + 1 < a.upw) gemv_load_unit<NCH, KSPLIT, EPI, FULL>(a, u + 1, lane, kw, kbase, pos, wt);
+    if constexpr (F64) {
+      double dA[R], dB[R];
+#pragma unroll
+      for (int r = 0; r < R; ++r) { dA[r] = 0.0; dB[r] = 0.0; }
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        const u32x4 wa = cur.a[c], wb = cur.b[c];
+        const float fa[8] = {lo_f(wa.x), hi_f(wa.x), lo_f(wa.y), hi_f(wa.y), lo_f(wa.z), hi_f(wa.z), lo_f(wa.w), hi_f(wa.w)};
+        const float fb[8] = {lo_f(wb.x), hi_f(wb.x), lo_f(wb.y), hi_f(wb.y), lo_f(wb.z), hi_f(wb.z), lo_f(wb.w), hi_f(wb.w)};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const double da = (double)fa[e], db = (double)fb[e];
+#pragma unroll
+          for (int r = 0; r < R; ++r) { dA[r] = __fma_rn(da, xd[c][r][e], dA[r]); dB[r] = __fma_rn(db, xd[c][r][e], dB[r]); }
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < R; ++r) { dA[r] = wave_sum_d(dA[r]); dB[r] = wave_sum_d(dB[r]); }
+      if constexpr (KSPLIT > 1) {
+        __syncthreads();
+        if (lane == 0) {
+#pragma unroll
+          for (int r = 0; r < R; ++r) { red_d[wave][0][r] = dA[r]; red_d[wave][1][r] = dB[r]; }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          dA[r] = ((red_d[0][0][r] + red_d[1][0][r]) + red_d[2][0][r]) + red_d[3][0][r];
+          dB[r] = ((red_d[0][1][r] + red_d[1][1][r]) + red_d[2][1][r]) + red_d[3][1][r];
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < R; ++r) { accA[r] = (float)dA[r]; accB[r] = (float)dB[r]; }
+      if constexpr (KSPLIT > 1) { if (wave != 0) continue; }
+    } else {
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
 #pragma unroll
@@ -352,7 +407,8 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs a) {
     }
 #pragma unroll
     for (int r = 0; r < R; ++r) { accA[r] = wave_sum(accA[r]); accB[r] = wave_sum(accB[r]); }
-    if constexpr (KSPLIT > 1) {
+    }
+    if constexpr (KSPLIT > 1 && !F64) {
       __syncthreads();
       if (lane == 0) {
 #pragma unroll

@@ -74,6 +74,142 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs a) {
     }
 }
 
+// Short prompts (17..64 rows: the L_c + 1 positions of a text-only prompt x 2 CFG rows): the 128 x 128 tiles above leave
+// N/128 = 16..128 workgroups to stream a whole weight matrix through direct-fragment loads (0.3 TB/s: 10.7 ms per
+// 25-position prefill).  This is the decode side's gemm16s_kernel with four 16-row blocks per weight fragment: a workgroup owns 64
+// weight rows (EPI_SILU: 32 value + their 32 gate rows), walks its K slice in chunks of 256 with whole 512-byte row pieces staged
+// in padded LDS next to the 64-row activation chunk (L2-resident), one 16-row weight tile per wave x four activation blocks
+// on v_mfma_f32_16x16x32_bf16; K splits over gridDim.y workgroups whose fp32 partial tiles meet through write-through
+// stores and an arrival ticket (the last workgroup adds the slices in order: deterministic), then the decode path's epilogues.
+template <int EPI>
+__global__ __launch_bounds__(256) void gemm64s_kernel(GemvArgs a) {
+  constexpr int KC = 256, LDW = KC + 8, NT = 256, TN = 64, HALF = 32, RB = 4, MR = 16 * RB;
+  __shared__ __attribute__((aligned(16))) bf16_t Ws[TN * LDW];
+  __shared__ __attribute__((aligned(16))) bf16_t Xs[MR * LDW];
+  __shared__ int s_last;
+  float (*Ct)[MR + 1] = (float (*)[MR + 1])Ws;                 // the output tile reuses the weight staging area after the K loop
+  static_assert(TN * (MR + 1) * sizeof(float) <= sizeof(Ws), "Ct fits the staging area");
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n = lane & 15, g = lane >> 4;
+  const int grp = blockIdx.x, ys = blockIdx.y;
+  const int K = a.K, F = a.N >> 1;
+  auto wrow = [&](int j) -> int {                              // LDS row j <-> weight row (clamped; masked in the epilogue)
+    if constexpr (EPI == EPI_SILU) {
+      const int r = (j < HALF) ? grp * HALF + j : F + grp * HALF + (j - HALF);
+      const int lim = (j < HALF) ? F : a.N;
+      return r < lim ? r : lim - 1;
+    } else {
+      const int r = grp * TN + j;
+      return r < a.N ? r : a.N - 1;
+    }
+  };
+  const int kslice = K / a.ksplit, kbeg = ys * kslice, nchunks = kslice / KC;
+  u32x4 wr[8], xr[8];
+  const bf16_t *wp[8], *xp[8];
+  int ll[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int idx = j * NT + tid, row = idx >> 5, c16 = idx & 31;          // 64 rows x 32 pieces of 16 B per chunk, both operands
+    wp[j] = a.W + (size_t)wrow(row) * K + kbeg + c16 * 8;
+    xp[j] = a.x + (size_t)(row < a.nrows ? row : a.nrows - 1) * K + kbeg + c16 * 8;
+    ll[j] = row * LDW + c16 * 8;
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) xr[j] = ld16(xp[j]);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) wr[j] = ld_nt16(wp[j]);
+  f32x4 acc[RB];
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb) acc[rb] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int c = 0; c < nchunks; ++c) {
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { *(u32x4*)&Xs[ll[j]] = xr[j]; *(u32x4*)&Ws[ll[j]] = wr[j]; }
+    __syncthreads();
+    if (c + 1 < nchunks) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) xr[j] = ld16(xp[j] + (size_t)(c + 1) * KC);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) wr[j] = ld_nt16(wp[j] + (size_t)(c + 1) * KC);
+    }
+    const bf16_t* wf = &Ws[(wave * 16 + n) * LDW + 8 * g];
+#pragma unroll
+    for (int st = 0; st < KC / 32; ++st) {
+      const u32x4 bw = *(const u32x4*)(wf + 32 * st);
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb) {
+        const u32x4 ax = *(const u32x4*)(&Xs[(rb * 16 + n) * LDW + 8 * g] + 32 * st);
+        acc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(zn_bf16x8p, ax), __builtin_bit_cast(zn_bf16x8p, bw), acc[rb], 0, 0, 0);
+      }
+    }
+  }
+  __syncthreads();                                             // every wave is done with Ws: it becomes Ct
+  // D layout: col (LDS row wave*16 + n) = lane & 15, row (activation row of block rb) = 4*(lane>>4) + reg
+  if (a.ksplit > 1) {
+    const size_t ld = (size_t)gridDim.x * TN;
+    float* pp = a.part + ((size_t)ys * MR) * ld + (size_t)grp * TN + wave * 16 + n;
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) st_wt(pp + (size_t)(rb * 16 + 4 * g + reg) * ld, acc[rb][reg]);
+    __builtin_amdgcn_s_waitcnt(0);                             // vmcnt(0): stores acknowledged
+    __syncthreads();
+    if (tid == 0) {
+      const int t = __hip_atomic_fetch_add(a.tickets + grp, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      s_last = (t == a.ksplit - 1);
+      if (s_last) __hip_atomic_store(a.tickets + grp, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (!s_last) return;
+    // MR * TN / NT = 16 tile elements per thread, four at a time with every slice of the four requested before the first add
+    for (int i0 = 0; i0 < MR * TN / NT; i0 += 4) {
+      float v[4][16];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int item = (i0 + i) * NT + tid, m = item / TN, col = item % TN;
+        const float* q = a.part + (size_t)m * ld + (size_t)grp * TN + col;
+#pragma unroll
+        for (int y = 0; y < 16; ++y) v[i][y] = (y < a.ksplit) ? ld_wt(q + (size_t)y * MR * ld) : 0.f;
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int item = (i0 + i) * NT + tid, m = item / TN, col = item % TN;
+        float sum = 0.f;
+#pragma unroll
+        for (int y = 0; y < 16; ++y) sum += v[i][y];
+        Ct[col][m] = sum;
+      }
+    }
+  } else {
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) Ct[wave * 16 + n][rb * 16 + 4 * g + reg] = acc[rb][reg];
+  }
+  __syncthreads();
+  // ---- epilogue: TN/2 row pairs x MR activation rows, 8 items per thread
+#pragma unroll
+  for (int it = 0; it < (TN / 2) * MR / NT; ++it) {
+    const int item = it * NT + tid, m = item % MR, pj = item / MR;
+    if (m >= a.nrows) continue;
+    if constexpr (EPI == EPI_SILU) {
+      const int u = grp * HALF + pj;
+      if (u >= F) continue;
+      gemv_epilogue<EPI>(a, m, u, F + u, true, u, Ct[pj][m], Ct[HALF + pj][m], 0u, 1.f, 0.f, 0);
+    } else {
+      const int rowA = grp * TN + 2 * pj, rowB = rowA + 1;
+      if (rowA >= a.N) continue;
+      const bool b_ok = rowB < a.N;
+      unsigned resid = 0;
+      if constexpr (EPI == EPI_RESID) {
+        const size_t o = (size_t)m * a.N + rowA;
+        resid = b_ok ? *(const unsigned*)(a.resid + o) : (unsigned)a.resid[o];
+      }
+      gemv_epilogue<EPI>(a, m, rowA, rowB, b_ok, rowA >> 1, Ct[2 * pj][m], b_ok ? Ct[2 * pj + 1][m] : 0.f, resid, 1.f, 0.f, 0);
+    }
+  }
+}
+
 // LDS-staged variant for M >= 256 rows (long prompts).  The direct-fragment kernel above asks the vector-memory pipe for
 // 16 different rows per 16-lane phase (the access pattern that bounded the decode-side gemm16_kernel); here both operand
 // panels of a 128 x 128 x 64 step are fetched as whole 128-byte row pieces (8 lanes x 16 B per row piece), stored to LDS
