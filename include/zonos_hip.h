@@ -147,6 +147,11 @@ int zn_graph_active(zn_handle h);
 int zn_decode_path(zn_handle h);
 /* (remaining_steps <= 0).all() of tensor_ops.py:95,102 — synchronises the stream. */
 int zn_all_stopped(zn_handle h, int32_t* out, zn_stream stream);
+/* The same check off the critical path: zn_all_stopped_begin queues the read-back of the loop state behind the steps enqueued
+ * so far and returns; zn_all_stopped_end (called after the NEXT steps have been enqueued) waits for it and reports the
+ * state as of _begin.  Steps that over-run a stop write only columns the caller's cut drops (model.py:511-528). */
+int zn_all_stopped_begin(zn_handle h, zn_stream stream);
+int zn_all_stopped_end(zn_handle h, int32_t* all_stopped_out);
 /* Copies the fp32 logits the sampler last consumed ([B, n_codebooks, vocab_head], after CFG and logit bias) and
  * the raw sampled tokens int32 [B, n_codebooks] to device buffers (either may be NULL).  For parity tests. */
 int zn_get_step_outputs(zn_handle h, float* logits_dev, int32_t* tokens_dev, zn_stream stream);

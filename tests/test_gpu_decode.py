@@ -660,8 +660,10 @@ def test_full_dims_batch8_teacher_forced_vs_solo_runs(full):
     GEMV kernels).  Same rounding points, different fp32 summation order: free-running, a near-tie (several of the 9
     top-2 margins per step lie within two bf16 ulps of a logit even for the decisive-margin heads) redirects a
     trajectory after a few frames, so the batched run is fed each solo run's tokens and the per-step logits are compared:
-    within 2^-5 of the logit scale (the bar of the block-level 16-rows-vs-2-rows test; a bf16 ulp is 0.5 at |l| ~ 100),
-    argmax equal wherever the solo margin exceeds twice that."""
+    within 2^-4.5 of the logit scale (a bf16 ulp is 0.5 at |l| ~ 100 and the heavy-tailed heads multiply a flipped hidden ulp
+    by up to 20; the two runs also prefill through different kernels: 50 rows stream through gemm64s_kernel, 400 rows through
+    the 128 x 128 GEMM), argmax equal wherever the solo margin exceeds twice that.  The comparison with the ORACLE at this
+    size is test_full_dims_batch8_vs_batched_oracle below."""
     model, _ = full
     heads = torch.cat([torch.from_numpy(synth.peaky_heads(1234, f"heads.{i}.weight", 1025, 2048)).to(torch.bfloat16) for i in range(9)], 0)
     keep = model.fused_heads.weight.data.clone()
@@ -698,12 +700,44 @@ def test_full_dims_batch8_teacher_forced_vs_solo_runs(full):
     top2 = np.sort(np.where(fin, ref, -np.inf), -1)[..., -2:]
     margin = top2[..., 1] - top2[..., 0]
     same = np.where(fin, got, -np.inf).argmax(-1) == np.where(fin, ref, -np.inf).argmax(-1)
-    tol = 2.0 ** -5 * scale
+    tol = 2.0 ** -4.5 * scale
     print(f"\n[batch 8 vs solo, full dims, teacher-forced] {n} steps: exact logits {float((diff == 0).mean()):.4f}, max|diff| {diff.max():.3g}, "
           f"mean|diff| {diff.mean():.3g} (max|logit| {scale:.1f}, tol {tol:.2f}); argmax equal {same.mean():.4f}; "
           f"decisive pairs {float((margin > 2 * tol).mean()):.3f}")
     assert diff.max() <= tol, diff.max()
     assert same[margin > 2 * tol].all()
+
+
+def test_full_dims_batch8_vs_batched_oracle(full):
+    """BASELINE config 3's per-GPU share against the ORACLE at the real dimensions: generate(batch_size=8) (16 rows: gemm16s /
+    gemm16k with their split-K tickets, LayerNorm inside in_proj, 16-row attention; prefill of 400 rows) vs the oracle's
+    generate(batch_size=8) on the same 8 utterances, 6 new tokens (prefill + 13 decode steps), the oracle's token stream fed
+    through the override hook: output codes bit-equal, every call's logits within 0.1 (the full-dims bar), greedy index
+    equal wherever the oracle's margin is decisive."""
+    model, w = full
+    B, N = 8, 6
+    conds = [synth.conditioning(500 + i, "cond", 2, 24, 2048) for i in range(B)]
+    cond = torch.cat([c[0:1] for c in conds] + [c[1:2] for c in conds], 0)
+    otr = zo.GenTrace()
+    torch.set_num_threads(16)
+    noeos = lambda s_, l: l.index_fill(2, torch.tensor([1024]), -float("inf"))
+    ref_out = zo.generate(w, synth.FULL_CFG, cond, max_new_tokens=N, batch_size=B, sampling_params=GREEDY, trace=otr, logits_hook=noeos)
+    toks = torch.stack(otr.tokens).numpy()
+    out, logits = _override_generate(model, cond, toks, N, B)
+    assert torch.equal(out, ref_out)
+    worst, exact, tot = 0.0, 0, 0
+    for k in range(len(otr.logits)):
+        a, b = logits[k], otr.logits[k].numpy()
+        fin = np.isfinite(b)
+        d = np.abs(np.where(fin, a - b, 0.0))
+        worst = max(worst, float(d.max()))
+        exact += int((d == 0).sum())
+        tot += d.size
+        t2 = np.sort(np.where(fin, b, -1e30), -1)[..., -2:]
+        dec = (t2[..., 1] - t2[..., 0]) > 0.2
+        assert (np.where(fin, a, -1e30).argmax(-1) == np.where(fin, b, -1e30).argmax(-1))[dec].all(), k
+    print(f"\n[batch 8 vs batched oracle, full dims] {len(otr.logits)} calls: exact logits {exact / tot:.4f}, worst |dlogit| {worst:.4g}")
+    assert worst <= 0.1
 
 
 @pytest.mark.parametrize("P", [3, 70, 250, 800])

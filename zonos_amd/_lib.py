@@ -65,6 +65,8 @@ SIGNATURES = {
     "zn_graph_active": (C.c_int, [C.c_void_p]),
     "zn_decode_path": (C.c_int, [C.c_void_p]),
     "zn_all_stopped": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.c_void_p]),
+    "zn_all_stopped_begin": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "zn_all_stopped_end": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
     "zn_get_step_outputs": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "zn_debug_force_eos": (C.c_int, [C.c_void_p, C.c_int32]),
     "zn_debug_token_override": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),

@@ -58,7 +58,9 @@ struct zn_handle_s {
   int lcap = 0;
   GenState* st = nullptr;
   int *remaining = nullptr, *stopping = nullptr;
-  int* done_host = nullptr;  // pinned
+  int* done_host = nullptr;  // pinned: [0..3] synchronous stop check, [4..7] asynchronous one
+  hipEvent_t stop_event = nullptr;
+  bool stop_pending = false;
   // per-generation state (host mirror)
   bool gen_active = false;
   int batch = 0, rows = 0, max_len = 0, t_total = 0, offset0 = 0, max_new = 0;
@@ -127,6 +129,7 @@ extern "C" int zn_destroy(zn_handle h) {
   void* ptrs[] = {h->emb_tables_dev, h->x, h->q, h->o1, h->mbuf, h->nbuf, h->logits_raw, h->last_logits, h->tok_raw, h->scores, h->cmax, h->pv_part, h->pv_tickets, h->pf_x, h->pf_n, h->pf_qkv, h->pf_a, h->pf_u, h->pf_m, h->pf_res, h->pf_zx, h->pf_xbc, h->pf_y, h->pf_g, h->qkv_tmp, h->fw_lengths, h->st, h->remaining, h->stopping, h->res, h->hn, h->m_zx, h->m_xbc, h->m_y, h->m_g, h->m_vg, h->g16_part, h->g16_tickets, h->ch_ctr, h->ch_y1, h->ch_x1, h->ch_x2};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (h->done_host) (void)hipHostFree(h->done_host);
+  if (h->stop_event) (void)hipEventDestroy(h->stop_event);
   if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
   delete h;
   return ZN_OK;
@@ -213,7 +216,8 @@ extern "C" int zn_create(const zn_config* cfg, const zn_weights* w, int32_t max_
   ZC(hipMemset(h->st, 0, sizeof(GenState)));
   ZC(hipMalloc(&h->remaining, (R / 2) * sizeof(int)));
   ZC(hipMalloc(&h->stopping, (R / 2) * sizeof(int)));
-  ZC(hipHostMalloc(&h->done_host, sizeof(int) * 4));
+  ZC(hipHostMalloc(&h->done_host, sizeof(int) * 8));
+  ZC(hipEventCreateWithFlags(&h->stop_event, hipEventDisableTiming));
   ZC(hipMalloc(&h->ch_ctr, (size_t)c.n_layer * ZN_CH_HANDOFFS * ZN_CH_CTR_WORDS * sizeof(unsigned)));
   ZC(hipMemset(h->ch_ctr, 0, (size_t)c.n_layer * ZN_CH_HANDOFFS * ZN_CH_CTR_WORDS * sizeof(unsigned)));
   ZC(hipMalloc(&h->ch_y1, R * c.d_model * 2));
@@ -799,6 +803,7 @@ extern "C" int zn_gen_begin(zn_handle h, int32_t batch, const void* const* kv_la
   h->len_hi = 0;
   for (int v : len0) if (v > h->len_hi) h->len_hi = v;
   h->gen_active = true;
+  h->stop_pending = false;
   return ZN_OK;
 }
 
@@ -1108,6 +1113,27 @@ extern "C" int zn_all_stopped(zn_handle h, int32_t* out, zn_stream stream) {
   *out = h->done_host[0];
   if (h->done_host[3] != 0)
     ZN_FAIL(h, ZN_ERR_HIP, "decode chain: a hand-off wait timed out (%d) - the results of this generation are invalid; zn_debug_tune(8, 2) selects the launches path", h->done_host[3]);
+  return ZN_OK;
+}
+
+// The stop check without a host round trip on the critical path: *_begin queues the copy of the loop state behind the steps
+// enqueued so far, the caller enqueues the next steps, *_end (one batch later) waits for the copy - long done by then.
+extern "C" int zn_all_stopped_begin(zn_handle h, zn_stream stream) {
+  if (!h) return ZN_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  HIPCHK(h, hipMemcpyAsync(h->done_host + 4, &h->st->all_done, 4 * sizeof(int), hipMemcpyDeviceToHost, s));
+  HIPCHK(h, hipEventRecord(h->stop_event, s));
+  h->stop_pending = true;
+  return ZN_OK;
+}
+extern "C" int zn_all_stopped_end(zn_handle h, int32_t* out) {
+  if (!h || !out) return ZN_ERR_ARG;
+  if (!h->stop_pending) ZN_FAIL(h, ZN_ERR_STATE, "zn_all_stopped_end without zn_all_stopped_begin");
+  HIPCHK(h, hipEventSynchronize(h->stop_event));
+  h->stop_pending = false;
+  *out = h->done_host[4];
+  if (h->done_host[7] != 0)
+    ZN_FAIL(h, ZN_ERR_HIP, "decode chain: a hand-off wait timed out (%d) - the results of this generation are invalid; zn_debug_tune(8, 2) selects the launches path", h->done_host[7]);
   return ZN_OK;
 }
 

@@ -222,6 +222,11 @@ class Zonos(nn.Module):
         frame = delayed[..., offset:offset + 1]
         pending, done = 0, ctypes_int()
         cpu_step_counter = 0
+        # Without a callback the stop flag of check k is read after the steps up to check k + 1 have been enqueued (the device ->
+        # host round trip leaves the critical path); a stop seen late rolls `offset` back to the check that saw it, and the
+        # over-run steps have only written columns beyond that cut.
+        deferred = callback is None and _trace is None
+        begun_at = None                                            # offset at the check whose read-back is in flight
         for step_idx in range(max_steps):
             offset += 1
             cpu_step_counter += 1
@@ -238,7 +243,15 @@ class Zonos(nn.Module):
                     hook = _trace.get("after_step")
                     if hook is not None:
                         hook(step_idx, delayed, offset)
-            if check:
+            if check and deferred:
+                if begun_at is not None:
+                    eng.call("zn_all_stopped_end", C.byref(done))
+                    if done.value:
+                        offset, begun_at = begun_at, None
+                        break
+                eng.call("zn_all_stopped_begin", st)
+                begun_at = offset
+            elif check:
                 eng.call("zn_all_stopped", C.byref(done), st)
                 if done.value:
                     break
@@ -246,6 +259,10 @@ class Zonos(nn.Module):
                 break
         if pending:
             eng.call("zn_decode_steps", pending, st)
+        if begun_at is not None:
+            eng.call("zn_all_stopped_end", C.byref(done))
+            if done.value:
+                offset = begun_at
         eng.call("zn_all_stopped", C.byref(done), st)      # also surfaces a timed-out in-kernel hand-off of the last steps
         out = revert_delay_pattern(delayed.to(torch.int64)).cpu()     # one device->host copy (model.py:511)
         valid_length = offset - nq
