@@ -53,8 +53,8 @@ def test_bad_arguments_return_status_not_crash(lib):
 
 
 # ---------------------------------------------------------------------------------------------- emitted hand-off ISA
-# The cross-workgroup hand-offs (split-K combine of gemm16s_kernel, per-block combine of the split P.V pass, the persistent
-# chain's counters) order relaxed agent-scope accesses by instruction selection, not by fences: partial results leave by
+# The cross-workgroup hand-offs (split-K combines of gemm16s_kernel / gemm64s_kernel, per-block combine of the split P.V pass, the
+# persistent chain's granules) order relaxed agent-scope accesses by instruction selection, not by fences: partial results leave by
 # write-through (sc1) stores, the storing wave drains (s_waitcnt vmcnt(0)) before the workgroup's barrier and the arrival
 # atomic, and every load of handed-off bytes is an sc1 load (MI355X_MICROARCH.md "Valid forms", table row 1;
 # cdna_hip_programming.md Guideline 16 R1).  Nothing in the memory model promises that selection, so the built code object
@@ -102,26 +102,22 @@ def _check_ticket_kernel(ins):
 
 
 def test_ticketed_combines_use_write_through_stores_and_sc1_loads(kernels_isa):
-    names = [n for n in kernels_isa if re.match(r"_Z14gemm16s_kernelILi\d+ELi\d+EE", n) or re.match(r"_Z14attn_pv_kernelILi\d+ELi\d+ELi2EE", n)]
+    names = [n for n in kernels_isa if re.match(r"_Z14gemm16s_kernelILi\d+ELi\d+EE", n) or re.match(r"_Z14attn_pv_kernelILi\d+ELi\d+ELi2EE", n)
+             or re.match(r"_Z14gemm64s_kernelILi\d+EE", n)]
     assert len(names) >= 10
     for n in names:
         _check_ticket_kernel(kernels_isa[n])
 
 
-def test_chain_kernel_handoffs_are_sc1_and_drained(kernels_isa):
+def test_chain_kernel_handoffs_are_granules_and_sc1_sweeps(kernels_isa):
+    """The persistent chain publishes 8-byte {tag, data} granules with ONE write-through store each (the data is the flag:
+    Guideline 16 R2) and every load of handed-off bytes is an sc1 buffer load."""
     names = [n for n in kernels_isa if n.startswith("_Z12chain_kernel")]
     assert len(names) == 4
     for n in names:
         ins = kernels_isa[n]
-        gathers = [l for l in ins if l.startswith("buffer_load_dwordx4")]
-        assert gathers and all(" sc1" in l for l in gathers), n                      # every gather of handed-off bytes bypasses L1
-        published = [i for i, l in enumerate(ins) if l.startswith("global_store_dword ") and " sc1" in l]
-        assert len(published) >= 3, n
-        arrivals = 0
-        for j in published:                                                           # publish -> drain -> arrival atomic, in that order
-            nxt = next((i for i in range(j + 1, min(len(ins), j + 80)) if ins[i].startswith("global_atomic_add")), None)
-            if nxt is None or any(ins[i].startswith("global_store_dword ") for i in range(j + 1, nxt)):
-                continue
-            assert any(ins[i].startswith("s_waitcnt") and "vmcnt(0)" in ins[i] for i in range(j + 1, nxt)), (n, j)
-            arrivals += 1
-        assert arrivals >= 3, n
+        sweeps = [l for l in ins if l.startswith("buffer_load_dwordx4")]
+        assert sweeps and all(" sc1" in l for l in sweeps), n
+        granules = [l for l in ins if l.startswith("global_store_dwordx2") and " sc1" in l]
+        assert len(granules) >= 3, n                                                  # y1, x1, m (+ x2 when the next in_proj follows)
+        assert not any(l.startswith("global_atomic_add") and "sc1" in l for l in ins)

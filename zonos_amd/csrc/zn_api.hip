@@ -34,9 +34,11 @@ struct zn_handle_s {
   bf16_t *res = nullptr, *hn = nullptr, *m_zx = nullptr, *m_xbc = nullptr, *m_y = nullptr, *m_g = nullptr;
   float* m_vg = nullptr;            // [rows][m_d_inner] fp32 y * silu(z) (mamba_ssm_kernel -> out_proj prologue)
   int m_nheads = 0, m_conv_dim = 0, m_d_in_proj = 0;
-  // persistent post-attention chain (zn_chain_kernel.h): hand-off counters [n_layer][4][ZN_CH_CTR_WORDS], intermediate y1
-  unsigned* ch_ctr = nullptr;
-  bf16_t *ch_y1 = nullptr, *ch_x1 = nullptr, *ch_x2 = nullptr;   // y1, x after the attention half, second residual-stream buffer (blocks alternate h->x / ch_x2)
+  // persistent post-attention chain (zn_chain_kernel.h): granule buffers of the four in-launch hand-offs ([rows][len / 2] x 8 B),
+  // the launch epoch (tag), the second residual-stream buffer (blocks alternate h->x / ch_x2)
+  unsigned long long *ch_gy1 = nullptr, *ch_gx1 = nullptr, *ch_gx2 = nullptr, *ch_gm = nullptr;
+  unsigned* ch_epoch = nullptr;
+  bf16_t* ch_x2 = nullptr;
   bf16_t* dbg_trace = nullptr;               // diagnostic: [n_layer][2][rows * d] copies of (x after the block, attention output) per decode step
   unsigned long long* ch_stamps = nullptr;   // diagnostic: [n_layer][32] timeline stamps of workgroup 0 (zn_debug_chain_stamps)
   int ch_variant = 0;          // 0 = shapes do not fit (launches path), 1 = <4,1,8,4,2> (Zonos-v0.1 dims), 2 = <1,1,2,1,1> (d_model 512)
@@ -70,7 +72,7 @@ struct zn_handle_s {
   int *lengths = nullptr, *codes = nullptr;
   int force_eos_step = -1;
   float eos_bias = 0.f;
-  int tune[12] = {256, 512, 512, 1024, 512, 704, 2, 2, 0, 0, 0, 0};   // target workgroups: in_proj, out_proj, fc1, fc2, heads; [5] longest context of the fused attention launch; [6] > 1: multi-step graphs; [7] > 1: LDS-staged small-M projections; [8] = 1: persistent chain kernel per block instead of five launches (batch 1); [9]: KV capacity above which the P.V pass splits per block (0 = 1408); [10] = 2: VALU prefill attention; [11] = 2: no in-workgroup-split small-M kernel
+  int tune[12] = {256, 512, 512, 1024, 512, 704, 2, 2, 0, 0, 0, 0};   // target workgroups: in_proj, out_proj, fc1, fc2, heads; [5] longest context of the fused attention launch; [6] > 1: multi-step graphs; [7] > 1: LDS-staged small-M projections; [8] = 2: no persistent chain kernel (five launches per block instead); [9]: KV capacity above which the P.V pass splits per block (0 = 1408); [10] = 2: VALU prefill attention; [11] = 2: no in-workgroup-split small-M kernel
   const int* tok_override = nullptr;
   int tok_override_calls = 0;
   hipStream_t cap_stream = nullptr;
@@ -126,7 +128,7 @@ static void free_graph(zn_handle h) {
 extern "C" int zn_destroy(zn_handle h) {
   if (!h) return ZN_OK;
   free_graph(h);
-  void* ptrs[] = {h->emb_tables_dev, h->x, h->q, h->o1, h->mbuf, h->nbuf, h->logits_raw, h->last_logits, h->tok_raw, h->scores, h->cmax, h->pv_part, h->pv_tickets, h->pf_x, h->pf_n, h->pf_qkv, h->pf_a, h->pf_u, h->pf_m, h->pf_res, h->pf_zx, h->pf_xbc, h->pf_y, h->pf_g, h->qkv_tmp, h->fw_lengths, h->st, h->remaining, h->stopping, h->res, h->hn, h->m_zx, h->m_xbc, h->m_y, h->m_g, h->m_vg, h->g16_part, h->g16_tickets, h->ch_ctr, h->ch_y1, h->ch_x1, h->ch_x2};
+  void* ptrs[] = {h->emb_tables_dev, h->x, h->q, h->o1, h->mbuf, h->nbuf, h->logits_raw, h->last_logits, h->tok_raw, h->scores, h->cmax, h->pv_part, h->pv_tickets, h->pf_x, h->pf_n, h->pf_qkv, h->pf_a, h->pf_u, h->pf_m, h->pf_res, h->pf_zx, h->pf_xbc, h->pf_y, h->pf_g, h->qkv_tmp, h->fw_lengths, h->st, h->remaining, h->stopping, h->res, h->hn, h->m_zx, h->m_xbc, h->m_y, h->m_g, h->m_vg, h->g16_part, h->g16_tickets, h->ch_gy1, h->ch_gx1, h->ch_gx2, h->ch_gm, h->ch_epoch, h->ch_x2};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (h->done_host) (void)hipHostFree(h->done_host);
   if (h->stop_event) (void)hipEventDestroy(h->stop_event);
@@ -218,13 +220,17 @@ extern "C" int zn_create(const zn_config* cfg, const zn_weights* w, int32_t max_
   ZC(hipMalloc(&h->stopping, (R / 2) * sizeof(int)));
   ZC(hipHostMalloc(&h->done_host, sizeof(int) * 8));
   ZC(hipEventCreateWithFlags(&h->stop_event, hipEventDisableTiming));
-  ZC(hipMalloc(&h->ch_ctr, (size_t)c.n_layer * ZN_CH_HANDOFFS * ZN_CH_CTR_WORDS * sizeof(unsigned)));
-  ZC(hipMemset(h->ch_ctr, 0, (size_t)c.n_layer * ZN_CH_HANDOFFS * ZN_CH_CTR_WORDS * sizeof(unsigned)));
-  ZC(hipMalloc(&h->ch_y1, R * c.d_model * 2));
-  ZC(hipMalloc(&h->ch_x1, R * c.d_model * 2));
+  for (unsigned long long** g : {&h->ch_gy1, &h->ch_gx1, &h->ch_gx2}) {
+    ZC(hipMalloc(g, R * (c.d_model / 2) * 8));
+    ZC(hipMemset(*g, 0, R * (c.d_model / 2) * 8));             // tag 0 is never a launch's epoch
+  }
+  ZC(hipMalloc(&h->ch_gm, R * (c.d_ff / 2 + 1) * 8));
+  ZC(hipMemset(h->ch_gm, 0, R * (c.d_ff / 2 + 1) * 8));
+  ZC(hipMalloc(&h->ch_epoch, 64));
+  { const unsigned one = 1; ZC(hipMemcpy(h->ch_epoch, &one, sizeof one, hipMemcpyHostToDevice)); }
   ZC(hipMalloc(&h->ch_x2, R * c.d_model * 2));
   h->ch_variant = chain_variant_for(c);
-  if (const char* e = getenv("ZN_CHAIN")) if (atoi(e) == 1) h->tune[8] = 1;
+  if (const char* e = getenv("ZN_CHAIN")) if (atoi(e) == 0) h->tune[8] = 2;
   {   // split-K partial tiles + tickets of the small-M projections (batches of 3..8 utterances; short-prompt prefill at any batch)
     ZC(hipMalloc(&h->g16_part, ZN_G16_PART_BYTES));
     ZC(hipMalloc(&h->g16_tickets, ZN_G16_MAX_GROUPS * sizeof(int)));
@@ -529,16 +535,16 @@ static int layer_decode(zn_handle h, int li, bf16_t* x, bf16_t* kv, int max_len,
   return layer_post_attention(h, li, x, rows, s);
 }
 
-// The persistent chain serves the step when the model fits an instantiation, at batch 1 (two rows), when selected
-// (zn_debug_tune(8, 1) or ZN_CHAIN=1 in the environment at zn_create; default: the launches path, which is faster today).
-static bool chain_active(zn_handle h, int rows) { return h->ch_variant != 0 && rows == 2 && h->tune[8] == 1; }
+// The persistent chain serves the step when the model fits an instantiation, at batch 1 (two rows), unless switched off
+// (zn_debug_tune(8, 2), or ZN_CHAIN=0 in the environment at zn_create): 1.07 vs 1.16 ms per decode step at the Zonos-v0.1 dimensions.
+static bool chain_active(zn_handle h, int rows) { return h->ch_variant != 0 && rows == 2 && h->tune[8] != 2; }
 
 // The chain never updates the residual stream in place (zn_chain_kernel.h): block li reads it from one buffer and leaves it
 // in the other.
 static bf16_t* chain_x(zn_handle h, int li) { return (li & 1) ? h->ch_x2 : h->x; }
 
 // Post-attention chain of block `li` plus the in_proj of block li + 1 in ONE launch (zn_chain_kernel.h); x = h->x, the
-// attention output in h->o1, the next block's q in h->q.  The hand-off counters of the layer must be zero.
+// attention output in h->o1, the next block's q in h->q.
 static int launch_chain(zn_handle h, int li, const std::vector<const void*>& kv_layers, int max_len, const int* lengths, hipStream_t s) {
   const zn_config& c = h->cfg;
   const zn_layer_weights& lw = h->layers[li];
@@ -546,8 +552,9 @@ static int launch_chain(zn_handle h, int li, const std::vector<const void*>& kv_
   ChainArgs a{};
   a.W_out = (const bf16_t*)lw.out_proj; a.W_fc1 = (const bf16_t*)lw.fc1; a.W_fc2 = (const bf16_t*)lw.fc2;
   a.ln2_w = (const bf16_t*)lw.norm2_w; a.ln2_b = (const bf16_t*)lw.norm2_b; a.eps = c.norm_eps; a.F = c.d_ff;
-  a.a = h->o1; a.xin = chain_x(h, li); a.xout = chain_x(h, li + 1); a.x1 = h->ch_x1; a.y1 = h->ch_y1; a.m = h->mbuf;
-  a.ctr = h->ch_ctr + (size_t)li * ZN_CH_HANDOFFS * ZN_CH_CTR_WORDS; a.tmo = &h->st->pad[0];
+  a.a = h->o1; a.xin = chain_x(h, li); a.xout = chain_x(h, li + 1);
+  a.g_y1 = h->ch_gy1; a.g_x1 = h->ch_gx1; a.g_x2 = h->ch_gx2; a.g_m = h->ch_gm;
+  a.epoch = h->ch_epoch; a.tmo = &h->st->pad[0];
   a.stamps = h->ch_stamps ? h->ch_stamps + (size_t)li * 32 : nullptr;
   if (!last) {
     const zn_layer_weights& nx = h->layers[li + 1];
@@ -577,8 +584,7 @@ static int decode_blocks(zn_handle h, const int* ext, int ext_scalar, hipStream_
     if (!h->dbg_trace) return;
     (void)hipMemcpyAsync((char*)h->dbg_trace + (size_t)(8 * li) * tb, chain ? chain_x(h, li + 1) : h->x, tb, hipMemcpyDeviceToDevice, s);
     (void)hipMemcpyAsync((char*)h->dbg_trace + (size_t)(8 * li + 1) * tb, h->o1, tb, hipMemcpyDeviceToDevice, s);
-    (void)hipMemcpyAsync((char*)h->dbg_trace + (size_t)(8 * li + 3) * tb, h->mbuf, (size_t)h->rows * c.d_ff * 2 <= 4 * tb ? (size_t)h->rows * c.d_ff * 2 : 4 * tb, hipMemcpyDeviceToDevice, s);
-    if (chain) (void)hipMemcpyAsync((char*)h->dbg_trace + (size_t)(8 * li + 7) * tb, h->ch_x1, tb, hipMemcpyDeviceToDevice, s);
+    if (!chain) (void)hipMemcpyAsync((char*)h->dbg_trace + (size_t)(8 * li + 3) * tb, h->mbuf, (size_t)h->rows * c.d_ff * 2 <= 4 * tb ? (size_t)h->rows * c.d_ff * 2 : 4 * tb, hipMemcpyDeviceToDevice, s);
   };
   auto trace_q = [&](int li) {      // q of block li, as the attention launch reads it
     if (h->dbg_trace) (void)hipMemcpyAsync((char*)h->dbg_trace + (size_t)(8 * li + 2) * tb, h->q, tb, hipMemcpyDeviceToDevice, s);
@@ -595,7 +601,6 @@ static int decode_blocks(zn_handle h, const int* ext, int ext_scalar, hipStream_
     }
     return ZN_OK;
   }
-  HIPCHK(h, hipMemsetAsync(h->ch_ctr, 0, (size_t)c.n_layer * ZN_CH_HANDOFFS * ZN_CH_CTR_WORDS * sizeof(unsigned), s));
   if ((rc = layer_in_proj(h, 0, h->x, (bf16_t*)h->kv_layers[0], h->max_len, h->lengths, h->rows, s))) return rc;
   for (int li = 0; li < c.n_layer; ++li) {
     trace_q(li);

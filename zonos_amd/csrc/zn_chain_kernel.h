@@ -12,18 +12,19 @@
 // so the results are bit-identical to the launches path) with three tiles requested ahead in registers — requests run
 // across the op boundaries, so the HBM stream no longer drains at every dependency —, and a fifth, communication wave
 // (it issues no weight loads, so its own waits cover only the hand-off traffic) finishes each op: epilogue of the
-// workgroup's rows, write-through (sc1) stores, drain, one arrival on a sharded agent-scope counter, a bounded relaxed
-// poll of the shards (sc1), an sc1 gather of the op's whole output vector (8-32 KB), LayerNorm where the next op wants
-// it, and the vector into LDS for the compute waves (cdna_hip_programming.md Guideline 16 R1; MI355X_MICROARCH.md
-// visibility table row 1).  Every spin is bounded; a timeout sets a word the host turns into an error.
+// workgroup's rows, published as 8-byte {tag, two bf16} granules (one write-through store each: the data is the flag, no
+// drain, no counter: cdna_hip_programming.md Guideline 16 R2); the consumer sweeps the op's whole output vector with sc1
+// loads until every tag carries this launch's epoch (bounded), applies LayerNorm where the next op wants it and puts the
+// vector into LDS for the compute waves; fc2's input (32 KB) is swept by the compute waves themselves, a K quarter each.
+// The first version arrived on sharded counters and polled them: 5-6 us per hand-off (publish 0.5-1.7 behind the CU's own
+// prefetch queue, 2.6-4.8 until every arrival was seen, gather 0.4-1.5); DESIGN.md section 4 has both timelines.
 #pragma once
 #include <utility>
 #include "zn_decode_kernels.h"
 
-#define ZN_CH_NSHARD 8
-#define ZN_CH_SSTRIDE 16                                   // u32 between shards: one 64-B line each
-#define ZN_CH_CTR_WORDS (ZN_CH_NSHARD * ZN_CH_SSTRIDE)     // words per hand-off counter block
-#define ZN_CH_HANDOFFS 4
+#ifndef ZN_CH_DEFER
+#define ZN_CH_DEFER 1                                      // 1: a weight request for a LATER op waits until this op's results are published
+#endif
 #define ZN_CH_CWAVES 4                                     // compute waves (a multiple of 4); the next wave = communication wave
 #define ZN_CH_NBUF 3                                       // weight tiles requested ahead per compute wave (register buffers)
 #define ZN_CH_THREADS ((ZN_CH_CWAVES + 1) * 64)
@@ -39,13 +40,13 @@ struct ChainArgs {
   // (even by an sc1 load) can survive in the XCD's L2 and be hit by a later gather although other XCDs have rewritten it
   // (observed: a stale x element once per ~4000 launches with x updated in place).
   const bf16_t* xin;                                       // [2][d] residual stream entering the block (read only)
-  bf16_t* x1;                                              // [2][d] after the attention half (op 1)
   bf16_t* xout;                                            // [2][d] residual stream leaving the block (op 3); != xin
-  bf16_t* y1;                                              // [2][d]
-  bf16_t* m;                                               // [2][F]
+  // granule buffers {tag << 32 | two bf16}: [2][len / 2] each, written once and then swept inside a launch
+  unsigned long long *g_y1, *g_x1, *g_x2;                  // len = d
+  unsigned long long* g_m;                                 // len = F
   bf16_t* q_out; bf16_t* kv; const float* rope; const int* lengths;   // op 4 epilogue (next block's cache)
   int max_len, hd, n_heads, n_heads_kv, rope_positions;
-  unsigned* ctr;                                           // [ZN_CH_HANDOFFS][ZN_CH_CTR_WORDS], zero at launch
+  unsigned* epoch;                                         // this launch's tag (> 0); workgroup 0 leaves epoch + 1 for the next launch
   int* tmo;                                                // sticky timeout word (GenState.pad[0])
   unsigned long long* stamps;                              // optional [32] (diagnostic builds of the timeline: workgroup 0's communication wave)
 };
@@ -60,21 +61,27 @@ ZN_DEVINL unsigned ld_sc1_u32(const void* p) { return __hip_atomic_load((const u
 ZN_DEVINL unsigned dpp_movu(unsigned v, int) { return v; }
 template <int CTRL> ZN_DEVINL unsigned dpp_u(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, true); }
 
-// The communication wave waits until `expect` workgroups have arrived at the hand-off (lanes 0..7 read one shard each,
-// lane 8 the sticky timeout word): relaxed sc1 polls, one load in flight, bounded.
-ZN_DEVINL bool chain_wait(const unsigned* ctr, unsigned expect, int* tmo, int lane) {
+ZN_DEVINL void st_granule(unsigned long long* g, unsigned tag, unsigned value) {      // ONE aligned 8-byte write-through store
+  __hip_atomic_store(g, ((unsigned long long)tag << 32) | value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// One wave sweeps the 4 * N granules it needs (two per 16-byte sc1 load: .x/.z values, .y/.w tags; byte offsets off[]) until every
+// tag equals `tag`, re-reading all of them every pass; bounded.  data[i] = the eight bf16 of off[i].
+template <int N>
+ZN_DEVINL bool sweep_granules(__amdgpu_buffer_rsrc_t rs, const int (&off)[N], unsigned tag, u32x4 (&data)[N], int* tmo, int lane) {
   const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
   for (;;) {
-    unsigned v = 0;
-    if (lane < ZN_CH_NSHARD) v = ld_sc1_u32(ctr + lane * ZN_CH_SSTRIDE);
-    else if (lane == ZN_CH_NSHARD) v = ld_sc1_u32(tmo);
-    unsigned s = lane < ZN_CH_NSHARD ? v : 0u;
-    s += dpp_u<ZN_DPP_XOR1>(s); s += dpp_u<ZN_DPP_XOR2>(s); s += dpp_u<ZN_DPP_HALF_MIRROR>(s);     // lanes 0..7
-    const unsigned total = (unsigned)__builtin_amdgcn_readlane((int)s, 0);
-    const unsigned dead = (unsigned)__builtin_amdgcn_readlane((int)v, ZN_CH_NSHARD);
-    if (total >= expect) return true;
-    if (dead) return false;
-    if (__builtin_amdgcn_s_memrealtime() - t0 > ZN_CH_TIMEOUT_TICKS) { if (lane == 0) atomicAdd(tmo, 1); return false; }
+    bool ok = true;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      const u32x4 l0 = ld_sc1_16(rs, off[i]), l1 = ld_sc1_16(rs, off[i] + 16);
+      ok &= (l0.y == tag) & (l0.w == tag) & (l1.y == tag) & (l1.w == tag);
+      data[i] = u32x4{l0.x, l0.z, l1.x, l1.z};
+    }
+    if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) return true;
+    if (__builtin_amdgcn_s_memrealtime() - t0 > ZN_CH_TIMEOUT_TICKS || __hip_atomic_load(tmo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+      if (lane == 0) atomicAdd(tmo, 1);
+      return false;
+    }
   }
 }
 
@@ -114,13 +121,15 @@ __global__ __launch_bounds__(ZN_CH_THREADS) void chain_kernel(ChainArgs a) {
   constexpr int R = 2, D = NCH * 512, CW = ZN_CH_CWAVES;
   constexpr int S1 = T_OUT, S2 = 2 * T_OUT, S3 = S2 + T_FC1, S4 = S3 + T_FC2, NS = S4 + T_IN;     // slot ranges per op
   constexpr int NOPS = T_IN > 0 ? 5 : 4;
+  constexpr bool DEFER = ZN_CH_DEFER != 0;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int c = blockIdx.x, G = gridDim.x;
   const int F = a.F;
+  const unsigned tag = *a.epoch;
   // units (weight-row pairs) per workgroup and op
   const int ppw_out = (D / 2) / G, ppw_fc1 = F / G, ppw_fc2 = (D / 2) / G, ppw_in = T_IN > 0 ? (a.nqkv / 2) / G : 0;
-  __shared__ __attribute__((aligned(16))) bf16_t s_act[R * 4 * D];          // the current op's input vector (rows of up to 4 d)
-  __shared__ float s_res[64][2][R];                                         // per-unit results (fc2: [unit * 4 + quarter])
+  __shared__ __attribute__((aligned(16))) bf16_t s_act[R * D];              // the current op's input vector (ops 0, 1, 2, 4)
+  __shared__ float s_res[2][64][2][R];                                      // per-unit results of even / odd ops (fc2: [unit * 4 + quarter])
 
   auto op_of = [](int s) constexpr { return s < S1 ? 0 : s < S2 ? 1 : s < S3 ? 2 : s < S4 ? 3 : 4; };
   auto first_of = [](int op) constexpr { return op == 0 ? 0 : op == 1 ? S1 : op == 2 ? S2 : op == 3 ? S3 : S4; };
@@ -159,6 +168,7 @@ __global__ __launch_bounds__(ZN_CH_THREADS) void chain_kernel(ChainArgs a) {
         for (int c2 = 0; c2 < NCH; ++c2) { w.a[c2] = ld_nt16(pa + c2 * 512); w.b[c2] = ld_nt16(pb + c2 * 512); }
       }
     };
+    auto load_slot = [&](int s) { if (s % 3 == 0) load(s, buf0); else if (s % 3 == 1) load(s, buf1); else load(s, buf2); };
     u32x4 xr[NCH][R];
     auto process = [&](int s, const WT& w) {
       bool ok; const bf16_t *pa, *pb; int ridx;
@@ -173,10 +183,12 @@ __global__ __launch_bounds__(ZN_CH_THREADS) void chain_kernel(ChainArgs a) {
 #pragma unroll
       for (int r = 0; r < R; ++r) { accA[r] = wave_sum(accA[r]); accB[r] = wave_sum(accB[r]); }
       if (lane == 0) {
+        const int par = op_of(s) & 1;
 #pragma unroll
-        for (int r = 0; r < R; ++r) { s_res[ridx][0][r] = accA[r]; s_res[ridx][1][r] = accB[r]; }
+        for (int r = 0; r < R; ++r) { s_res[par][ridx][0][r] = accA[r]; s_res[par][ridx][1][r] = accB[r]; }
       }
     };
+    __syncthreads();                                      // S: the communication wave's own requests are in the CU's queue first
     load(0, buf0);
     if constexpr (NS > 1) load(1, buf1);
     if constexpr (NS > 2) load(2, buf2);
@@ -184,17 +196,40 @@ __global__ __launch_bounds__(ZN_CH_THREADS) void chain_kernel(ChainArgs a) {
       constexpr int s = decltype(SC)::value;
       constexpr int op = op_of(s);
       if constexpr (s == first_of(op)) {
-        if constexpr (op > 0) __syncthreads();            // A(op-1): this workgroup's results of the previous op are in LDS
-        __syncthreads();                                  // B(op): the op's input vector is in LDS
-        const int kofs = (op == 3) ? (wave & 3) * D : 0, rstride = (op == 3) ? 4 * D : D;
+        if constexpr (op > 0) {
+          __syncthreads();                                // A(op-1): this workgroup's results of the previous op are in LDS
+          if constexpr (DEFER) {
+            __syncthreads();                              // P(op-1): ... and published; the requests held back for that go out now
+            zn_static_for<first_of(op - 1), first_of(op)>([&](auto QC) {
+              constexpr int q = decltype(QC)::value;
+              if constexpr (q + 3 < NS && op_of(q + 3 < NS ? q + 3 : 0) != op - 1) load_slot(q + 3);
+            });
+          }
+        }
+        if constexpr (op == 3) {
+          // fc2's input m [2][4 d]: this wave's K quarter straight from the granules (no LDS, no barrier)
+          const int qt = wave & 3;
+          int off[NCH * R];
+          u32x4 dat[NCH * R];
 #pragma unroll
-        for (int c2 = 0; c2 < NCH; ++c2)
+          for (int c2 = 0; c2 < NCH; ++c2)
 #pragma unroll
-          for (int r = 0; r < R; ++r) xr[c2][r] = *(const u32x4*)&s_act[r * rstride + kofs + (c2 * 64 + lane) * 8];
+            for (int r = 0; r < R; ++r) off[c2 * R + r] = (r * (2 * D) + qt * (D / 2) + (c2 * 64 + lane) * 4) * 8;
+          sweep_granules<NCH * R>(zn_rsrc(a.g_m), off, tag, dat, a.tmo, lane);
+#pragma unroll
+          for (int c2 = 0; c2 < NCH; ++c2)
+#pragma unroll
+            for (int r = 0; r < R; ++r) xr[c2][r] = dat[c2 * R + r];
+        } else {
+          __syncthreads();                                // B(op): the op's input vector is in LDS
+#pragma unroll
+          for (int c2 = 0; c2 < NCH; ++c2)
+#pragma unroll
+            for (int r = 0; r < R; ++r) xr[c2][r] = *(const u32x4*)&s_act[r * D + (c2 * 64 + lane) * 8];
+        }
       }
-      if constexpr (s % 3 == 0) { process(s, buf0); if constexpr (s + 3 < NS) load(s + 3, buf0); }
-      else if constexpr (s % 3 == 1) { process(s, buf1); if constexpr (s + 3 < NS) load(s + 3, buf1); }
-      else { process(s, buf2); if constexpr (s + 3 < NS) load(s + 3, buf2); }
+      if constexpr (s % 3 == 0) process(s, buf0); else if constexpr (s % 3 == 1) process(s, buf1); else process(s, buf2);
+      if constexpr (s + 3 < NS && (!DEFER || op_of(s + 3 < NS ? s + 3 : 0) == op)) load_slot(s + 3);
     });
     __syncthreads();                                      // A(last op)
     return;
@@ -202,12 +237,12 @@ __global__ __launch_bounds__(ZN_CH_THREADS) void chain_kernel(ChainArgs a) {
 
   // -------------------------------------------------------------------------------------- communication wave
   // operands that do not depend on this launch's hand-offs are requested up front
-  u32x4 g[NCH][R];                                         // gathered vector in gemv_kernel's lane layout
+  u32x4 g[NCH * R];                                        // gathered vector in gemv_kernel's lane layout: [c2 * R + r]
   u32x4 l2w[NCH], l2b[NCH], lnw[NCH], lnbb[NCH];
 #pragma unroll
   for (int c2 = 0; c2 < NCH; ++c2)
 #pragma unroll
-    for (int r = 0; r < R; ++r) g[c2][r] = ld16(a.a + (size_t)r * D + (c2 * 64 + lane) * 8);
+    for (int r = 0; r < R; ++r) g[c2 * R + r] = ld16(a.a + (size_t)r * D + (c2 * 64 + lane) * 8);
 #pragma unroll
   for (int c2 = 0; c2 < NCH; ++c2) { l2w[c2] = ld16(a.ln2_w + (c2 * 64 + lane) * 8); l2b[c2] = ld16(a.ln2_b + (c2 * 64 + lane) * 8); }
   if constexpr (T_IN > 0) {
@@ -235,88 +270,86 @@ __global__ __launch_bounds__(ZN_CH_THREADS) void chain_kernel(ChainArgs a) {
       }
     }
   }
+  __syncthreads();                                         // S
 #pragma unroll
   for (int c2 = 0; c2 < NCH; ++c2)
 #pragma unroll
-    for (int r = 0; r < R; ++r) *(u32x4*)&s_act[r * D + (c2 * 64 + lane) * 8] = g[c2][r];
+    for (int r = 0; r < R; ++r) *(u32x4*)&s_act[r * D + (c2 * 64 + lane) * 8] = g[c2 * R + r];
   __syncthreads();                                         // B(0)
   int nst = 0;
   auto stamp = [&]() { if (a.stamps && c == 0 && lane == 0) a.stamps[nst] = __builtin_amdgcn_s_memrealtime(); ++nst; };
   stamp();
 
-  const __amdgpu_buffer_rsrc_t rs_y1 = zn_rsrc(a.y1), rs_x1 = zn_rsrc(a.x1), rs_xo = zn_rsrc(a.xout), rs_m = zn_rsrc(a.m);
+  int goff[NCH * R];                                       // byte offsets of this lane's granules in a [2][d / 2] granule vector
+#pragma unroll
+  for (int c2 = 0; c2 < NCH; ++c2)
+#pragma unroll
+    for (int r = 0; r < R; ++r) goff[c2 * R + r] = (r * (D / 2) + (c2 * 64 + lane) * 4) * 8;
   unsigned x1own = 0;
   zn_static_for<0, NOPS>([&](auto OC) {
     constexpr int op = decltype(OC)::value;
+    constexpr int par = op & 1;
     __syncthreads();                                       // A(op): every compute wave's results are in LDS
     stamp();
-    // ---- epilogue of this workgroup's units, published write-through
+    // ---- epilogue of this workgroup's units, published as granules
     if constexpr (op == 0) {                               // EPI_STORE
-      if (it_out) st_sc1_u32(a.y1 + (size_t)ir * D + 2 * u_out, pack2(s_res[ij][0][ir], s_res[ij][1][ir]));
+      if (it_out) st_granule(a.g_y1 + (size_t)ir * (D / 2) + u_out, tag, pack2(s_res[par][ij][0][ir], s_res[par][ij][1][ir]));
     } else if constexpr (op == 1) {                        // EPI_RESID
       if (it_out) {
-        x1own = pack2(lo_f(resid) + bfround(s_res[ij][0][ir]), hi_f(resid) + bfround(s_res[ij][1][ir]));
-        st_sc1_u32(a.x1 + (size_t)ir * D + 2 * u_out, x1own);
+        x1own = pack2(lo_f(resid) + bfround(s_res[par][ij][0][ir]), hi_f(resid) + bfround(s_res[par][ij][1][ir]));
+        st_granule(a.g_x1 + (size_t)ir * (D / 2) + u_out, tag, x1own);
       }
-    } else if constexpr (op == 2) {                        // EPI_SILU: lane = r * ppw_fc1 + j, neighbours pack a dword
+    } else if constexpr (op == 2) {                        // EPI_SILU: lane = r * ppw_fc1 + j, neighbours share a granule
       const int r2 = lane / ppw_fc1, j2 = lane % ppw_fc1;
       const bool on = r2 < R;
       const int jj = on ? j2 : 0, rr = on ? r2 : 0;
-      const float y = bfround(s_res[jj][0][rr]), gt = bfround(s_res[jj][1][rr]);
+      const float y = bfround(s_res[par][jj][0][rr]), gt = bfround(s_res[par][jj][1][rr]);
       const float sg = bfround(gt / (1.0f + expf(-gt)));
       const unsigned mine = (unsigned)f2bf(y * sg);
       const unsigned nb = (unsigned)__shfl_down((int)mine, 1);
-      if (on && (j2 & 1) == 0) st_sc1_u32(a.m + (size_t)r2 * F + c * ppw_fc1 + j2, mine | (nb << 16));
+      if (on && (j2 & 1) == 0) st_granule(a.g_m + (size_t)r2 * (F / 2) + ((c * ppw_fc1 + j2) >> 1), tag, mine | (nb << 16));
     } else if constexpr (op == 3) {                        // EPI_RESID over the four K quarters, in gemv_kernel's order
       if (it_out) {
-        const float vA = ((s_res[ij * 4 + 0][0][ir] + s_res[ij * 4 + 1][0][ir]) + s_res[ij * 4 + 2][0][ir]) + s_res[ij * 4 + 3][0][ir];
-        const float vB = ((s_res[ij * 4 + 0][1][ir] + s_res[ij * 4 + 1][1][ir]) + s_res[ij * 4 + 2][1][ir]) + s_res[ij * 4 + 3][1][ir];
+        const float vA = ((s_res[par][ij * 4 + 0][0][ir] + s_res[par][ij * 4 + 1][0][ir]) + s_res[par][ij * 4 + 2][0][ir]) + s_res[par][ij * 4 + 3][0][ir];
+        const float vB = ((s_res[par][ij * 4 + 0][1][ir] + s_res[par][ij * 4 + 1][1][ir]) + s_res[par][ij * 4 + 2][1][ir]) + s_res[par][ij * 4 + 3][1][ir];
         const unsigned o = pack2(lo_f(x1own) + bfround(vA), hi_f(x1own) + bfround(vB));
-        if constexpr (NOPS == 5) st_sc1_u32(a.xout + (size_t)ir * D + 2 * u_out, o);
-        else *(unsigned*)(a.xout + (size_t)ir * D + 2 * u_out) = o;         // last op of the launch: the next kernel reads it
+        if constexpr (NOPS == 5) st_granule(a.g_x2 + (size_t)ir * (D / 2) + u_out, tag, o);
+        *(unsigned*)(a.xout + (size_t)ir * D + 2 * u_out) = o;              // the plain copy later launches read
       }
     } else {                                               // EPI_ROPE_KV of the next block (read by the next launch)
       if (it_in) {
         GemvArgs ga{};
         ga.hd = a.hd; ga.n_heads = a.n_heads; ga.n_heads_kv = a.n_heads_kv; ga.q_out = a.q_out; ga.kv = a.kv; ga.max_len = a.max_len;
-        gemv_epilogue<EPI_ROPE_KV>(ga, ir, 2 * u_in, 2 * u_in + 1, true, u_in, s_res[ij][0][ir], s_res[ij][1][ir], 0u, cs, sn, pos);
+        gemv_epilogue<EPI_ROPE_KV>(ga, ir, 2 * u_in, 2 * u_in + 1, true, u_in, s_res[par][ij][0][ir], s_res[par][ij][1][ir], 0u, cs, sn, pos);
       }
     }
     if constexpr (op + 1 < NOPS) {
-      // ---- arrive (stores drained first), wait for every workgroup, gather the op's output vector
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      unsigned* ctr = a.ctr + op * ZN_CH_CTR_WORDS;
-      if (lane == 0) __hip_atomic_fetch_add(ctr + (c % ZN_CH_NSHARD) * ZN_CH_SSTRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if constexpr (DEFER) __syncthreads();                // P(op): published; the compute waves may queue weight requests again
       stamp();
-      chain_wait(ctr, (unsigned)G, a.tmo, lane);
-      stamp();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");      // no instruction: keeps the gather below the poll
-      if constexpr (op == 2) {
-        // m [R][4 d]: 8 x NCH wave-wide 16-B loads, staged through registers in groups of 8
+      if constexpr (op != 2) {                             // (fc2's input is swept by the compute waves)
+        sweep_granules<NCH * R>(zn_rsrc(op == 0 ? a.g_y1 : op == 1 ? a.g_x1 : a.g_x2), goff, tag, g, a.tmo, lane);
+        stamp();
+        if constexpr (op == 1 || op == 3) {
+          u32x4 gl[NCH][R];
 #pragma unroll
-        for (int grp = 0; grp < NCH; ++grp) {
-          u32x4 t8[8];
+          for (int c2 = 0; c2 < NCH; ++c2)
 #pragma unroll
-          for (int i = 0; i < 8; ++i) t8[i] = ld_sc1_16(rs_m, ((grp * 8 + i) * 64 + lane) * 16);
+            for (int r = 0; r < R; ++r) gl[c2][r] = g[c2 * R + r];
+          chain_layernorm<NCH>(gl, op == 1 ? l2w : lnw, op == 1 ? l2b : lnbb, a.eps);
 #pragma unroll
-          for (int i = 0; i < 8; ++i) *(u32x4*)&s_act[((grp * 8 + i) * 64 + lane) * 8] = t8[i];
+          for (int c2 = 0; c2 < NCH; ++c2)
+#pragma unroll
+            for (int r = 0; r < R; ++r) g[c2 * R + r] = gl[c2][r];
         }
-      } else {
-        const __amdgpu_buffer_rsrc_t rs = (op == 0) ? rs_y1 : (op == 1) ? rs_x1 : rs_xo;
 #pragma unroll
         for (int c2 = 0; c2 < NCH; ++c2)
 #pragma unroll
-          for (int r = 0; r < R; ++r) g[c2][r] = ld_sc1_16(rs, (r * D + (c2 * 64 + lane) * 8) * 2);
-        if constexpr (op == 1) chain_layernorm<NCH>(g, l2w, l2b, a.eps);
-        if constexpr (op == 3) chain_layernorm<NCH>(g, lnw, lnbb, a.eps);
-#pragma unroll
-        for (int c2 = 0; c2 < NCH; ++c2)
-#pragma unroll
-          for (int r = 0; r < R; ++r) *(u32x4*)&s_act[r * D + (c2 * 64 + lane) * 8] = g[c2][r];
-      }
-      __syncthreads();                                     // B(op + 1)
+          for (int r = 0; r < R; ++r) *(u32x4*)&s_act[r * D + (c2 * 64 + lane) * 8] = g[c2 * R + r];
+        __syncthreads();                                   // B(op + 1)
+      } else stamp();
       stamp();
     }
   });
   stamp();
+  if (c == 0 && lane == 0) *a.epoch = tag + 1;             // every workgroup read the epoch before its first publish, which this one has seen
 }
