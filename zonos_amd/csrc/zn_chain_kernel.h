@@ -9,7 +9,7 @@
 // As five launches these cost ~3.3 us of fixed time each (boundary + ramp until the first weights arrive) on top of
 // their streaming time; here one workgroup per CU stays resident for the whole chain: its 4 compute waves walk a STATIC
 // list of weight tiles (a tile = two weight rows x 512*NCH columns = one gemv_kernel work unit, same arithmetic order,
-// so the results are bit-identical to the launches path) with three tiles requested ahead in registers — requests run
+// so the results are bit-identical to the launches path) with up to ZN_CH_NBUF tiles requested ahead in registers — requests run
 // across the op boundaries, so the HBM stream no longer drains at every dependency —, and a fifth, communication wave
 // (it issues no weight loads, so its own waits cover only the hand-off traffic) finishes each op: epilogue of the
 // workgroup's rows, published as 8-byte {tag, two bf16} granules (one write-through store each: the data is the flag, no
@@ -22,11 +22,15 @@
 #include <utility>
 #include "zn_decode_kernels.h"
 
-#ifndef ZN_CH_DEFER
-#define ZN_CH_DEFER 1                                      // 1: a weight request for a LATER op waits until this op's results are published
+#ifndef ZN_CH_DEFER_MASK
+#define ZN_CH_DEFER_MASK 0xF                               // bit k: weight requests for LATER ops raised during op k wait until op k's results are published
+// (measured, decode step at 400 tokens: 0x0 1.103 ms, 0x3 1.071, 0xB 1.048, 0xF 1.027: a request queued in front of a publish or a
+// sweep delays the hand-off by its whole service time, and the stream it feeds is not the bottleneck at that moment)
 #endif
 #define ZN_CH_CWAVES 4                                     // compute waves (a multiple of 4); the next wave = communication wave
+#ifndef ZN_CH_NBUF
 #define ZN_CH_NBUF 3                                       // weight tiles requested ahead per compute wave (register buffers)
+#endif
 #define ZN_CH_THREADS ((ZN_CH_CWAVES + 1) * 64)
 #define ZN_CH_TIMEOUT_TICKS 2000000ull                     // 20 ms of s_memrealtime (100 MHz)
 
@@ -67,9 +71,10 @@ ZN_DEVINL void st_granule(unsigned long long* g, unsigned tag, unsigned value) {
 // One wave sweeps the 4 * N granules it needs (two per 16-byte sc1 load: .x/.z values, .y/.w tags; byte offsets off[]) until every
 // tag equals `tag`, re-reading all of them every pass; bounded.  data[i] = the eight bf16 of off[i].
 template <int N>
-ZN_DEVINL bool sweep_granules(__amdgpu_buffer_rsrc_t rs, const int (&off)[N], unsigned tag, u32x4 (&data)[N], int* tmo, int lane) {
+ZN_DEVINL bool sweep_granules(__amdgpu_buffer_rsrc_t rs, const int (&off)[N], unsigned tag, u32x4 (&data)[N], int* tmo, int lane, int* passes = nullptr) {
   const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
   for (;;) {
+    if (passes) ++*passes;
     bool ok = true;
 #pragma unroll
     for (int i = 0; i < N; ++i) {
@@ -121,7 +126,11 @@ __global__ __launch_bounds__(ZN_CH_THREADS) void chain_kernel(ChainArgs a) {
   constexpr int R = 2, D = NCH * 512, CW = ZN_CH_CWAVES;
   constexpr int S1 = T_OUT, S2 = 2 * T_OUT, S3 = S2 + T_FC1, S4 = S3 + T_FC2, NS = S4 + T_IN;     // slot ranges per op
   constexpr int NOPS = T_IN > 0 ? 5 : 4;
-  constexpr bool DEFER = ZN_CH_DEFER != 0;
+  constexpr int MASK = ZN_CH_DEFER_MASK;
+  // The second out_proj (op 1) reuses the first one's weight tiles in place: its slots raise no request.  Requests are numbered
+  // l = 0 .. NL-1 in slot order without them (buffer l % 3); a buffer takes request l + 3 after its last use.
+  constexpr int NB = ZN_CH_NBUF;
+  constexpr int NL = NS - T_OUT, INIT = T_OUT + 1 < NB ? T_OUT + 1 : NB;    // requests raised at kernel start: op 0's tiles + one more
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int c = blockIdx.x, G = gridDim.x;
   const int F = a.F;
@@ -137,8 +146,8 @@ __global__ __launch_bounds__(ZN_CH_THREADS) void chain_kernel(ChainArgs a) {
   if (wave < CW) {
     // ------------------------------------------------------------------------------------ compute waves
     struct WT { u32x4 a[NCH], b[NCH]; };
-    WT buf0, buf1, buf2;
-    static_assert(ZN_CH_NBUF == 3 && CW % 4 == 0, "three rotating tile buffers; fc2 splits K over groups of four waves");
+    WT bufs[NB];                                           // every index below is a compile-time constant: the buffers live in registers
+    static_assert(NB >= 2 && CW % 4 == 0, "rotating tile buffers; fc2 splits K over groups of four waves");
     // tile of slot s for this wave: exists?, weight pointer of rows A and B (lane's first chunk), result index
     auto tile = [&](int s, bool& ok, const bf16_t*& pa, const bf16_t*& pb, int& ridx) {
       const int op = op_of(s), t = s - first_of(op);
@@ -168,7 +177,8 @@ __global__ __launch_bounds__(ZN_CH_THREADS) void chain_kernel(ChainArgs a) {
         for (int c2 = 0; c2 < NCH; ++c2) { w.a[c2] = ld_nt16(pa + c2 * 512); w.b[c2] = ld_nt16(pb + c2 * 512); }
       }
     };
-    auto load_slot = [&](int s) { if (s % 3 == 0) load(s, buf0); else if (s % 3 == 1) load(s, buf1); else load(s, buf2); };
+    auto slot_of_load = [](int l) constexpr { return l < S1 ? l : l + T_OUT; };
+    auto load_req = [&](auto LC) { constexpr int l = decltype(LC)::value; load(slot_of_load(l), bufs[l % NB]); };
     u32x4 xr[NCH][R];
     auto process = [&](int s, const WT& w) {
       bool ok; const bf16_t *pa, *pb; int ridx;
@@ -188,21 +198,33 @@ __global__ __launch_bounds__(ZN_CH_THREADS) void chain_kernel(ChainArgs a) {
         for (int r = 0; r < R; ++r) { s_res[par][ridx][0][r] = accA[r]; s_res[par][ridx][1][r] = accB[r]; }
       }
     };
+    // request raised by the last use of slot s's buffer (-1: none), and whether it waits for the op's publish
+    auto raised_by = [](int s) constexpr {
+      const int op = s < S1 ? 0 : s < S2 ? 1 : s < S3 ? 2 : s < S4 ? 3 : 4;
+      if (op == 0) return -1;                              // the tile stays for op 1
+      const int l = (s - T_OUT) + NB;                      // op 1 slot s shares the buffer of request s - T_OUT; later slots hold request s - T_OUT
+      return l < NL ? l : -1;
+    };
+#ifdef ZN_CH_EARLY_O
+    zn_static_for<0, T_OUT>([&](auto LC) { load_req(LC); });      // op 0's own tiles are on the critical path: requested at once
+    __syncthreads();                                      // S: the communication wave's own requests are in the CU's queue before the prefetch
+    zn_static_for<T_OUT, INIT>([&](auto LC) { load_req(LC); });
+#else
     __syncthreads();                                      // S: the communication wave's own requests are in the CU's queue first
-    load(0, buf0);
-    if constexpr (NS > 1) load(1, buf1);
-    if constexpr (NS > 2) load(2, buf2);
+    zn_static_for<0, INIT>([&](auto LC) { load_req(LC); });
+#endif
     zn_static_for<0, NS>([&](auto SC) {
       constexpr int s = decltype(SC)::value;
       constexpr int op = op_of(s);
       if constexpr (s == first_of(op)) {
         if constexpr (op > 0) {
           __syncthreads();                                // A(op-1): this workgroup's results of the previous op are in LDS
-          if constexpr (DEFER) {
-            __syncthreads();                              // P(op-1): ... and published; the requests held back for that go out now
+          __syncthreads();                                // P(op-1): ... and published; the requests held back for that go out now
+          if constexpr (op == 1) zn_static_for<INIT, (NL < NB ? NL : NB)>([&](auto LC) { load_req(LC); });
+          if constexpr (((MASK >> (op - 1)) & 1) != 0) {
             zn_static_for<first_of(op - 1), first_of(op)>([&](auto QC) {
-              constexpr int q = decltype(QC)::value;
-              if constexpr (q + 3 < NS && op_of(q + 3 < NS ? q + 3 : 0) != op - 1) load_slot(q + 3);
+              constexpr int q = decltype(QC)::value, l = raised_by(q);
+              if constexpr (l >= 0) { if constexpr (op_of(slot_of_load(l >= 0 ? l : 0)) != op - 1) load_req(std::integral_constant<int, (l >= 0 ? l : 0)>{}); }
             });
           }
         }
@@ -228,8 +250,12 @@ __global__ __launch_bounds__(ZN_CH_THREADS) void chain_kernel(ChainArgs a) {
             for (int r = 0; r < R; ++r) xr[c2][r] = *(const u32x4*)&s_act[r * D + (c2 * 64 + lane) * 8];
         }
       }
-      if constexpr (s % 3 == 0) process(s, buf0); else if constexpr (s % 3 == 1) process(s, buf1); else process(s, buf2);
-      if constexpr (s + 3 < NS && (!DEFER || op_of(s + 3 < NS ? s + 3 : 0) == op)) load_slot(s + 3);
+      constexpr int lb = (op == 0 ? s : s - T_OUT) % NB;   // buffer holding this slot's weights
+      process(s, bufs[lb]);
+      constexpr int l = raised_by(s);
+      if constexpr (l >= 0) {
+        if constexpr (((MASK >> op) & 1) == 0 || op_of(slot_of_load(l >= 0 ? l : 0)) == op) load_req(std::integral_constant<int, (l >= 0 ? l : 0)>{});
+      }
     });
     __syncthreads();                                      // A(last op)
     return;
@@ -324,10 +350,14 @@ __global__ __launch_bounds__(ZN_CH_THREADS) void chain_kernel(ChainArgs a) {
       }
     }
     if constexpr (op + 1 < NOPS) {
-      if constexpr (DEFER) __syncthreads();                // P(op): published; the compute waves may queue weight requests again
+      __syncthreads();                                     // P(op): published; the compute waves may queue weight requests again
       stamp();
       if constexpr (op != 2) {                             // (fc2's input is swept by the compute waves)
-        sweep_granules<NCH * R>(zn_rsrc(op == 0 ? a.g_y1 : op == 1 ? a.g_x1 : a.g_x2), goff, tag, g, a.tmo, lane);
+        // (requesting the first pass ahead of the compute waves' held-back requests was measured slower, 1.089 vs 1.023 ms per step: it
+        // comes back before the slowest publishers' stores are visible, and the second pass then queues behind those requests)
+        int passes = 0;
+        sweep_granules<NCH * R>(zn_rsrc(op == 0 ? a.g_y1 : op == 1 ? a.g_x1 : a.g_x2), goff, tag, g, a.tmo, lane, a.stamps ? &passes : nullptr);
+        if (a.stamps && c == 0 && lane == 0) a.stamps[24 + op] = (unsigned long long)passes;
         stamp();
         if constexpr (op == 1 || op == 3) {
           u32x4 gl[NCH][R];
