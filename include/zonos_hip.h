@@ -169,7 +169,8 @@ int zn_debug_tune(zn_handle h, int32_t key, int32_t value);
 /* Test/benchmark hook: add `bias` to the codebook-0 EOS logit on every step (-inf suppresses EOS so that all
  * max_new_tokens+7 steps run). */
 /* Diagnostic: workgroup 0 of every persistent chain launch records s_memrealtime (100 MHz) stamps of its phases into
- * stamps_dev [n_layer][32] (NULL = off).  Stamp order per launch: input ready; then per op: results ready, arrived,
+ * stamps_dev [2 * n_layer][32] (NULL = off); rows n_layer.. hold the fused attention launch's (start, length known, scores
+ * issued, scores done, P.V done, reduced, stored).  Stamp order per launch: input ready; then per op: results ready, arrived,
  * all arrived, next input ready; last: end. */
 int zn_debug_chain_stamps(zn_handle h, uint64_t* stamps_dev);
 /* Diagnostic: every decode step copies, per block, the residual stream after the block, the block's attention output, its

@@ -30,7 +30,7 @@ for name, v in (("launches", 2), ("chain", 1), ("launches", 2), ("chain", 1)):
 print("codes identical:", torch.equal(outs["launches"], outs["chain"]))
 
 # timeline of workgroup 0's communication wave, one mid-stack layer of the last decode step
-stamps = torch.zeros(26, 32, dtype=torch.int64, device="cuda:0")
+stamps = torch.zeros(52, 32, dtype=torch.int64, device="cuda:0")
 eng.call("zn_debug_tune", 8, 1)
 eng.call("zn_debug_chain_stamps", stamps.data_ptr())
 model.generate(cond, max_new_tokens=64, sampling_params={"temperature": 0.0})

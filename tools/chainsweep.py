@@ -24,7 +24,7 @@ for _ in range(2):
     out = model.generate(cond, max_new_tokens=n, sampling_params={"temperature": 0.0})
     torch.cuda.synchronize()
     best = min(best, time.perf_counter() - t0)
-stamps = torch.zeros(26, 32, dtype=torch.int64, device="cuda:0")
+stamps = torch.zeros(52, 32, dtype=torch.int64, device="cuda:0")
 eng.call("zn_debug_chain_stamps", stamps.data_ptr())
 model.generate(cond, max_new_tokens=64, sampling_params={"temperature": 0.0})
 torch.cuda.synchronize()
@@ -34,4 +34,5 @@ names = ["in"] + [f"{op}{k}" for op in ("o1", "o2", "f1", "f2") for k in (" res"
 li = 12
 tl = " ".join(f"{nm}={(st[li][i] - st[li][0]) / 100.0:.2f}" for i, nm in enumerate(names))
 print(f"{os.environ.get('ZONOS_HIP_LIB', 'default').split('/')[-1]} tune5={os.environ.get('ZN_TUNE5')}: {best * 1e3 / (n + 8):.4f} ms/step, checksum {int(out.sum())}; chain {((st[li][len(names) - 1] - st[li][0]) / 100.0):.2f} us, "
+      f"attention(13) start +{(st[26 + 13][0] - st[12][len(names) - 1]) / 100.0:.2f} after chain(12) end: " + " ".join(f"{nm}={(st[26 + 13][i] - st[26 + 13][0]) / 100.0:.2f}" for i, nm in enumerate(["start", "len", "sc issued", "sc done", "pv", "reduced", "pre-store", "stored"])) + f"; chain(13) in +{(st[13][0] - st[26 + 13][7]) / 100.0:.2f} after | "
       f"gap {(st[13][0] - st[12][len(names) - 1]) / 100.0:.2f} us | sweep passes y1/x1/x2 {st[li][24]}/{st[li][25]}/{st[li][27]} | {tl}", flush=True)

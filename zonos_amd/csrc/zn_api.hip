@@ -40,6 +40,7 @@ struct zn_handle_s {
   unsigned* ch_epoch = nullptr;
   bf16_t* ch_x2 = nullptr;
   bf16_t* dbg_trace = nullptr;               // diagnostic: [n_layer][2][rows * d] copies of (x after the block, attention output) per decode step
+  unsigned long long* at_stamps = nullptr;   // diagnostic: [n_layer][8] timeline of the fused attention launch (second half of the chain stamp buffer)
   unsigned long long* ch_stamps = nullptr;   // diagnostic: [n_layer][32] timeline stamps of workgroup 0 (zn_debug_chain_stamps)
   int ch_variant = 0;          // 0 = shapes do not fit (launches path), 1 = <4,1,8,4,2> (Zonos-v0.1 dims), 2 = <1,1,2,1,1> (d_model 512)
   float* g16_part = nullptr;   // gemm16s_kernel: split-K partial tiles
@@ -457,13 +458,13 @@ static int ensure_attn_ws(zn_handle h, int max_len) {
 }
 
 static int run_attention(zn_handle h, const bf16_t* q, const bf16_t* kv, int max_len, const int* lengths, const int* ext, int ext_scalar,
-                         bf16_t* out, int rows, hipStream_t s) {
+                         bf16_t* out, int rows, hipStream_t s, unsigned long long* stamps = nullptr) {
   const zn_config& c = h->cfg;
   if (max_len > h->lcap || rows > h->max_rows) ZN_FAIL(h, ZN_ERR_STATE, "attention workspace too small (max_len %d rows %d)", max_len, rows);
   AttnArgs a{};
   a.q = q; a.kv = kv; a.lengths = lengths; a.ext = ext; a.ext_scalar = ext_scalar; a.max_len = max_len;
   a.n_heads = c.n_heads; a.n_heads_kv = c.n_heads_kv; a.lcap = h->lcap; a.scale = (float)(1.0 / std::sqrt((double)h->hd));
-  a.scores = h->scores; a.cmax = h->cmax; a.out = out; a.rows = rows;
+  a.scores = h->scores; a.cmax = h->cmax; a.out = out; a.rows = rows; a.stamps = stamps;
   const int hd = h->hd;
   dim3 grid((max_len + ZN_ACHUNK - 1) / ZN_ACHUNK, c.n_heads_kv, rows);
   // one fused launch for short contexts (the caller bounds the context: h->attn_fused), two passes beyond
@@ -604,7 +605,8 @@ static int decode_blocks(zn_handle h, const int* ext, int ext_scalar, hipStream_
   if ((rc = layer_in_proj(h, 0, h->x, (bf16_t*)h->kv_layers[0], h->max_len, h->lengths, h->rows, s))) return rc;
   for (int li = 0; li < c.n_layer; ++li) {
     trace_q(li);
-    if ((rc = run_attention(h, h->q, (bf16_t*)h->kv_layers[li], h->max_len, h->lengths, ext, ext_scalar, h->o1, h->rows, s))) return rc;
+    if ((rc = run_attention(h, h->q, (bf16_t*)h->kv_layers[li], h->max_len, h->lengths, ext, ext_scalar, h->o1, h->rows, s,
+                            h->ch_stamps ? h->ch_stamps + (size_t)(c.n_layer + li) * 32 : nullptr))) return rc;
     if ((rc = launch_chain(h, li, h->kv_layers, h->max_len, h->lengths, s))) return rc;
     trace(li);
   }

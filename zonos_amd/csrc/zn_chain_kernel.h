@@ -40,9 +40,8 @@ struct ChainArgs {
   float eps;
   int F, nqkv;                                             // d_ff (= 4 d_model), rows of the next in_proj
   const bf16_t* a;                                         // [2][d] attention output
-  // No address is written twice inside a launch, nor read before it is written there: a line fetched earlier in the launch
-  // (even by an sc1 load) can survive in the XCD's L2 and be hit by a later gather although other XCDs have rewritten it
-  // (observed: a stale x element once per ~4000 launches with x updated in place).
+  // No handed-off address is written twice inside a launch, nor read before it is written there (the residual stream enters
+  // through one buffer and leaves through another): every sweep then either sees this launch's tag or an older launch's.
   const bf16_t* xin;                                       // [2][d] residual stream entering the block (read only)
   bf16_t* xout;                                            // [2][d] residual stream leaving the block (op 3); != xin
   // granule buffers {tag << 32 | two bf16}: [2][len / 2] each, written once and then swept inside a launch

@@ -851,6 +851,7 @@ struct AttnArgs {
   float* scores;        // [rows][Hq][lcap]
   float* cmax;          // [rows][Hq][lcap/64]   per-64-key-chunk maxima
   bf16_t* out;          // [rows][Hq*hd]
+  unsigned long long* stamps;   // optional [8] diagnostic timeline (s_memrealtime) of workgroup 0 of the fused launch
 };
 #define ZN_ACHUNK 64
 
@@ -937,6 +938,9 @@ __global__ __launch_bounds__(512) void attn_pv_kernel(AttnArgs a) {
   } else if constexpr (SPLIT) { slice = blockIdx.x; kvh = blockIdx.y; r = blockIdx.z / a.nbcap; }
   else { slice = blockIdx.x; kvh = blockIdx.y; r = blockIdx.z; }
   const int jb = SPLIT ? (int)(blockIdx.z % a.nbcap) : 0;       // SPLIT: the block this workgroup owns
+  int nst = 0;
+  auto stamp = [&]() { if (FUSED && a.stamps && blockIdx.x == 0 && threadIdx.x == 0) a.stamps[nst] = __builtin_amdgcn_s_memrealtime(); ++nst; };
+  stamp();
   // length (and span) first; the first block's requests below do not wait for them (clamped addresses, masked use)
   const int Lraw = a.lengths[r];
   const int Eraw = a.ext ? a.ext[r] : a.ext_scalar;
@@ -1015,6 +1019,7 @@ __global__ __launch_bounds__(512) void attn_pv_kernel(AttnArgs a) {
     issue_k(kkA, 0, a.max_len - 1);                                    // block 0, before the length is known
     __builtin_amdgcn_sched_barrier(0);
     L = Lraw + 1; nb = (L + 511) >> 9;
+    stamp();
     if (nb > 1) {                                                      // wave-uniform
       issue_k(kkB, 512, L - 1);
 #pragma unroll
@@ -1062,7 +1067,9 @@ __global__ __launch_bounds__(512) void attn_pv_kernel(AttnArgs a) {
         if (j + 3 < nb) issue_k(kkB, (j + 3) * 512, L - 1);
       }
     }
+    stamp();
     __syncthreads();
+    stamp();
   } else {
     __builtin_amdgcn_sched_barrier(0);
     L = Lraw + 1; nb = (L + 511) >> 9;
@@ -1194,6 +1201,7 @@ __global__ __launch_bounds__(512) void attn_pv_kernel(AttnArgs a) {
       }
     }
   }
+  stamp();
   // reduce: 4 key lanes per 16-lane row by DPP, then the rows of the workgroup through LDS in a fixed order
   __shared__ float s_acc[NW * 4][G][32];
   __shared__ float s_l[NW][G];
@@ -1232,7 +1240,9 @@ __global__ __launch_bounds__(512) void attn_pv_kernel(AttnArgs a) {
     for (int w = 0; w < NW; ++w) l += s_l[w][g];
   }
   if constexpr (!SPLIT) {
+    stamp();
     if (tid < G * 32) a.out[((size_t)r * a.n_heads + kvh * G + g) * HD + slice * 32 + d] = f2bf(__fmul_rn(v, 1.0f / l));
+    stamp();
   } else {
     constexpr int PSZ = G * 32 + G;
     const int group = (r * a.n_heads_kv + kvh) * (HD / 32) + slice;
