@@ -30,8 +30,8 @@ sys.path.insert(0, ROOT)
 
 FRAME_RATE = 44100 / 512          # 86.1328 DAC frames per second of audio
 HBM_PEAK = 8.0e12                 # B/s, MI355X spec (MI355X_MICROARCH.md)
-PMC_FILE = os.path.join(ROOT, "profiles", "pmc_fc1.json")
-KERNEL_SOURCES = ("zonos_amd/csrc/zn_decode_kernels.h", "zonos_amd/csrc/zn_common.h")
+PMC_FILE = os.path.join(ROOT, "profiles", "pmc_chain.json")
+KERNEL_SOURCES = ("zonos_amd/csrc/zn_chain_kernel.h", "zonos_amd/csrc/zn_decode_kernels.h", "zonos_amd/csrc/zn_common.h")
 
 
 def algorithmic_bytes_per_step(cfg, B, L):
@@ -229,15 +229,20 @@ def run_rank(args) -> int:
         result["ar_only"] = {"s_per_utterance": round(t_ar, 4), "ms_per_decode_step": round(1e3 * t_ar / (steps_per_utt + 1), 4),
                              "audio_sec_per_sec": round(B * max_new / FRAME_RATE / t_ar, 3)}
         result["hipgraph_step"] = bool(eng.lib.zn_graph_active(eng.h))
+        result["chain_kernel_path"] = bool(eng.lib.zn_decode_path(eng.h))     # the generation just run: persistent chain or launches
     if rank == 0 and not dry:
         from zonos_amd import _lib
-        # ---- roofline of the dominant kernel (LayerNorm + fc1 GEMV + SiLU gate: 67 MB of the 123 MB per layer), HIP events
-        # on the launch stream; the launches cycle over the 26 layers' weights so that each streams from HBM
+        # ---- roofline of the dominant kernel, HIP events on the launch stream; the launches cycle over the 26 layers' weights so
+        # that each streams from HBM.  Batch 1: the persistent chain launch (out_proj x2, LayerNorm+fc1+SiLU, fc2, next in_proj:
+        # ~70 % of the decode step's GPU time); larger batches: the LayerNorm + fc1 + SiLU-gate GEMM of the launches path.
         ms, by = C.c_float(0), C.c_double(0)
-        eng.call("zn_bench_kernel", 0, 2 * B, 260, C.byref(ms), C.byref(by), _lib.stream_ptr())
+        chain = B == 1 and bool(result.get("chain_kernel_path"))
+        eng.call("zn_bench_kernel", 5 if chain else 0, 2 * B, 260, C.byref(ms), C.byref(by), _lib.stream_ptr())
         ach = by.value / (ms.value * 1e-3)
-        traffic, traffic_note = pmc_traffic()
-        result["roofline"] = {"bound": "hbm", "kernel": "gemv_kernel<R=2,NCH=4,KSPLIT=1,PRO_LN,EPI_SILU> (LayerNorm+fc1+SiLU-gate)",
+        traffic, traffic_note = pmc_traffic() if chain else (None, "PMC summary covers the batch-1 chain launch only")
+        kname = ("chain_kernel<NCH=4,T_OUT=1,T_FC1=8,T_FC2=4,T_IN=2> (out_proj x2 + LayerNorm+fc1+SiLU-gate + fc2 + next block's LayerNorm+in_proj+RoPE+KV append, one persistent launch)"
+                 if chain else "gemm16s/gemv LayerNorm+fc1+SiLU-gate")
+        result["roofline"] = {"bound": "hbm", "kernel": kname,
                               "achieved": round(ach / 1e9, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": round(ach / HBM_PEAK, 4),
                               "traffic": traffic, "traffic_note": traffic_note, "bytes_per_launch": by.value, "us_per_launch": round(ms.value * 1e3, 3)}
         Lavg = l_c + 1 + steps_per_utt / 2
@@ -246,7 +251,7 @@ def run_rank(args) -> int:
         result["step_roofline"] = {"bound": "hbm", "algorithmic_bytes_per_decode_step": int(step_bytes), "achieved": round(step_bytes / step_s / 1e9, 1),
                                    "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": round(step_bytes / step_s / HBM_PEAK, 4)}
         others = {}
-        for which, name in ((1, "fc2+residual"), (2, "out_proj+residual"), (3, "LayerNorm+heads")):
+        for which, name in ((0, "LayerNorm+fc1+SiLU-gate (launches path)"), (1, "fc2+residual (launches path)"), (2, "out_proj+residual (launches path)"), (3, "LayerNorm+heads")):
             eng.call("zn_bench_kernel", which, 2 * B, 260, C.byref(ms), C.byref(by), _lib.stream_ptr())
             others[name] = {"us_per_launch": round(ms.value * 1e3, 3), "GB/s": round(by.value / (ms.value * 1e-3) / 1e9, 1)}
         result["other_kernels"] = others
@@ -316,13 +321,13 @@ def kernel_source_hash() -> str:
 
 def pmc_traffic():
     """HBM bytes per launch of the dominant kernel from the PMC passes (FETCH_SIZE x2 + WRITE_SIZE; separate rocprofv3
-    --pmc runs of tools/pmc_kernel.py, summarised by tools/pmc_summary.py into profiles/pmc_fc1.json).  The summary
+    --pmc runs of tools/pmc_kernel.py 5, summarised by tools/pmc_summary.py into profiles/pmc_chain.json).  The summary
     records the kernel's name and a hash of the kernel sources it was measured on: a summary of another kernel state is
     refused (traffic = null), never reported."""
     try:
         rec = json.load(open(PMC_FILE))
     except Exception:
-        return None, "no PMC summary (profiles/pmc_fc1.json)"
+        return None, "no PMC summary (profiles/pmc_chain.json)"
     if rec.get("kernel_source_sha256_16") != kernel_source_hash():
         return None, f"PMC summary is stale: measured on kernel sources {rec.get('kernel_source_sha256_16')}, current {kernel_source_hash()}"
     return rec["traffic_bytes_per_launch"], f"{rec.get('kernel_name')}; rocprofv3 --pmc passes of {rec.get('date', '?')}"

@@ -15,6 +15,9 @@ eng = model.engine(1)
 eng.call("zn_debug_eos_bias", float("-inf"))
 if os.environ.get("ZN_TUNE5"):
     eng.call("zn_debug_tune", 5, int(os.environ["ZN_TUNE5"]))
+for kv in os.environ.get("ZN_TUNE", "").split(","):          # e.g. ZN_TUNE=12:2,13:3
+    if kv:
+        eng.call("zn_debug_tune", int(kv.split(":")[0]), int(kv.split(":")[1]))
 cond = synth.conditioning(1234, "cond", 2, 24, 2048).to("cuda:0")
 model.generate(cond, max_new_tokens=32, sampling_params={"temperature": 0.0})
 best = 1e9
@@ -33,6 +36,6 @@ st = stamps.cpu().numpy()
 names = ["in"] + [f"{op}{k}" for op in ("o1", "o2", "f1", "f2") for k in (" res", " pub", " swept", " next")] + ["ip res", "end"]
 li = 12
 tl = " ".join(f"{nm}={(st[li][i] - st[li][0]) / 100.0:.2f}" for i, nm in enumerate(names))
-print(f"{os.environ.get('ZONOS_HIP_LIB', 'default').split('/')[-1]} tune5={os.environ.get('ZN_TUNE5')}: {best * 1e3 / (n + 8):.4f} ms/step, checksum {int(out.sum())}; chain {((st[li][len(names) - 1] - st[li][0]) / 100.0):.2f} us, "
-      f"attention(13) start +{(st[26 + 13][0] - st[12][len(names) - 1]) / 100.0:.2f} after chain(12) end: " + " ".join(f"{nm}={(st[26 + 13][i] - st[26 + 13][0]) / 100.0:.2f}" for i, nm in enumerate(["start", "len", "sc issued", "sc done", "pv", "reduced", "pre-store", "stored"])) + f"; chain(13) in +{(st[13][0] - st[26 + 13][7]) / 100.0:.2f} after | "
+print(f"{os.environ.get('ZONOS_HIP_LIB', 'default').split('/')[-1]} tune5={os.environ.get('ZN_TUNE5')} tune={os.environ.get('ZN_TUNE')}: {best * 1e3 / (n + 8):.4f} ms/step, checksum {int(out.sum())}; chain {((st[li][len(names) - 1] - st[li][0]) / 100.0):.2f} us, "
+      f"attention(13) start +{(st[26 + 13][0] - st[12][len(names) - 1]) / 100.0:.2f} after chain(12) end: " + " ".join(f"{nm}={(st[26 + 13][i] - st[26 + 13][0]) / 100.0:.2f}" for i, nm in enumerate(["start", "len", "sc own", "sc all", "pv", "dpp+lds", "lsum", "barrier", "summed", "store issued"])) + f"; chain(13) in +{(st[13][0] - st[26 + 13][9]) / 100.0:.2f} after | "
       f"gap {(st[13][0] - st[12][len(names) - 1]) / 100.0:.2f} us | sweep passes y1/x1/x2 {st[li][24]}/{st[li][25]}/{st[li][27]} | {tl}", flush=True)

@@ -1,4 +1,5 @@
-"""Run only the dominant decode kernel (LayerNorm+fc1+SiLU GEMV) 260 times, cycling over the 26 layers' weights.
+"""Run only one decode kernel (argument = zn_bench_kernel's `which`; 5 = the persistent chain launch, the dominant kernel at
+batch 1; 0 = the LayerNorm+fc1+SiLU GEMV of the launches path) 260 times, cycling over the 26 layers' weights.
 Meant to be wrapped by rocprofv3 (--kernel-trace --stats, or --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes)."""
 import ctypes as C
 import os

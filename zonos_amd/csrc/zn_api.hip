@@ -73,7 +73,7 @@ struct zn_handle_s {
   int *lengths = nullptr, *codes = nullptr;
   int force_eos_step = -1;
   float eos_bias = 0.f;
-  int tune[12] = {256, 512, 512, 1024, 512, 704, 2, 2, 0, 0, 0, 0};   // target workgroups: in_proj, out_proj, fc1, fc2, heads; [5] longest context of the fused attention launch; [6] > 1: multi-step graphs; [7] > 1: LDS-staged small-M projections; [8] = 2: no persistent chain kernel (five launches per block instead); [9]: KV capacity above which the P.V pass splits per block (0 = 1408); [10] = 2: VALU prefill attention; [11] = 2: no in-workgroup-split small-M kernel
+  int tune[16] = {256, 512, 512, 1024, 512, 704, 2, 2, 0, 0, 0, 0, 0, 0, 0, 0};   // target workgroups: in_proj, out_proj, fc1, fc2, heads; [5] longest context of the fused attention launch; [6] > 1: multi-step graphs; [7] > 1: LDS-staged small-M projections; [8] = 2: no persistent chain kernel (five launches per block instead); [9]: KV capacity above which the P.V pass splits per block (0 = 1408); [10] = 2: VALU prefill attention; [11] = 2: no in-workgroup-split small-M kernel
   const int* tok_override = nullptr;
   int tok_override_calls = 0;
   hipStream_t cap_stream = nullptr;
@@ -1161,7 +1161,7 @@ extern "C" int zn_debug_token_override(zn_handle h, const int32_t* tokens_dev, i
   return ZN_OK;
 }
 extern "C" int zn_debug_tune(zn_handle h, int32_t key, int32_t value) {
-  if (!h || key < 0 || key >= 12 || value < 1) return ZN_ERR_ARG;
+  if (!h || key < 0 || key >= 16 || value < 1) return ZN_ERR_ARG;
   h->tune[key] = value; free_graph(h);
   return ZN_OK;
 }
@@ -1184,7 +1184,7 @@ extern "C" int zn_debug_eos_bias(zn_handle h, float bias) { if (!h) return ZN_ER
 extern "C" int zn_bench_kernel(zn_handle h, int32_t which, int32_t rows, int32_t iters, float* ms_per_launch, double* bytes_per_launch,
                                zn_stream stream) {
   if (!h) return ZN_ERR_ARG;
-  if (!ms_per_launch || !bytes_per_launch || iters < 1 || (rows & 0xff) < 1 || (rows & 0xff) > h->max_rows || which < 0 || which > 4)
+  if (!ms_per_launch || !bytes_per_launch || iters < 1 || (rows & 0xff) < 1 || (rows & 0xff) > h->max_rows || which < 0 || which > 5)
     ZN_FAIL(h, ZN_ERR_ARG, "zn_bench_kernel: bad argument");
   const bool same_layer = (rows & 0x100) != 0;   // measurement variant: keep hitting layer 0 (weights stay in the Infinity Cache)
   rows &= 0xff;
@@ -1195,8 +1195,9 @@ extern "C" int zn_bench_kernel(zn_handle h, int32_t which, int32_t rows, int32_t
   HIPCHK(h, hipMemsetAsync(h->mbuf, 0, (size_t)rows * c.d_ff * 2, s));
   HIPCHK(h, hipMemsetAsync(h->o1, 0, (size_t)rows * d * 2, s));
   const int hd = h->hd, nq = c.n_heads * hd, nkv = c.n_heads_kv * hd;
-  bf16_t* tkv = nullptr; int* tlen = nullptr;             // which == 4: a scratch cache of 8 positions per row, all rows at position 0
-  if (which == 4) {
+  bf16_t* tkv = nullptr; int* tlen = nullptr;             // which == 4, 5: a scratch cache of 8 positions per row, all rows at position 0
+  if (which == 5 && !chain_active(h, rows)) ZN_FAIL(h, ZN_ERR_UNSUPPORTED, "zn_bench_kernel: the persistent chain serves batch 1 (2 rows) of the transformer only");
+  if (which == 4 || which == 5) {
     HIPCHK(h, hipMalloc(&tkv, (size_t)rows * 8 * 2 * nkv * 2));
     HIPCHK(h, hipMalloc(&tlen, (size_t)rows * sizeof(int)));
     HIPCHK(h, hipMemsetAsync(tlen, 0, (size_t)rows * sizeof(int), s));
@@ -1220,6 +1221,9 @@ extern "C" int zn_bench_kernel(zn_handle h, int32_t which, int32_t rows, int32_t
       } else if (which == 2) {
         a.W = (const bf16_t*)lw.out_proj; a.N = d; a.K = c.n_heads * h->hd; a.x = h->o1; a.resid = h->x; a.out = h->x;
         rc = run_gemv<PRO_NONE, EPI_RESID>(h, a, rows, h->tune[1], s);
+      } else if (which == 5) {
+        if (i % c.n_layer == c.n_layer - 1) continue;       // the last block's launch has no in_proj: not the launch being priced
+        rc = launch_chain(h, i % c.n_layer, std::vector<const void*>(c.n_layer, tkv), 8, tlen, s);
       } else if (which == 4) {
         a.W = (const bf16_t*)lw.in_proj; a.N = nq + 2 * nkv; a.K = d; a.x = h->x; a.ln_w = (const bf16_t*)lw.norm_w; a.ln_b = (const bf16_t*)lw.norm_b;
         a.lengths = tlen; a.hd = hd; a.n_heads = c.n_heads; a.n_heads_kv = c.n_heads_kv;
@@ -1238,8 +1242,11 @@ extern "C" int zn_bench_kernel(zn_handle h, int32_t which, int32_t rows, int32_t
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
   if (tkv) (void)hipFree(tkv);
   if (tlen) (void)hipFree(tlen);
-  *ms_per_launch = ms / iters;
-  const double wbytes = which == 0 ? 2.0 * c.d_ff * d * 2 : which == 1 ? (double)d * c.d_ff * 2 : which == 2 ? (double)d * c.n_heads * h->hd * 2
+  int launches = iters;
+  if (which == 5) { launches = 0; for (int i = 0; i < iters; ++i) launches += (i % c.n_layer != c.n_layer - 1); }
+  *ms_per_launch = ms / launches;
+  // chain launch: out_proj (read once, applied twice), fc1, fc2 of the block and in_proj of the next one
+  const double wbytes = which == 5 ? ((double)d * nq + 3.0 * c.d_ff * d + (double)(nq + 2 * nkv) * d) * 2 : which == 0 ? 2.0 * c.d_ff * d * 2 : which == 1 ? (double)d * c.d_ff * 2 : which == 2 ? (double)d * c.n_heads * h->hd * 2
                         : which == 4 ? (double)(nq + 2 * nkv) * d * 2 : (double)c.n_codebooks * c.vocab_head * d * 2;
   *bytes_per_launch = wbytes;   // algorithmic bytes = the weight matrix, read once (activations are KBs)
   return ZN_OK;

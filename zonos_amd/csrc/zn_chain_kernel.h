@@ -10,8 +10,8 @@
 // their streaming time; here one workgroup per CU stays resident for the whole chain: its 4 compute waves walk a STATIC
 // list of weight tiles (a tile = two weight rows x 512*NCH columns = one gemv_kernel work unit, same arithmetic order,
 // so the results are bit-identical to the launches path) with up to ZN_CH_NBUF tiles requested ahead in registers — requests run
-// across the op boundaries, so the HBM stream no longer drains at every dependency —, and a fifth, communication wave
-// (it issues no weight loads, so its own waits cover only the hand-off traffic) finishes each op: epilogue of the
+// across the op boundaries, so the HBM stream no longer drains at every dependency —, and two communication waves, one per
+// activation row (they issue no weight loads, so their own waits cover only the hand-off traffic) finish each op: epilogue of the
 // workgroup's rows, published as 8-byte {tag, two bf16} granules (one write-through store each: the data is the flag, no
 // drain, no counter: cdna_hip_programming.md Guideline 16 R2); the consumer sweeps the op's whole output vector with sc1
 // loads until every tag carries this launch's epoch (bounded), applies LayerNorm where the next op wants it and puts the
@@ -27,11 +27,11 @@
 // (measured, decode step at 400 tokens: 0x0 1.103 ms, 0x3 1.071, 0xB 1.048, 0xF 1.027: a request queued in front of a publish or a
 // sweep delays the hand-off by its whole service time, and the stream it feeds is not the bottleneck at that moment)
 #endif
-#define ZN_CH_CWAVES 4                                     // compute waves (a multiple of 4); the next wave = communication wave
+#define ZN_CH_CWAVES 4                                     // compute waves (a multiple of 4); the next two waves = communication waves
 #ifndef ZN_CH_NBUF
 #define ZN_CH_NBUF 3                                       // weight tiles requested ahead per compute wave (register buffers)
 #endif
-#define ZN_CH_THREADS ((ZN_CH_CWAVES + 1) * 64)
+#define ZN_CH_THREADS ((ZN_CH_CWAVES + 2) * 64)              // + one communication wave per activation row
 #define ZN_CH_TIMEOUT_TICKS 2000000ull                     // 20 ms of s_memrealtime (100 MHz)
 
 struct ChainArgs {
@@ -89,33 +89,20 @@ ZN_DEVINL bool sweep_granules(__amdgpu_buffer_rsrc_t rs, const int (&off)[N], un
   }
 }
 
-// nn.LayerNorm on two rows held as gemv_kernel holds them (lane owns elements (c*64 + lane)*8 .. +8 of each row), through the
-// helpers gemv_kernel's PRO_LN prologue uses (explicit roundings): identical statistics and outputs.
+// nn.LayerNorm on ONE row held as gemv_kernel holds it (lane owns elements (c*64 + lane)*8 .. +8), through the helpers
+// gemv_kernel's PRO_LN prologue uses (explicit roundings, rows independent of each other): identical statistics and outputs.
 template <int NCH>
-ZN_DEVINL void chain_layernorm(u32x4 (&xr)[NCH][2], const u32x4 (&lng)[NCH], const u32x4 (&lnb)[NCH], float eps) {
-  constexpr int R = 2;
+ZN_DEVINL void chain_layernorm_row(u32x4 (&x)[NCH], const u32x4 (&lng)[NCH], const u32x4 (&lnb)[NCH], float eps) {
   const float invK = 1.0f / (float)(NCH * 512);
-  float s[R], ss[R], mean[R], rstd[R];
+  float s = 0.f, ss = 0.f;
 #pragma unroll
-  for (int r = 0; r < R; ++r) {
-    s[r] = 0.f;
+  for (int c = 0; c < NCH; ++c) s += ln_sum8(x[c]);
+  const float mean = __fmul_rn(wave_sum(s), invK);
 #pragma unroll
-    for (int c = 0; c < NCH; ++c) s[r] += ln_sum8(xr[c][r]);
-  }
+  for (int c = 0; c < NCH; ++c) ss = ln_sq8(x[c], mean, ss);
+  const float rstd = ln_rstd(wave_sum(ss), invK, eps);
 #pragma unroll
-  for (int r = 0; r < R; ++r) mean[r] = __fmul_rn(wave_sum(s[r]), invK);
-#pragma unroll
-  for (int r = 0; r < R; ++r) {
-    ss[r] = 0.f;
-#pragma unroll
-    for (int c = 0; c < NCH; ++c) ss[r] = ln_sq8(xr[c][r], mean[r], ss[r]);
-  }
-#pragma unroll
-  for (int r = 0; r < R; ++r) rstd[r] = ln_rstd(wave_sum(ss[r]), invK, eps);
-#pragma unroll
-  for (int c = 0; c < NCH; ++c)
-#pragma unroll
-    for (int r = 0; r < R; ++r) xr[c][r] = ln_norm8(xr[c][r], mean[r], rstd[r], lng[c], lnb[c]);
+  for (int c = 0; c < NCH; ++c) x[c] = ln_norm8(x[c], mean, rstd, lng[c], lnb[c]);
 }
 
 // T_* = tiles per compute wave per op (upper bounds; a wave skips the tiles its workgroup does not have).  d_model =
@@ -260,14 +247,16 @@ __global__ __launch_bounds__(ZN_CH_THREADS) void chain_kernel(ChainArgs a) {
     return;
   }
 
-  // -------------------------------------------------------------------------------------- communication wave
+  // -------------------------------------------------------------------------------------- communication waves
+  // Wave CW + r gathers (sweeps), normalises and stages row r of every hand-off; wave CW also runs the epilogues.  (One wave
+  // for both rows spent 1.2 us per LayerNorm, VALU-bound on a single SIMD, on the critical path of ops 2 and 4.)
+  const int myr = wave - CW;
+  const bool epi = myr == 0;
   // operands that do not depend on this launch's hand-offs are requested up front
-  u32x4 g[NCH * R];                                        // gathered vector in gemv_kernel's lane layout: [c2 * R + r]
+  u32x4 g[NCH];                                            // this wave's row in gemv_kernel's lane layout
   u32x4 l2w[NCH], l2b[NCH], lnw[NCH], lnbb[NCH];
 #pragma unroll
-  for (int c2 = 0; c2 < NCH; ++c2)
-#pragma unroll
-    for (int r = 0; r < R; ++r) g[c2 * R + r] = ld16(a.a + (size_t)r * D + (c2 * 64 + lane) * 8);
+  for (int c2 = 0; c2 < NCH; ++c2) g[c2] = ld16(a.a + (size_t)myr * D + (c2 * 64 + lane) * 8);
 #pragma unroll
   for (int c2 = 0; c2 < NCH; ++c2) { l2w[c2] = ld16(a.ln2_w + (c2 * 64 + lane) * 8); l2b[c2] = ld16(a.ln2_b + (c2 * 64 + lane) * 8); }
   if constexpr (T_IN > 0) {
@@ -276,11 +265,11 @@ __global__ __launch_bounds__(ZN_CH_THREADS) void chain_kernel(ChainArgs a) {
   }
   // items of the row-pair ops (0, 1, 3, 4): lane = j * R + r
   const int ij = lane >> 1, ir = lane & 1;
-  const bool it_out = ij < ppw_out;                        // ops 0, 1, 3 (same units: d/2 pairs)
+  const bool it_out = epi && ij < ppw_out;                 // ops 0, 1, 3 (same units: d/2 pairs)
   const int u_out = c * ppw_out + (it_out ? ij : 0);
   unsigned resid = 0;
   if (it_out) resid = *(const unsigned*)(a.xin + (size_t)ir * D + 2 * u_out);
-  const bool it_in = T_IN > 0 && ij < ppw_in;
+  const bool it_in = epi && T_IN > 0 && ij < ppw_in;
   const int u_in = c * ppw_in + (it_in ? ij : 0);
   int pos = 0; float cs = 1.f, sn = 0.f;
   if constexpr (T_IN > 0) {
@@ -297,19 +286,15 @@ __global__ __launch_bounds__(ZN_CH_THREADS) void chain_kernel(ChainArgs a) {
   }
   __syncthreads();                                         // S
 #pragma unroll
-  for (int c2 = 0; c2 < NCH; ++c2)
-#pragma unroll
-    for (int r = 0; r < R; ++r) *(u32x4*)&s_act[r * D + (c2 * 64 + lane) * 8] = g[c2 * R + r];
+  for (int c2 = 0; c2 < NCH; ++c2) *(u32x4*)&s_act[myr * D + (c2 * 64 + lane) * 8] = g[c2];
   __syncthreads();                                         // B(0)
   int nst = 0;
-  auto stamp = [&]() { if (a.stamps && c == 0 && lane == 0) a.stamps[nst] = __builtin_amdgcn_s_memrealtime(); ++nst; };
+  auto stamp = [&]() { if (a.stamps && epi && c == 0 && lane == 0) a.stamps[nst] = __builtin_amdgcn_s_memrealtime(); ++nst; };
   stamp();
 
-  int goff[NCH * R];                                       // byte offsets of this lane's granules in a [2][d / 2] granule vector
+  int goff[NCH];                                           // byte offsets of this lane's granules of row myr in a [2][d / 2] granule vector
 #pragma unroll
-  for (int c2 = 0; c2 < NCH; ++c2)
-#pragma unroll
-    for (int r = 0; r < R; ++r) goff[c2 * R + r] = (r * (D / 2) + (c2 * 64 + lane) * 4) * 8;
+  for (int c2 = 0; c2 < NCH; ++c2) goff[c2] = (myr * (D / 2) + (c2 * 64 + lane) * 4) * 8;
   unsigned x1own = 0;
   zn_static_for<0, NOPS>([&](auto OC) {
     constexpr int op = decltype(OC)::value;
@@ -325,14 +310,16 @@ __global__ __launch_bounds__(ZN_CH_THREADS) void chain_kernel(ChainArgs a) {
         st_granule(a.g_x1 + (size_t)ir * (D / 2) + u_out, tag, x1own);
       }
     } else if constexpr (op == 2) {                        // EPI_SILU: lane = r * ppw_fc1 + j, neighbours share a granule
-      const int r2 = lane / ppw_fc1, j2 = lane % ppw_fc1;
-      const bool on = r2 < R;
-      const int jj = on ? j2 : 0, rr = on ? r2 : 0;
-      const float y = bfround(s_res[par][jj][0][rr]), gt = bfround(s_res[par][jj][1][rr]);
-      const float sg = bfround(gt / (1.0f + expf(-gt)));
-      const unsigned mine = (unsigned)f2bf(y * sg);
-      const unsigned nb = (unsigned)__shfl_down((int)mine, 1);
-      if (on && (j2 & 1) == 0) st_granule(a.g_m + (size_t)r2 * (F / 2) + ((c * ppw_fc1 + j2) >> 1), tag, mine | (nb << 16));
+      if (epi) {                                           // wave-uniform
+        const int r2 = lane / ppw_fc1, j2 = lane % ppw_fc1;
+        const bool on = r2 < R;
+        const int jj = on ? j2 : 0, rr = on ? r2 : 0;
+        const float y = bfround(s_res[par][jj][0][rr]), gt = bfround(s_res[par][jj][1][rr]);
+        const float sg = bfround(gt / (1.0f + expf(-gt)));
+        const unsigned mine = (unsigned)f2bf(y * sg);
+        const unsigned nb = (unsigned)__shfl_down((int)mine, 1);
+        if (on && (j2 & 1) == 0) st_granule(a.g_m + (size_t)r2 * (F / 2) + ((c * ppw_fc1 + j2) >> 1), tag, mine | (nb << 16));
+      }
     } else if constexpr (op == 3) {                        // EPI_RESID over the four K quarters, in gemv_kernel's order
       if (it_out) {
         const float vA = ((s_res[par][ij * 4 + 0][0][ir] + s_res[par][ij * 4 + 1][0][ir]) + s_res[par][ij * 4 + 2][0][ir]) + s_res[par][ij * 4 + 3][0][ir];
@@ -355,30 +342,17 @@ __global__ __launch_bounds__(ZN_CH_THREADS) void chain_kernel(ChainArgs a) {
         // (requesting the first pass ahead of the compute waves' held-back requests was measured slower, 1.089 vs 1.023 ms per step: it
         // comes back before the slowest publishers' stores are visible, and the second pass then queues behind those requests)
         int passes = 0;
-        sweep_granules<NCH * R>(zn_rsrc(op == 0 ? a.g_y1 : op == 1 ? a.g_x1 : a.g_x2), goff, tag, g, a.tmo, lane, a.stamps ? &passes : nullptr);
-        if (a.stamps && c == 0 && lane == 0) a.stamps[24 + op] = (unsigned long long)passes;
+        sweep_granules<NCH>(zn_rsrc(op == 0 ? a.g_y1 : op == 1 ? a.g_x1 : a.g_x2), goff, tag, g, a.tmo, lane, a.stamps ? &passes : nullptr);
+        if (a.stamps && epi && c == 0 && lane == 0) a.stamps[24 + op] = (unsigned long long)passes;
         stamp();
-        if constexpr (op == 1 || op == 3) {
-          u32x4 gl[NCH][R];
+        if constexpr (op == 1 || op == 3) chain_layernorm_row<NCH>(g, op == 1 ? l2w : lnw, op == 1 ? l2b : lnbb, a.eps);
 #pragma unroll
-          for (int c2 = 0; c2 < NCH; ++c2)
-#pragma unroll
-            for (int r = 0; r < R; ++r) gl[c2][r] = g[c2 * R + r];
-          chain_layernorm<NCH>(gl, op == 1 ? l2w : lnw, op == 1 ? l2b : lnbb, a.eps);
-#pragma unroll
-          for (int c2 = 0; c2 < NCH; ++c2)
-#pragma unroll
-            for (int r = 0; r < R; ++r) g[c2 * R + r] = gl[c2][r];
-        }
-#pragma unroll
-        for (int c2 = 0; c2 < NCH; ++c2)
-#pragma unroll
-          for (int r = 0; r < R; ++r) *(u32x4*)&s_act[r * D + (c2 * 64 + lane) * 8] = g[c2 * R + r];
+        for (int c2 = 0; c2 < NCH; ++c2) *(u32x4*)&s_act[myr * D + (c2 * 64 + lane) * 8] = g[c2];
         __syncthreads();                                   // B(op + 1)
       } else stamp();
       stamp();
     }
   });
   stamp();
-  if (c == 0 && lane == 0) *a.epoch = tag + 1;             // every workgroup read the epoch before its first publish, which this one has seen
+  if (epi && c == 0 && lane == 0) *a.epoch = tag + 1;      // every workgroup read the epoch before its first publish, which this one has seen
 }

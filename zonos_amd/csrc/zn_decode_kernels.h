@@ -1215,6 +1215,7 @@ __global__ __launch_bounds__(512) void attn_pv_kernel(AttnArgs a) {
       for (int e = 0; e < 8; ++e) s_acc[wave * 4 + row][g][(lane & 3) * 8 + e] = acc[g][e];
     }
   }
+  stamp();
 #pragma unroll
   for (int q = 0; q < GL; ++q) {
     // lsum[q] of lane vsub belongs to head vsub + 4q: sum over the 16 lanes with that vsub, per wave
@@ -1230,7 +1231,9 @@ __global__ __launch_bounds__(512) void attn_pv_kernel(AttnArgs a) {
       if (4 * q + 3 < G) s_l[wave][4 * q + 3] = l3;
     }
   }
+  stamp();
   __syncthreads();
+  stamp();
   float v = 0.f, l = 0.f;
   const int g = tid >> 5, d = tid & 31;
   if (tid < G * 32) {
