@@ -155,6 +155,10 @@ int zn_all_stopped_end(zn_handle h, int32_t* all_stopped_out);
 /* Copies the fp32 logits the sampler last consumed ([B, n_codebooks, vocab_head], after CFG and logit bias) and
  * the raw sampled tokens int32 [B, n_codebooks] to device buffers (either may be NULL).  For parity tests. */
 int zn_get_step_outputs(zn_handle h, float* logits_dev, int32_t* tokens_dev, zn_stream stream);
+/* The caller rewrote cells of delayed_codes between two zn_decode_steps calls (teacher forcing): every step's sampler launch
+ * also leaves the embedding of the column it wrote for the next step, and that embedding is stale now.  The next
+ * zn_decode_steps call embeds the current column again. */
+int zn_codes_changed(zn_handle h);
 /* Test hook: at loop step `step` (0-based) force codebook-0 EOS by setting its logit to 1e4 (-1 = off). */
 int zn_debug_force_eos(zn_handle h, int32_t step);
 /* Test hook: replace the sampled raw tokens of call k (0 = first frame, k = loop step k-1) by

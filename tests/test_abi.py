@@ -121,3 +121,20 @@ def test_chain_kernel_handoffs_are_granules_and_sc1_sweeps(kernels_isa):
         granules = [l for l in ins if l.startswith("global_store_dwordx2") and " sc1" in l]
         assert len(granules) >= 3, n                                                  # y1, x1, m (+ x2 when the next in_proj follows)
         assert not any(l.startswith("global_atomic_add") and "sc1" in l for l in ins)
+
+
+def test_sampler_tail_ticket_orders_the_token_handoff(kernels_isa):
+    """sample_kernel's last workgroup runs the step's bookkeeping + next embedding: the tokens of the other workgroups leave by ONE
+    write-through store, drained before the barrier and the arrival atomic, and are read back with sc1 loads."""
+    ins = kernels_isa["_Z13sample_kernel10SampleArgs"]
+    at = [i for i, l in enumerate(ins) if l.startswith("global_atomic_add")]
+    assert len(at) == 1
+    a = at[0]
+    before = ins[max(0, a - 40):a]
+    bar = max(i for i, l in enumerate(before) if l.startswith("s_barrier"))
+    drain = [i for i, l in enumerate(before[:bar]) if l.startswith("s_waitcnt") and "vmcnt(0)" in l]
+    assert drain and bar - drain[-1] <= 3
+    stores = [l for l in before[:drain[-1]] if l.startswith("global_store")]
+    assert stores and " sc1" in stores[-1], stores
+    sc1_loads = [l for l in ins[a:] if l.startswith("global_load_dword ") and " sc1" in l]
+    assert len(sc1_loads) >= 2, "token loads of the tail are sc1"

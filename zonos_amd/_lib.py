@@ -70,6 +70,7 @@ SIGNATURES = {
     "zn_get_step_outputs": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "zn_debug_force_eos": (C.c_int, [C.c_void_p, C.c_int32]),
     "zn_debug_token_override": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),
+    "zn_codes_changed": (C.c_int, [C.c_void_p]),
     "zn_debug_prefill_mode": (C.c_int, [C.c_void_p, C.c_int32]),
     "zn_debug_tune": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
     "zn_debug_eos_bias": (C.c_int, [C.c_void_p, C.c_float]),

@@ -40,6 +40,9 @@ struct zn_handle_s {
   unsigned* ch_epoch = nullptr;
   bf16_t* ch_x2 = nullptr;
   bf16_t* dbg_trace = nullptr;               // diagnostic: [n_layer][2][rows * d] copies of (x after the block, attention output) per decode step
+  bf16_t* x_emb = nullptr;                  // [max_rows][d] embedding of the column the next decode step consumes (written by the step's tail)
+  int* tail_ticket = nullptr;               // arrival ticket of the sampler launch whose last workgroup runs the step's tail
+  bool emb_valid = false;                   // x_emb holds the embedding of column st->offset
   unsigned long long* at_stamps = nullptr;   // diagnostic: [n_layer][8] timeline of the fused attention launch (second half of the chain stamp buffer)
   unsigned long long* ch_stamps = nullptr;   // diagnostic: [n_layer][32] timeline stamps of workgroup 0 (zn_debug_chain_stamps)
   int ch_variant = 0;          // 0 = shapes do not fit (launches path), 1 = <4,1,8,4,2> (Zonos-v0.1 dims), 2 = <1,1,2,1,1> (d_model 512)
@@ -129,7 +132,7 @@ static void free_graph(zn_handle h) {
 extern "C" int zn_destroy(zn_handle h) {
   if (!h) return ZN_OK;
   free_graph(h);
-  void* ptrs[] = {h->emb_tables_dev, h->x, h->q, h->o1, h->mbuf, h->nbuf, h->logits_raw, h->last_logits, h->tok_raw, h->scores, h->cmax, h->pv_part, h->pv_tickets, h->pf_x, h->pf_n, h->pf_qkv, h->pf_a, h->pf_u, h->pf_m, h->pf_res, h->pf_zx, h->pf_xbc, h->pf_y, h->pf_g, h->qkv_tmp, h->fw_lengths, h->st, h->remaining, h->stopping, h->res, h->hn, h->m_zx, h->m_xbc, h->m_y, h->m_g, h->m_vg, h->g16_part, h->g16_tickets, h->ch_gy1, h->ch_gx1, h->ch_gx2, h->ch_gm, h->ch_epoch, h->ch_x2};
+  void* ptrs[] = {h->emb_tables_dev, h->x, h->q, h->o1, h->mbuf, h->nbuf, h->logits_raw, h->last_logits, h->tok_raw, h->scores, h->cmax, h->pv_part, h->pv_tickets, h->pf_x, h->pf_n, h->pf_qkv, h->pf_a, h->pf_u, h->pf_m, h->pf_res, h->pf_zx, h->pf_xbc, h->pf_y, h->pf_g, h->qkv_tmp, h->fw_lengths, h->st, h->remaining, h->stopping, h->res, h->hn, h->m_zx, h->m_xbc, h->m_y, h->m_g, h->m_vg, h->g16_part, h->g16_tickets, h->ch_gy1, h->ch_gx1, h->ch_gx2, h->ch_gm, h->ch_epoch, h->ch_x2, h->x_emb, h->tail_ticket};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (h->done_host) (void)hipHostFree(h->done_host);
   if (h->stop_event) (void)hipEventDestroy(h->stop_event);
@@ -233,6 +236,9 @@ extern "C" int zn_create(const zn_config* cfg, const zn_weights* w, int32_t max_
   h->ch_variant = chain_variant_for(c);
   if (const char* e = getenv("ZN_CHAIN")) if (atoi(e) == 0) h->tune[8] = 2;
   {   // split-K partial tiles + tickets of the small-M projections (batches of 3..8 utterances; short-prompt prefill at any batch)
+    ZC(hipMalloc(&h->x_emb, R * c.d_model * 2));
+    ZC(hipMalloc(&h->tail_ticket, sizeof(int)));
+    ZC(hipMemset(h->tail_ticket, 0, sizeof(int)));
     ZC(hipMalloc(&h->g16_part, ZN_G16_PART_BYTES));
     ZC(hipMalloc(&h->g16_tickets, ZN_G16_MAX_GROUPS * sizeof(int)));
     ZC(hipMemset(h->g16_tickets, 0, ZN_G16_MAX_GROUPS * sizeof(int)));
@@ -546,14 +552,15 @@ static bf16_t* chain_x(zn_handle h, int li) { return (li & 1) ? h->ch_x2 : h->x;
 
 // Post-attention chain of block `li` plus the in_proj of block li + 1 in ONE launch (zn_chain_kernel.h); x = h->x, the
 // attention output in h->o1, the next block's q in h->q.
-static int launch_chain(zn_handle h, int li, const std::vector<const void*>& kv_layers, int max_len, const int* lengths, hipStream_t s) {
+static int launch_chain(zn_handle h, int li, const std::vector<const void*>& kv_layers, int max_len, const int* lengths, hipStream_t s,
+                        const bf16_t* xin = nullptr) {
   const zn_config& c = h->cfg;
   const zn_layer_weights& lw = h->layers[li];
   const bool last = li + 1 >= c.n_layer;
   ChainArgs a{};
   a.W_out = (const bf16_t*)lw.out_proj; a.W_fc1 = (const bf16_t*)lw.fc1; a.W_fc2 = (const bf16_t*)lw.fc2;
   a.ln2_w = (const bf16_t*)lw.norm2_w; a.ln2_b = (const bf16_t*)lw.norm2_b; a.eps = c.norm_eps; a.F = c.d_ff;
-  a.a = h->o1; a.xin = chain_x(h, li); a.xout = chain_x(h, li + 1);
+  a.a = h->o1; a.xin = xin ? xin : chain_x(h, li); a.xout = chain_x(h, li + 1);
   a.g_y1 = h->ch_gy1; a.g_x1 = h->ch_gx1; a.g_x2 = h->ch_gx2; a.g_m = h->ch_gm;
   a.epoch = h->ch_epoch; a.tmo = &h->st->pad[0];
   a.stamps = h->ch_stamps ? h->ch_stamps + (size_t)li * 32 : nullptr;
@@ -576,11 +583,13 @@ static int launch_chain(zn_handle h, int li, const std::vector<const void*>& kv_
 }
 
 // All blocks of one decode step on h->x (transformer): launches per op, or in_proj(0) + (attention, chain) per block.
-static int decode_blocks(zn_handle h, const int* ext, int ext_scalar, hipStream_t s) {
+// x0 != NULL: the residual stream enters the first block from there (the decode step's embedding buffer) instead of h->x.
+static int decode_blocks(zn_handle h, const int* ext, int ext_scalar, hipStream_t s, const bf16_t* x0 = nullptr) {
   const zn_config& c = h->cfg;
   int rc;
   const size_t tb = (size_t)h->rows * c.d_model * 2;
   const bool chain = chain_active(h, h->rows);
+  if (x0 && !chain) { HIPCHK(h, hipMemcpyAsync(h->x, x0, tb, hipMemcpyDeviceToDevice, s)); x0 = nullptr; }
   auto trace = [&](int li) {        // slots per block: x after the block, attention output, q, m (first d values per row pair), x after the attention half
     if (!h->dbg_trace) return;
     (void)hipMemcpyAsync((char*)h->dbg_trace + (size_t)(8 * li) * tb, chain ? chain_x(h, li + 1) : h->x, tb, hipMemcpyDeviceToDevice, s);
@@ -602,12 +611,12 @@ static int decode_blocks(zn_handle h, const int* ext, int ext_scalar, hipStream_
     }
     return ZN_OK;
   }
-  if ((rc = layer_in_proj(h, 0, h->x, (bf16_t*)h->kv_layers[0], h->max_len, h->lengths, h->rows, s))) return rc;
+  if ((rc = layer_in_proj(h, 0, x0 ? const_cast<bf16_t*>(x0) : h->x, (bf16_t*)h->kv_layers[0], h->max_len, h->lengths, h->rows, s))) return rc;
   for (int li = 0; li < c.n_layer; ++li) {
     trace_q(li);
     if ((rc = run_attention(h, h->q, (bf16_t*)h->kv_layers[li], h->max_len, h->lengths, ext, ext_scalar, h->o1, h->rows, s,
                             h->ch_stamps ? h->ch_stamps + (size_t)(c.n_layer + li) * 32 : nullptr))) return rc;
-    if ((rc = launch_chain(h, li, h->kv_layers, h->max_len, h->lengths, s))) return rc;
+    if ((rc = launch_chain(h, li, h->kv_layers, h->max_len, h->lengths, s, li == 0 ? x0 : nullptr))) return rc;
     trace(li);
   }
   if (c.n_layer & 1) HIPCHK(h, hipMemcpyAsync(h->x, h->ch_x2, tb, hipMemcpyDeviceToDevice, s));   // odd depth: the stream ends in the second buffer
@@ -749,18 +758,25 @@ static SampleArgs make_sample_args(zn_handle h, const zn_sampling& sp) {
   return a;
 }
 
-// embed -> 26 blocks -> heads -> CFG/bias/penalty/sample -> bookkeeping: one iteration of model.py:467-502
+static EmbedArgs make_embed_args(zn_handle h) {
+  const zn_config& c = h->cfg;
+  EmbedArgs e{};
+  e.tables = h->emb_tables_dev; e.codes = h->codes; e.col_dev = &h->st->offset; e.sb = c.n_codebooks * h->t_total; e.si = h->t_total;
+  e.col = 0; e.n_q = c.n_codebooks; e.d = c.d_model; e.batch = h->batch; e.vocab_embed = c.vocab_embed; e.out = h->x_emb; e.dup = 1;
+  return e;
+}
+
+// One iteration of model.py:467-502.  The embedding of the current column is in h->x_emb when the step starts (zn_decode_steps
+// launches embed_kernel before the first step of a run; every step's tail leaves the next one's): 26 blocks -> heads ->
+// CFG/bias/penalty/sample, whose last workgroup runs the bookkeeping and the next step's embedding (SampleArgs::ticket).
 static int enqueue_step(zn_handle h, hipStream_t s) {
   const zn_config& c = h->cfg;
   int rc;
-  EmbedArgs e{};
-  e.tables = h->emb_tables_dev; e.codes = h->codes; e.col_dev = &h->st->offset; e.sb = c.n_codebooks * h->t_total; e.si = h->t_total;
-  e.col = 0; e.n_q = c.n_codebooks; e.d = c.d_model; e.batch = h->batch; e.vocab_embed = c.vocab_embed; e.out = h->x; e.dup = 1;
-  hipLaunchKernelGGL(embed_kernel, dim3(h->batch), dim3(256), 0, s, e);
   if (c.arch == 1) {
+    HIPCHK(h, hipMemcpyAsync(h->x, h->x_emb, (size_t)h->rows * c.d_model * 2, hipMemcpyDeviceToDevice, s));
     if ((rc = hybrid_token(h, true, s))) return rc;
   } else {
-    if ((rc = decode_blocks(h, nullptr, 0, s))) return rc;
+    if ((rc = decode_blocks(h, nullptr, 0, s, h->x_emb))) return rc;
     if ((rc = heads_logits(h, h->x, h->rows, s))) return rc;
   }
   SampleArgs a = make_sample_args(h, h->sp);
@@ -768,12 +784,18 @@ static int enqueue_step(zn_handle h, hipStream_t s) {
   a.codes = h->codes; a.t_total = h->t_total; a.ctx = h->max_new < 100 ? h->max_new : 100;
   a.use_penalty = (h->sp.repetition_penalty != 1.0f); a.st = h->st; a.logits_out = h->last_logits; a.tokens = h->tok_raw;
   a.draw = 1;
-  hipLaunchKernelGGL(sample_kernel, dim3(c.n_codebooks, h->batch), dim3(256), 0, s, a);
-  FrameArgs f{};
+  FrameArgs& f = a.fr;
   f.st = h->st; f.codes = h->codes; f.t_total = h->t_total; f.batch = h->batch; f.n_q = c.n_codebooks; f.eos_id = c.eos_id;
   f.mask_id = c.mask_id; f.tokens = h->tok_raw; f.remaining = h->remaining; f.stopping = h->stopping; f.lengths = h->lengths;
   f.rows = h->rows; f.first = 0; f.override = h->tok_override; f.override_calls = h->tok_override_calls;
-  hipLaunchKernelGGL(frame_update_kernel, dim3(1), dim3(256), 0, s, f);
+  if (h->batch <= ZN_TAIL_MAXB) {
+    a.ticket = h->tail_ticket; a.em = make_embed_args(h);
+    hipLaunchKernelGGL(sample_kernel, dim3(c.n_codebooks, h->batch), dim3(256), 0, s, a);
+  } else {                                                  // more utterances than the tail's LDS table holds: three launches
+    hipLaunchKernelGGL(sample_kernel, dim3(c.n_codebooks, h->batch), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(frame_update_kernel, dim3(1), dim3(256), 0, s, f);
+    hipLaunchKernelGGL(embed_kernel, dim3(h->batch), dim3(256), 0, s, make_embed_args(h));
+  }
   return ZN_OK;
 }
 
@@ -811,6 +833,7 @@ extern "C" int zn_gen_begin(zn_handle h, int32_t batch, const void* const* kv_la
   for (int v : len0) if (v > h->len_hi) h->len_hi = v;
   h->gen_active = true;
   h->stop_pending = false;
+  h->emb_valid = false;
   return ZN_OK;
 }
 
@@ -1070,6 +1093,7 @@ extern "C" int zn_sample_first(zn_handle h, zn_stream stream) {
   f.mask_id = c.mask_id; f.tokens = h->tok_raw; f.remaining = h->remaining; f.stopping = h->stopping; f.lengths = h->lengths;
   f.rows = h->rows; f.first = 1; f.override = h->tok_override; f.override_calls = h->tok_override_calls;
   hipLaunchKernelGGL(frame_update_kernel, dim3(1), dim3(256), 0, s, f);
+  h->emb_valid = false;
   HIPCHK(h, hipGetLastError());
   return ZN_OK;
 }
@@ -1079,6 +1103,10 @@ extern "C" int zn_decode_steps(zn_handle h, int32_t n, zn_stream stream) {
   if (!h->gen_active) ZN_FAIL(h, ZN_ERR_STATE, "zn_decode_steps before zn_gen_begin");
   if (n < 0) ZN_FAIL(h, ZN_ERR_ARG, "n < 0");
   hipStream_t s = (hipStream_t)stream;
+  if (n > 0 && !h->emb_valid) {        // first step of the generation: later ones find the embedding their predecessor's tail left
+    hipLaunchKernelGGL(embed_kernel, dim3(h->batch), dim3(256), 0, s, make_embed_args(h));
+    h->emb_valid = true;
+  }
   for (int i = 0; i < n;) {
     // this step appends one key per row; a run of ZN_GRAPH_STEPS steps with one launch shape replays the long graph
     const bool fused = attn_fused_for(h, h->len_hi + 1);
@@ -1153,6 +1181,7 @@ extern "C" int zn_get_step_outputs(zn_handle h, float* logits_dev, int32_t* toke
   return ZN_OK;
 }
 
+extern "C" int zn_codes_changed(zn_handle h) { if (!h) return ZN_ERR_ARG; h->emb_valid = false; return ZN_OK; }
 extern "C" int zn_debug_force_eos(zn_handle h, int32_t step) { if (!h) return ZN_ERR_ARG; h->force_eos_step = step; return ZN_OK; }
 extern "C" int zn_debug_token_override(zn_handle h, const int32_t* tokens_dev, int32_t calls) {
   if (!h) return ZN_ERR_ARG;

@@ -1316,17 +1316,8 @@ struct EmbedArgs {
   int dup;                      // 1: also write row b + batch (CFG duplicate, generation_utils.py:192)
 };
 #define ZN_EMBED_MAXQ 16
-__global__ __launch_bounds__(256) void embed_kernel(EmbedArgs a) {
-  const int b = blockIdx.x;
-  const int col = a.col_dev ? *a.col_dev : a.col;
-  // all codes, then all table rows, are requested before the first add (three memory round trips on the step's
-  // launch-bound tail instead of one per codebook); indices past n_q repeat the last codebook and are not added
-  int code[ZN_EMBED_MAXQ];
-#pragma unroll
-  for (int i = 0; i < ZN_EMBED_MAXQ; ++i) {
-    const int c = a.codes[(size_t)b * a.sb + (size_t)min(i, a.n_q - 1) * a.si + col];
-    code[i] = c < 0 ? 0 : (c >= a.vocab_embed ? a.vocab_embed - 1 : c);
-  }
+// Sum of the n_q codebook embeddings of utterance b (codes clamped into the table) -> out rows b (and b + batch).
+ZN_DEVINL void embed_row(const EmbedArgs& a, int b, const int (&code)[ZN_EMBED_MAXQ]) {
   for (int k = threadIdx.x * 8; k < a.d; k += 256 * 8) {
     u32x4 v[ZN_EMBED_MAXQ];
 #pragma unroll
@@ -1345,6 +1336,19 @@ __global__ __launch_bounds__(256) void embed_kernel(EmbedArgs a) {
     *(u32x4*)(a.out + (size_t)b * a.d + k) = o;
     if (a.dup) *(u32x4*)(a.out + (size_t)(b + a.batch) * a.d + k) = o;
   }
+}
+__global__ __launch_bounds__(256) void embed_kernel(EmbedArgs a) {
+  const int b = blockIdx.x;
+  const int col = a.col_dev ? *a.col_dev : a.col;
+  // all codes, then all table rows, are requested before the first add (three memory round trips on the step's
+  // launch-bound tail instead of one per codebook); indices past n_q repeat the last codebook and are not added
+  int code[ZN_EMBED_MAXQ];
+#pragma unroll
+  for (int i = 0; i < ZN_EMBED_MAXQ; ++i) {
+    const int c = a.codes[(size_t)b * a.sb + (size_t)min(i, a.n_q - 1) * a.si + col];
+    code[i] = c < 0 ? 0 : (c >= a.vocab_embed ? a.vocab_embed - 1 : c);
+  }
+  embed_row(a, b, code);
 }
 
 // rows of a [rows][S][d] tensor at position s -> x [rows][d]
@@ -1413,6 +1417,19 @@ struct GenState {      // device-resident loop state (model.py:439-465)
   int pad[3];
 };
 
+struct FrameArgs {
+  GenState* st;
+  int* codes; int t_total, batch, n_q, eos_id, mask_id;
+  const int* tokens;   // raw sampled [B][n_q]
+  int* remaining;      // [B]
+  int* stopping;       // [B]
+  int* lengths; int rows;
+  int first;           // 1: model.py:423-431 (first frame after prefill: plain write-where-unknown)
+  const int* override; // test hook: raw tokens [calls][B][n_q] replacing the sampled ones (call 0 = first frame)
+  int override_calls;
+};
+#define ZN_FRAME_MAXQ 16
+#define ZN_TAIL_MAXB 64
 struct SampleArgs {
   const float* raw;        // [2B][n_q*V] bf16-valued fp32 from the heads GEMV (mix=1) or [B][n_q][V] final logits
   int mix; float cfg_scale;
@@ -1428,6 +1445,12 @@ struct SampleArgs {
   float* logits_out;       // [B][n_q][V] logits as consumed by the sampler (after bias), may be NULL
   float* probs_out;        // optional filtered probabilities
   int* tokens;             // [B][n_q]
+  // Loop steps: the last workgroup of the launch to finish (arrival ticket, nobody waits) also runs the step's bookkeeping
+  // (frame_update_kernel's body) and the NEXT step's embedding (embed_kernel's body, into em.out) - two launches fewer on the
+  // step's launch-bound tail.  ticket == NULL: off (single ops, the first frame).
+  int* ticket;
+  FrameArgs fr;
+  EmbedArgs em;            // codes/col fields unused: the codes come from the bookkeeping just done
 };
 
 ZN_DEVINL void block_argmax(float v, int i, float* sv, int* si, float& bv, int& bi) {
@@ -1471,6 +1494,60 @@ ZN_DEVINL unsigned long long zn_mix64(unsigned long long z) {
   z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
   return z ^ (z >> 31);
 }
+
+// TAIL: called by the last workgroup of sample_kernel (tokens of the other workgroups arrive by sc1 loads); s_code[b][cb] receives
+// the codes of the column just written (= what the next step embeds).
+template <bool TAIL>
+ZN_DEVINL void frame_update_body(const FrameArgs& a, int (*s_code)[ZN_FRAME_MAXQ]) {
+  // 16 lanes per utterance, one per codebook: every cell, token and counter is requested at once (the per-codebook loop
+  // of the reference becomes one memory round trip); lanes of one utterance share a wave, so all of them have read the
+  // counters before lane 0 of the group rewrites them.  n_q <= 16 is checked by zn_create.
+  const int o = a.st->offset, stp = a.st->step;
+  __shared__ int s_done;
+  if (threadIdx.x == 0) s_done = 1;
+  __syncthreads();
+  const int cb = threadIdx.x & (ZN_FRAME_MAXQ - 1);
+  for (int b = threadIdx.x / ZN_FRAME_MAXQ; b < a.batch; b += blockDim.x / ZN_FRAME_MAXQ) {
+    const int* tk = a.tokens + b * a.n_q;
+    const int call = a.first ? 0 : stp + 1;
+    const bool ovr = a.override && call < a.override_calls;
+    if (ovr) tk = a.override + ((size_t)call * a.batch + b) * a.n_q;
+    const int cbc = min(cb, a.n_q - 1);
+    const int col = a.first ? o : o + 1;
+    const bool in_range = cb < a.n_q && col < a.t_total;
+    int* cell = a.codes + ((size_t)b * a.n_q + cbc) * a.t_total + min(col, a.t_total - 1);
+    int tok, tok0;
+    if (TAIL && !ovr) {
+      tok = __hip_atomic_load(tk + cbc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      tok0 = __hip_atomic_load(tk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else { tok = tk[cbc]; tok0 = tk[0]; }
+    const int cur = *cell;
+    if (a.first) {                                           // model.py:423-431: plain write-where-unknown
+      if (in_range && cur == -1) *cell = tok;
+      continue;
+    }
+    // model.py:483-497 + tensor_ops.py:155-211
+    int rem = a.remaining[b];
+    int stop = a.stopping[b];
+    if (tok0 == a.eos_id) { rem = rem < a.n_q ? rem : a.n_q; stop = 1; }
+    int eos_idx = a.n_q - rem; if (eos_idx > a.n_q - 1) eos_idx = a.n_q - 1;
+    int t = tok;
+    if (stop && cb < eos_idx) t = a.mask_id; else if (stop && cb == eos_idx) t = a.eos_id;
+    if (in_range && cur == -1) *cell = t;                    // tensor_ops.py:42-49
+    if (TAIL) s_code[b][cb] = (in_range && cur == -1) ? t : cur;
+    rem -= 1;                                                // tensor_ops.py:87
+    if (cb == 0) {
+      a.remaining[b] = rem; a.stopping[b] = stop;
+      if (rem > 0) atomicAnd(&s_done, 0);
+    }
+  }
+  __syncthreads();
+  if (!a.first) {
+    for (int r = threadIdx.x; r < a.rows; r += blockDim.x) a.lengths[r] += 1;   // tensor_ops.py:85-86
+    if (threadIdx.x == 0) { a.st->offset = o + 1; a.st->step = stp + 1; a.st->all_done = s_done; }
+  }
+}
+__global__ __launch_bounds__(256) void frame_update_kernel(FrameArgs a) { frame_update_body<false>(a, nullptr); }
 
 #define ZN_SAMPLE_MAXV 2048
 __global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
@@ -1653,61 +1730,35 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
     block_argmax(bv, bi, sv, si, rv, ri);
     tok = ri == 0x7fffffff ? 0 : ri;
   }
-  if (tid == 0) a.tokens[b * a.n_q + cb] = tok;
+  if (!a.ticket) {
+    if (tid == 0) a.tokens[b * a.n_q + cb] = tok;
+    return;
+  }
+  // ---- the step's tail in the last workgroup to arrive (Guideline 16 R1: write-through token, drain, barrier, ticket; sc1 loads)
+  __shared__ int s_last;
+  __shared__ int s_code[ZN_TAIL_MAXB][ZN_FRAME_MAXQ];
+  if (tid == 0) __hip_atomic_store(a.tokens + b * a.n_q + cb, tok, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __builtin_amdgcn_s_waitcnt(0);                          // vmcnt(0): the token store is acknowledged before the ticket
+  __syncthreads();
+  if (tid == 0) {
+    const int n = (int)(gridDim.x * gridDim.y);
+    const int t = __hip_atomic_fetch_add(a.ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = (t == n - 1);
+    if (s_last) __hip_atomic_store(a.ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  if (!s_last) return;
+  frame_update_body<true>(a.fr, s_code);
+  __syncthreads();
+  for (int ub = 0; ub < a.fr.batch; ++ub) {
+    int code[ZN_EMBED_MAXQ];
+#pragma unroll
+    for (int i = 0; i < ZN_EMBED_MAXQ; ++i) {
+      const int c = s_code[ub][min(i, a.em.n_q - 1)];
+      code[i] = c < 0 ? 0 : (c >= a.em.vocab_embed ? a.em.vocab_embed - 1 : c);
+    }
+    embed_row(a.em, ub, code);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------ bookkeeping
-struct FrameArgs {
-  GenState* st;
-  int* codes; int t_total, batch, n_q, eos_id, mask_id;
-  const int* tokens;   // raw sampled [B][n_q]
-  int* remaining;      // [B]
-  int* stopping;       // [B]
-  int* lengths; int rows;
-  int first;           // 1: model.py:423-431 (first frame after prefill: plain write-where-unknown)
-  const int* override; // test hook: raw tokens [calls][B][n_q] replacing the sampled ones (call 0 = first frame)
-  int override_calls;
-};
-#define ZN_FRAME_MAXQ 16
-__global__ __launch_bounds__(256) void frame_update_kernel(FrameArgs a) {
-  // 16 lanes per utterance, one per codebook: every cell, token and counter is requested at once (the per-codebook loop
-  // of the reference becomes one memory round trip); lanes of one utterance share a wave, so all of them have read the
-  // counters before lane 0 of the group rewrites them.  n_q <= 16 is checked by zn_create.
-  const int o = a.st->offset, stp = a.st->step;
-  __shared__ int s_done;
-  if (threadIdx.x == 0) s_done = 1;
-  __syncthreads();
-  const int cb = threadIdx.x & (ZN_FRAME_MAXQ - 1);
-  for (int b = threadIdx.x / ZN_FRAME_MAXQ; b < a.batch; b += blockDim.x / ZN_FRAME_MAXQ) {
-    const int* tk = a.tokens + b * a.n_q;
-    const int call = a.first ? 0 : stp + 1;
-    if (a.override && call < a.override_calls) tk = a.override + ((size_t)call * a.batch + b) * a.n_q;
-    const int cbc = min(cb, a.n_q - 1);
-    const int col = a.first ? o : o + 1;
-    const bool in_range = cb < a.n_q && col < a.t_total;
-    int* cell = a.codes + ((size_t)b * a.n_q + cbc) * a.t_total + min(col, a.t_total - 1);
-    const int cur = *cell, tok = tk[cbc], tok0 = tk[0];
-    if (a.first) {                                           // model.py:423-431: plain write-where-unknown
-      if (in_range && cur == -1) *cell = tok;
-      continue;
-    }
-    // model.py:483-497 + tensor_ops.py:155-211
-    int rem = a.remaining[b];
-    int stop = a.stopping[b];
-    if (tok0 == a.eos_id) { rem = rem < a.n_q ? rem : a.n_q; stop = 1; }
-    int eos_idx = a.n_q - rem; if (eos_idx > a.n_q - 1) eos_idx = a.n_q - 1;
-    int t = tok;
-    if (stop && cb < eos_idx) t = a.mask_id; else if (stop && cb == eos_idx) t = a.eos_id;
-    if (in_range && cur == -1) *cell = t;                    // tensor_ops.py:42-49
-    rem -= 1;                                                // tensor_ops.py:87
-    if (cb == 0) {
-      a.remaining[b] = rem; a.stopping[b] = stop;
-      if (rem > 0) atomicAnd(&s_done, 0);
-    }
-  }
-  __syncthreads();
-  if (!a.first) {
-    for (int r = threadIdx.x; r < a.rows; r += blockDim.x) a.lengths[r] += 1;   // tensor_ops.py:85-86
-    if (threadIdx.x == 0) { a.st->offset = o + 1; a.st->step = stp + 1; a.st->all_done = s_done; }
-  }
-}

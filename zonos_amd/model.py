@@ -243,6 +243,7 @@ class Zonos(nn.Module):
                     hook = _trace.get("after_step")
                     if hook is not None:
                         hook(step_idx, delayed, offset)
+                        eng.call("zn_codes_changed")        # the hook may rewrite the column the next step embeds
             if check and deferred:
                 if begun_at is not None:
                     eng.call("zn_all_stopped_end", C.byref(done))
