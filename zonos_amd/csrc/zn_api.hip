@@ -589,7 +589,7 @@ static int decode_blocks(zn_handle h, const int* ext, int ext_scalar, hipStream_
   int rc;
   const size_t tb = (size_t)h->rows * c.d_model * 2;
   const bool chain = chain_active(h, h->rows);
-  if (x0 && !chain) { HIPCHK(h, hipMemcpyAsync(h->x, x0, tb, hipMemcpyDeviceToDevice, s)); x0 = nullptr; }
+  if (x0 && !chain) ZN_FAIL(h, ZN_ERR_STATE, "decode_blocks: a separate input buffer is the chain path's");
   auto trace = [&](int li) {        // slots per block: x after the block, attention output, q, m (first d values per row pair), x after the attention half
     if (!h->dbg_trace) return;
     (void)hipMemcpyAsync((char*)h->dbg_trace + (size_t)(8 * li) * tb, chain ? chain_x(h, li + 1) : h->x, tb, hipMemcpyDeviceToDevice, s);
@@ -766,17 +766,27 @@ static EmbedArgs make_embed_args(zn_handle h) {
   return e;
 }
 
-// One iteration of model.py:467-502.  The embedding of the current column is in h->x_emb when the step starts (zn_decode_steps
-// launches embed_kernel before the first step of a run; every step's tail leaves the next one's): 26 blocks -> heads ->
-// CFG/bias/penalty/sample, whose last workgroup runs the bookkeeping and the next step's embedding (SampleArgs::ticket).
+// Batch 1 on the chain path: the step's tail (bookkeeping + next step's embedding) runs in the sampler launch's last workgroup.
+// Larger batches keep three launches (embed_kernel spreads the utterances over workgroups; one workgroup embedding 8 utterances
+// in turn cost 31 us per step at batch 8), and so does everything off the chain path (its first op reads h->x).
+static bool tail_fused(zn_handle h) { return h->cfg.arch == 0 && chain_active(h, h->rows) && h->batch <= 2; }
+
+// One iteration of model.py:467-502: embed -> 26 blocks -> heads -> CFG/bias/penalty/sample -> bookkeeping.  With the fused tail the
+// embedding of the current column is already in h->x_emb when the step starts (zn_decode_steps launches embed_kernel before the
+// first step of a run; every step's sampler launch leaves the next one's, SampleArgs::ticket).
 static int enqueue_step(zn_handle h, hipStream_t s) {
   const zn_config& c = h->cfg;
   int rc;
+  const bool fused = tail_fused(h);
+  if (!fused) {
+    EmbedArgs e = make_embed_args(h);
+    e.out = h->x;
+    hipLaunchKernelGGL(embed_kernel, dim3(h->batch), dim3(256), 0, s, e);
+  }
   if (c.arch == 1) {
-    HIPCHK(h, hipMemcpyAsync(h->x, h->x_emb, (size_t)h->rows * c.d_model * 2, hipMemcpyDeviceToDevice, s));
     if ((rc = hybrid_token(h, true, s))) return rc;
   } else {
-    if ((rc = decode_blocks(h, nullptr, 0, s, h->x_emb))) return rc;
+    if ((rc = decode_blocks(h, nullptr, 0, s, fused ? h->x_emb : nullptr))) return rc;
     if ((rc = heads_logits(h, h->x, h->rows, s))) return rc;
   }
   SampleArgs a = make_sample_args(h, h->sp);
@@ -788,14 +798,9 @@ static int enqueue_step(zn_handle h, hipStream_t s) {
   f.st = h->st; f.codes = h->codes; f.t_total = h->t_total; f.batch = h->batch; f.n_q = c.n_codebooks; f.eos_id = c.eos_id;
   f.mask_id = c.mask_id; f.tokens = h->tok_raw; f.remaining = h->remaining; f.stopping = h->stopping; f.lengths = h->lengths;
   f.rows = h->rows; f.first = 0; f.override = h->tok_override; f.override_calls = h->tok_override_calls;
-  if (h->batch <= ZN_TAIL_MAXB) {
-    a.ticket = h->tail_ticket; a.em = make_embed_args(h);
-    hipLaunchKernelGGL(sample_kernel, dim3(c.n_codebooks, h->batch), dim3(256), 0, s, a);
-  } else {                                                  // more utterances than the tail's LDS table holds: three launches
-    hipLaunchKernelGGL(sample_kernel, dim3(c.n_codebooks, h->batch), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(frame_update_kernel, dim3(1), dim3(256), 0, s, f);
-    hipLaunchKernelGGL(embed_kernel, dim3(h->batch), dim3(256), 0, s, make_embed_args(h));
-  }
+  if (fused) { a.ticket = h->tail_ticket; a.em = make_embed_args(h); }
+  hipLaunchKernelGGL(sample_kernel, dim3(c.n_codebooks, h->batch), dim3(256), 0, s, a);
+  if (!fused) hipLaunchKernelGGL(frame_update_kernel, dim3(1), dim3(256), 0, s, f);
   return ZN_OK;
 }
 
@@ -1103,7 +1108,7 @@ extern "C" int zn_decode_steps(zn_handle h, int32_t n, zn_stream stream) {
   if (!h->gen_active) ZN_FAIL(h, ZN_ERR_STATE, "zn_decode_steps before zn_gen_begin");
   if (n < 0) ZN_FAIL(h, ZN_ERR_ARG, "n < 0");
   hipStream_t s = (hipStream_t)stream;
-  if (n > 0 && !h->emb_valid) {        // first step of the generation: later ones find the embedding their predecessor's tail left
+  if (n > 0 && tail_fused(h) && !h->emb_valid) {   // first step of the generation: later ones find the embedding their predecessor's tail left
     hipLaunchKernelGGL(embed_kernel, dim3(h->batch), dim3(256), 0, s, make_embed_args(h));
     h->emb_valid = true;
   }
@@ -1191,7 +1196,7 @@ extern "C" int zn_debug_token_override(zn_handle h, const int32_t* tokens_dev, i
 }
 extern "C" int zn_debug_tune(zn_handle h, int32_t key, int32_t value) {
   if (!h || key < 0 || key >= 16 || value < 1) return ZN_ERR_ARG;
-  h->tune[key] = value; free_graph(h);
+  h->tune[key] = value; free_graph(h); h->emb_valid = false;
   return ZN_OK;
 }
 extern "C" int zn_debug_trace(zn_handle h, void* trace_dev) {
