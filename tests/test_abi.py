@@ -113,7 +113,7 @@ def test_chain_kernel_handoffs_are_granules_and_sc1_sweeps(kernels_isa):
     """The persistent chain publishes 8-byte {tag, data} granules with ONE write-through store each (the data is the flag:
     Guideline 16 R2) and every load of handed-off bytes is an sc1 buffer load."""
     names = [n for n in kernels_isa if n.startswith("_Z12chain_kernel")]
-    assert len(names) == 4
+    assert len(names) == 6
     for n in names:
         ins = kernels_isa[n]
         sweeps = [l for l in ins if l.startswith("buffer_load_dwordx4")]

@@ -166,8 +166,9 @@ static int chain_variant_for(const zn_config& c) {
   auto fits = [&](int t_out, int t_fc1, int t_fc2, int t_in) {
     return p_out <= ZN_CH_CWAVES * t_out && p_fc1 <= ZN_CH_CWAVES * t_fc1 && p_out <= (ZN_CH_CWAVES / 4) * t_fc2 && p_in <= ZN_CH_CWAVES * t_in;
   };
-  if (c.d_model == 2048 && fits(1, 8, 4, 2) && chain_resident<4, 1, 8, 4, 2>(n_cus) && chain_resident<4, 1, 8, 4, 0>(n_cus)) return 1;
-  if (c.d_model == 512 && fits(1, 2, 1, 1) && chain_resident<1, 1, 2, 1, 1>(n_cus) && chain_resident<1, 1, 2, 1, 0>(n_cus)) return 2;
+  // the last block's launch ends with the fused heads (T_IN = 5 / 3 tiles per wave) when they fit its lanes, else after fc2 (T_IN = 0)
+  if (c.d_model == 2048 && fits(1, 8, 4, 2) && chain_resident<4, 1, 8, 4, 2>(n_cus) && chain_resident<4, 1, 8, 4, 0>(n_cus) && chain_resident<4, 1, 8, 4, 5>(n_cus)) return 1;
+  if (c.d_model == 512 && fits(1, 2, 1, 1) && chain_resident<1, 1, 2, 1, 1>(n_cus) && chain_resident<1, 1, 2, 1, 0>(n_cus) && chain_resident<1, 1, 2, 1, 5>(n_cus)) return 2;
   return 0;
 }
 
@@ -552,8 +553,15 @@ static bf16_t* chain_x(zn_handle h, int li) { return (li & 1) ? h->ch_x2 : h->x;
 
 // Post-attention chain of block `li` plus the in_proj of block li + 1 in ONE launch (zn_chain_kernel.h); x = h->x, the
 // attention output in h->o1, the next block's q in h->q.
+// Heads matrix rows per workgroup fit the chain's op-4 schedule (5 tiles per compute wave, one epilogue lane per (pair, row))?
+static bool chain_heads_fit(zn_handle h) {
+  const int units = (h->cfg.n_codebooks * h->cfg.vocab_head + 1) / 2, ppw = (units + ZN_CH_GRID - 1) / ZN_CH_GRID;
+  return ppw <= ZN_CH_CWAVES * 5 && ppw * 2 <= 64;
+}
+
+// with_heads: the last block's launch also applies norm_f + the fused heads (fp32 logits into h->logits_raw)
 static int launch_chain(zn_handle h, int li, const std::vector<const void*>& kv_layers, int max_len, const int* lengths, hipStream_t s,
-                        const bf16_t* xin = nullptr) {
+                        const bf16_t* xin = nullptr, bool with_heads = false) {
   const zn_config& c = h->cfg;
   const zn_layer_weights& lw = h->layers[li];
   const bool last = li + 1 >= c.n_layer;
@@ -571,12 +579,19 @@ static int launch_chain(zn_handle h, int li, const std::vector<const void*>& kv_
     a.q_out = h->q; a.kv = (bf16_t*)kv_layers[li + 1]; a.rope = h->rope; a.lengths = lengths;
     a.max_len = max_len; a.hd = h->hd; a.n_heads = c.n_heads; a.n_heads_kv = c.n_heads_kv; a.rope_positions = c.rope_positions;
   }
+  const bool heads = last && with_heads;
+  if (heads) {
+    a.W_in = (const bf16_t*)h->heads; a.lnn_w = (const bf16_t*)h->norm_f_w; a.lnn_b = (const bf16_t*)h->norm_f_b;
+    a.nqkv = c.n_codebooks * c.vocab_head; a.heads_out = h->logits_raw;
+  }
   const dim3 grid(ZN_CH_GRID), block(ZN_CH_THREADS);
   if (h->ch_variant == 1) {
-    if (last) hipLaunchKernelGGL((chain_kernel<4, 1, 8, 4, 0>), grid, block, ZN_CH_DYN_LDS, s, a);
+    if (heads) hipLaunchKernelGGL((chain_kernel<4, 1, 8, 4, 5>), grid, block, ZN_CH_DYN_LDS, s, a);
+    else if (last) hipLaunchKernelGGL((chain_kernel<4, 1, 8, 4, 0>), grid, block, ZN_CH_DYN_LDS, s, a);
     else hipLaunchKernelGGL((chain_kernel<4, 1, 8, 4, 2>), grid, block, ZN_CH_DYN_LDS, s, a);
   } else {
-    if (last) hipLaunchKernelGGL((chain_kernel<1, 1, 2, 1, 0>), grid, block, ZN_CH_DYN_LDS, s, a);
+    if (heads) hipLaunchKernelGGL((chain_kernel<1, 1, 2, 1, 5>), grid, block, ZN_CH_DYN_LDS, s, a);
+    else if (last) hipLaunchKernelGGL((chain_kernel<1, 1, 2, 1, 0>), grid, block, ZN_CH_DYN_LDS, s, a);
     else hipLaunchKernelGGL((chain_kernel<1, 1, 2, 1, 1>), grid, block, ZN_CH_DYN_LDS, s, a);
   }
   return ZN_OK;
@@ -584,7 +599,8 @@ static int launch_chain(zn_handle h, int li, const std::vector<const void*>& kv_
 
 // All blocks of one decode step on h->x (transformer): launches per op, or in_proj(0) + (attention, chain) per block.
 // x0 != NULL: the residual stream enters the first block from there (the decode step's embedding buffer) instead of h->x.
-static int decode_blocks(zn_handle h, const int* ext, int ext_scalar, hipStream_t s, const bf16_t* x0 = nullptr) {
+// heads_done != NULL: the caller wants the logits too; set when the last block's chain launch has produced them.
+static int decode_blocks(zn_handle h, const int* ext, int ext_scalar, hipStream_t s, const bf16_t* x0 = nullptr, bool* heads_done = nullptr) {
   const zn_config& c = h->cfg;
   int rc;
   const size_t tb = (size_t)h->rows * c.d_model * 2;
@@ -616,7 +632,9 @@ static int decode_blocks(zn_handle h, const int* ext, int ext_scalar, hipStream_
     trace_q(li);
     if ((rc = run_attention(h, h->q, (bf16_t*)h->kv_layers[li], h->max_len, h->lengths, ext, ext_scalar, h->o1, h->rows, s,
                             h->ch_stamps ? h->ch_stamps + (size_t)(c.n_layer + li) * 32 : nullptr))) return rc;
-    if ((rc = launch_chain(h, li, h->kv_layers, h->max_len, h->lengths, s, li == 0 ? x0 : nullptr))) return rc;
+    const bool wh = heads_done && li + 1 == c.n_layer && chain_heads_fit(h);
+    if ((rc = launch_chain(h, li, h->kv_layers, h->max_len, h->lengths, s, li == 0 ? x0 : nullptr, wh))) return rc;
+    if (wh) *heads_done = true;
     trace(li);
   }
   if (c.n_layer & 1) HIPCHK(h, hipMemcpyAsync(h->x, h->ch_x2, tb, hipMemcpyDeviceToDevice, s));   // odd depth: the stream ends in the second buffer
@@ -786,8 +804,9 @@ static int enqueue_step(zn_handle h, hipStream_t s) {
   if (c.arch == 1) {
     if ((rc = hybrid_token(h, true, s))) return rc;
   } else {
-    if ((rc = decode_blocks(h, nullptr, 0, s, fused ? h->x_emb : nullptr))) return rc;
-    if ((rc = heads_logits(h, h->x, h->rows, s))) return rc;
+    bool heads_done = false;
+    if ((rc = decode_blocks(h, nullptr, 0, s, fused ? h->x_emb : nullptr, &heads_done))) return rc;
+    if (!heads_done && (rc = heads_logits(h, h->x, h->rows, s))) return rc;
   }
   SampleArgs a = make_sample_args(h, h->sp);
   a.raw = h->logits_raw; a.mix = 1; a.cfg_scale = h->cfg_scale; a.apply_bias = 1; a.batch = h->batch;

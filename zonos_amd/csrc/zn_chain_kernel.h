@@ -5,6 +5,7 @@
 //   op 2  m  = y * silu(gate), (y, gate) = fc1(LayerNorm2(x))  (_torch.py:327, 473-474)
 //   op 3  x  = x + fc2(m)
 //   op 4  q | k | v = in_proj(LayerNorm1'(x)) of the NEXT block, RoPE, KV append   (_torch.py:399-408, 105-106)
+//         (last block: logits = heads(norm_f(x)), model.py:139-141, instead)
 //
 // As five launches these cost ~3.3 us of fixed time each (boundary + ramp until the first weights arrive) on top of
 // their streaming time; here one workgroup per CU stays resident for the whole chain: its 4 compute waves walk a STATIC
@@ -38,7 +39,8 @@ struct ChainArgs {
   const bf16_t *W_out, *W_fc1, *W_fc2, *W_in;              // W_in = next block's in_proj (NULL: the chain ends after fc2)
   const bf16_t *ln2_w, *ln2_b, *lnn_w, *lnn_b;             // this block's norm2, next block's norm
   float eps;
-  int F, nqkv;                                             // d_ff (= 4 d_model), rows of the next in_proj
+  int F, nqkv;                                             // d_ff (= 4 d_model), rows of the next in_proj (or of the heads matrix)
+  float* heads_out;                                        // != NULL: op 4 = final LayerNorm + fused heads of the LAST block, fp32 logits [2][nqkv] (W_in = heads, lnn_* = norm_f)
   const bf16_t* a;                                         // [2][d] attention output
   // No handed-off address is written twice inside a launch, nor read before it is written there (the residual stream enters
   // through one buffer and leaves through another): every sweep then either sees this launch's tag or an older launch's.
@@ -122,7 +124,8 @@ __global__ __launch_bounds__(ZN_CH_THREADS) void chain_kernel(ChainArgs a) {
   const int F = a.F;
   const unsigned tag = *a.epoch;
   // units (weight-row pairs) per workgroup and op
-  const int ppw_out = (D / 2) / G, ppw_fc1 = F / G, ppw_fc2 = (D / 2) / G, ppw_in = T_IN > 0 ? (a.nqkv / 2) / G : 0;
+  const int units_in = (a.nqkv + 1) / 2;                  // row pairs of op 4 (the heads matrix has an odd row count: its last pair is half)
+  const int ppw_out = (D / 2) / G, ppw_fc1 = F / G, ppw_fc2 = (D / 2) / G, ppw_in = T_IN > 0 ? (units_in + G - 1) / G : 0;
   __shared__ __attribute__((aligned(16))) bf16_t s_act[R * D];              // the current op's input vector (ops 0, 1, 2, 4)
   __shared__ float s_res[2][64][2][R];                                      // per-unit results of even / odd ops (fc2: [unit * 4 + quarter])
 
@@ -148,12 +151,12 @@ __global__ __launch_bounds__(ZN_CH_THREADS) void chain_kernel(ChainArgs a) {
       }
       const int j = wave + CW * t;
       const int ppw = op <= 1 ? ppw_out : op == 2 ? ppw_fc1 : ppw_in;
-      ok = j < ppw;
+      ok = j < ppw && (op < 4 || c * ppw + j < units_in);
       const int u = c * ppw + (ok ? j : 0);
       ridx = j;
       if (op <= 1) { pa = a.W_out + (size_t)(2 * u) * D + lane * 8; pb = pa + D; }
       else if (op == 2) { pa = a.W_fc1 + (size_t)u * D + lane * 8; pb = pa + (size_t)F * D; }
-      else { pa = a.W_in + (size_t)(2 * u) * D + lane * 8; pb = pa + D; }
+      else { pa = a.W_in + (size_t)(2 * u) * D + lane * 8; pb = (2 * u + 1 < a.nqkv) ? pa + D : pa; }   // half pair: row B repeats row A, result dropped
     };
     auto load = [&](int s, WT& w) {
       bool ok; const bf16_t *pa, *pb; int ridx;
@@ -269,11 +272,11 @@ __global__ __launch_bounds__(ZN_CH_THREADS) void chain_kernel(ChainArgs a) {
   const int u_out = c * ppw_out + (it_out ? ij : 0);
   unsigned resid = 0;
   if (it_out) resid = *(const unsigned*)(a.xin + (size_t)ir * D + 2 * u_out);
-  const bool it_in = epi && T_IN > 0 && ij < ppw_in;
+  const bool it_in = epi && T_IN > 0 && ij < ppw_in && c * ppw_in + ij < units_in;
   const int u_in = c * ppw_in + (it_in ? ij : 0);
   int pos = 0; float cs = 1.f, sn = 0.f;
   if constexpr (T_IN > 0) {
-    if (it_in) {
+    if (it_in && !a.heads_out) {
       pos = a.lengths[ir];
       const int rowA = 2 * u_in;
       if (rowA < (a.n_heads + a.n_heads_kv) * a.hd) {
@@ -328,8 +331,11 @@ __global__ __launch_bounds__(ZN_CH_THREADS) void chain_kernel(ChainArgs a) {
         if constexpr (NOPS == 5) st_granule(a.g_x2 + (size_t)ir * (D / 2) + u_out, tag, o);
         *(unsigned*)(a.xout + (size_t)ir * D + 2 * u_out) = o;              // the plain copy later launches read
       }
-    } else {                                               // EPI_ROPE_KV of the next block (read by the next launch)
-      if (it_in) {
+    } else {                                               // EPI_ROPE_KV of the next block (read by the next launch), or the logits
+      if (it_in && a.heads_out) {                          // EPI_F32 (gemv_epilogue): bf16-valued fp32
+        a.heads_out[(size_t)ir * a.nqkv + 2 * u_in] = bfround(s_res[par][ij][0][ir]);
+        if (2 * u_in + 1 < a.nqkv) a.heads_out[(size_t)ir * a.nqkv + 2 * u_in + 1] = bfround(s_res[par][ij][1][ir]);
+      } else if (it_in) {
         GemvArgs ga{};
         ga.hd = a.hd; ga.n_heads = a.n_heads; ga.n_heads_kv = a.n_heads_kv; ga.q_out = a.q_out; ga.kv = a.kv; ga.max_len = a.max_len;
         gemv_epilogue<EPI_ROPE_KV>(ga, ir, 2 * u_in, 2 * u_in + 1, true, u_in, s_res[par][ij][0][ir], s_res[par][ij][1][ir], 0u, cs, sn, pos);
