@@ -86,3 +86,30 @@ def test_chain_is_bit_identical_to_the_launches_path(which):
         assert same > 0.98 and worst <= 0.04
     a2, la2, _ = _run(model, cond, n, chain=True)           # replay: no state survives a generation (counters, timeout word)
     assert torch.equal(a, a2) and torch.equal(la.view(torch.int32), la2.view(torch.int32))
+
+
+def test_whole_step_kernel_is_bit_identical_to_the_chain_path():
+    """The opt-in whole-step kernel (csrc/zn_stack_kernel.h: the attention as an op of the persistent chain, every block of the
+    decode step in ONE launch; zn_debug_tune(15, 3)) against the default path (attention launch + chain launch per block) at the
+    Zonos-v0.1-transformer dimensions: free-running greedy codes equal and the logits of every step bit-equal, over single-step
+    launches (teacher-free trace mode, 40 steps) and over 8-step graphs (300 steps: contexts 26 .. 333)."""
+    cfg, seed = synth.FULL_CFG, 1234
+    model, _ = build_model(cfg, seed, "cuda:0")
+    eng = model.engine(1)
+    cond = synth.conditioning(seed, "cond", 2, 24, cfg["d_model"])
+    try:
+        eng.call("zn_debug_tune", 15, 1)
+        a, la, pa = _run(model, cond, 40)
+        eng.call("zn_debug_tune", 15, 3)
+        b, lb, pb = _run(model, cond, 40)
+        assert torch.equal(a, b)
+        assert torch.equal(la.view(torch.int32), lb.view(torch.int32))
+        eng.call("zn_debug_eos_bias", float("-inf"))
+        outs = []
+        for t15 in (1, 3):
+            eng.call("zn_debug_tune", 15, t15)
+            outs.append(model.generate(cond.to("cuda:0"), max_new_tokens=300, sampling_params=GREEDY).cpu())
+        assert torch.equal(outs[0], outs[1])
+    finally:
+        eng.call("zn_debug_tune", 15, 1)
+        eng.call("zn_debug_eos_bias", 0.0)

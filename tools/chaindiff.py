@@ -23,8 +23,14 @@ trace = torch.zeros(NL, 8, 2, CFG["d_model"], dtype=torch.bfloat16, device="cuda
 eng.call("zn_debug_trace", trace.data_ptr())
 
 
+STACK = os.environ.get("ZN_DIFF_STACK") == "1"        # compare the whole-step kernel with the chain path instead
+
+
 def run(chain):
-    eng.call("zn_debug_tune", 8, 1 if chain else 2)
+    if STACK:
+        eng.call("zn_debug_tune", 15, 3 if chain else 1)
+    else:
+        eng.call("zn_debug_tune", 8, 1 if chain else 2)
     eng.call("zn_debug_tune", 6, 1)
     tr = {"logits": [], "traces": []}
     tr["after_step"] = lambda step_idx, delayed, col: tr["traces"].append(trace.clone()) if step_idx >= 0 else None
@@ -42,7 +48,7 @@ for k in range(len(ta)):
     if bool(d.any()):
         print(f"decode step {k} (call {k + 1}): first differing trace entries:")
         for li in range(NL):
-            for which, nm in ((2, "q"), (1, "attention out"), (7, "x after attention half"), (3, "m"), (0, "x after block")):
+            for which, nm in (((2, "q"), (1, "attention out"), (0, "x after block")) if STACK else ((2, "q"), (1, "attention out"), (7, "x after attention half"), (3, "m"), (0, "x after block"))):
                 dd = d[li, 3:7].reshape(2, -1) if which == 3 else d[li, which]
                 if bool(dd.any()):
                     idx = dd.nonzero()
@@ -50,6 +56,7 @@ for k in range(len(ta)):
                     print(f"  layer {li} {nm}: {int(dd.sum())} elements differ; first at row {r} feature {f}: launches {float((ta[k][li, 3:7].reshape(2, -1) if which == 3 else ta[k][li, which])[r, f]):.6g} chain {float((tb[k][li, 3:7].reshape(2, -1) if which == 3 else tb[k][li, which])[r, f]):.6g}")
                     if int(dd.sum()) < 12:
                         print("     all:", [(int(i[0]), int(i[1])) for i in idx])
-            if bool(d[li].any()) and li >= 2 + min(l for l in range(NL) if bool(d[l].any())):
+            if not STACK and bool(d[li].any()) and li >= 2 + min(l for l in range(NL) if bool(d[l].any())):
                 break
-        break
+        if not STACK or k >= 2:
+            break

@@ -1,0 +1,32 @@
+"""ms per decode step and the in-kernel timeline of block 13 of the whole-step kernel (workgroup 0's first communication wave).
+    python tools/stacksweep.py [new_tokens]"""
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from zonos_amd import synth  # noqa: E402
+from zonos_amd.testing import build_model  # noqa: E402
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 400
+model, _ = build_model(synth.FULL_CFG, 1234, "cuda:0")
+eng = model.engine(1)
+eng.call("zn_debug_eos_bias", float("-inf"))
+eng.call("zn_debug_tune", 15, 3)
+cond = synth.conditioning(1234, "cond", 2, 24, 2048).to("cuda:0")
+stamps = torch.zeros(52, 32, dtype=torch.int64, device="cuda:0")
+eng.call("zn_debug_chain_stamps", stamps.data_ptr())
+best = 1e9
+for _ in range(3):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out = model.generate(cond, max_new_tokens=n, sampling_params={"temperature": 0.0})
+    torch.cuda.synchronize()
+    best = min(best, time.perf_counter() - t0)
+st = stamps.cpu().numpy()[0]
+names = ["block start", "attn inputs", "scores", "attn result", "a swept = op0 in",
+         "o1 res", "o1 pub", "o1 swept", "o1 next", "o2 res", "o2 pub", "o2 swept", "o2 next", "f1 res", "f1 pub", "f1 -", "f1 next",
+         "f2 res", "f2 pub", "f2 swept", "f2 next", "ip res", "end"]
+print(f"stack: {best * 1e3 / (n + 8):.4f} ms/step, checksum {int(out.sum())}; block 13: " + " ".join(f"{nm}={(st[i] - st[0]) / 100.0:.2f}" for i, nm in enumerate(names)))

@@ -3,6 +3,7 @@
 #include "../../include/zonos_hip.h"
 #include "zn_decode_kernels.h"
 #include "zn_chain_kernel.h"
+#include "zn_stack_kernel.h"
 #include "zn_prefill_kernels.h"
 #include "zn_cond_kernels.h"
 #include "zn_mamba_kernels.h"
@@ -37,6 +38,9 @@ struct zn_handle_s {
   // persistent post-attention chain (zn_chain_kernel.h): granule buffers of the four in-launch hand-offs ([rows][len / 2] x 8 B),
   // the launch epoch (tag), the second residual-stream buffer (blocks alternate h->x / ch_x2)
   unsigned long long *ch_gy1 = nullptr, *ch_gx1 = nullptr, *ch_gx2 = nullptr, *ch_gm = nullptr;
+  unsigned long long *ch_gqkv = nullptr, *ch_ga = nullptr;   // whole-step kernel: q | k | v of the next block, attention output
+  StackLayer* stack_layers = nullptr;        // device table [n_layer], rebuilt by zn_gen_begin (it holds the KV cache pointers)
+  bool use_stack = false, stack_ok = false, stack_checked = false;                    // the steps being enqueued run the whole-step kernel
   unsigned* ch_epoch = nullptr;
   bf16_t* ch_x2 = nullptr;
   bf16_t* dbg_trace = nullptr;               // diagnostic: [n_layer][2][rows * d] copies of (x after the block, attention output) per decode step
@@ -82,9 +86,9 @@ struct zn_handle_s {
   hipStream_t cap_stream = nullptr;
   // captured decode steps per attention launch shape (k & 1: 1 = fused single launch, 0 = two passes) and per length
   // (k >> 1: 0 = one step, 1 = ZN_GRAPH_STEPS consecutive steps: fewer graph launches on the chain)
-  hipGraphExec_t graph_exec[4] = {nullptr, nullptr, nullptr, nullptr};
-  hipGraph_t graph[4] = {nullptr, nullptr, nullptr, nullptr};
-  bool graph_tried[4] = {false, false, false, false};
+  hipGraphExec_t graph_exec[8] = {};
+  hipGraph_t graph[8] = {};
+  bool graph_tried[8] = {};
   int len_hi = 0;            // host-side upper bound of the rows' KV lengths (keys already cached)
   bool attn_fused = false;   // launch shape of the next run_attention
   std::string err;
@@ -122,7 +126,7 @@ extern "C" size_t zn_mamba_state_bytes_per_layer(const zn_config* c, int32_t row
 }
 
 static void free_graph(zn_handle h) {
-  for (int k = 0; k < 4; ++k) {
+  for (int k = 0; k < 8; ++k) {
     if (h->graph_exec[k]) { (void)hipGraphExecDestroy(h->graph_exec[k]); h->graph_exec[k] = nullptr; }
     if (h->graph[k]) { (void)hipGraphDestroy(h->graph[k]); h->graph[k] = nullptr; }
     h->graph_tried[k] = false;
@@ -132,7 +136,7 @@ static void free_graph(zn_handle h) {
 extern "C" int zn_destroy(zn_handle h) {
   if (!h) return ZN_OK;
   free_graph(h);
-  void* ptrs[] = {h->emb_tables_dev, h->x, h->q, h->o1, h->mbuf, h->nbuf, h->logits_raw, h->last_logits, h->tok_raw, h->scores, h->cmax, h->pv_part, h->pv_tickets, h->pf_x, h->pf_n, h->pf_qkv, h->pf_a, h->pf_u, h->pf_m, h->pf_res, h->pf_zx, h->pf_xbc, h->pf_y, h->pf_g, h->qkv_tmp, h->fw_lengths, h->st, h->remaining, h->stopping, h->res, h->hn, h->m_zx, h->m_xbc, h->m_y, h->m_g, h->m_vg, h->g16_part, h->g16_tickets, h->ch_gy1, h->ch_gx1, h->ch_gx2, h->ch_gm, h->ch_epoch, h->ch_x2, h->x_emb, h->tail_ticket};
+  void* ptrs[] = {h->emb_tables_dev, h->x, h->q, h->o1, h->mbuf, h->nbuf, h->logits_raw, h->last_logits, h->tok_raw, h->scores, h->cmax, h->pv_part, h->pv_tickets, h->pf_x, h->pf_n, h->pf_qkv, h->pf_a, h->pf_u, h->pf_m, h->pf_res, h->pf_zx, h->pf_xbc, h->pf_y, h->pf_g, h->qkv_tmp, h->fw_lengths, h->st, h->remaining, h->stopping, h->res, h->hn, h->m_zx, h->m_xbc, h->m_y, h->m_g, h->m_vg, h->g16_part, h->g16_tickets, h->ch_gy1, h->ch_gx1, h->ch_gx2, h->ch_gm, h->ch_epoch, h->ch_x2, h->x_emb, h->tail_ticket, h->ch_gqkv, h->ch_ga, h->stack_layers};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (h->done_host) (void)hipHostFree(h->done_host);
   if (h->stop_event) (void)hipEventDestroy(h->stop_event);
@@ -229,6 +233,10 @@ extern "C" int zn_create(const zn_config* cfg, const zn_weights* w, int32_t max_
     ZC(hipMalloc(g, R * (c.d_model / 2) * 8));
     ZC(hipMemset(*g, 0, R * (c.d_model / 2) * 8));             // tag 0 is never a launch's epoch
   }
+  { const size_t nqkv = (size_t)(c.n_heads + 2 * c.n_heads_kv) * hd;
+    ZC(hipMalloc(&h->ch_gqkv, R * (nqkv / 2 + 1) * 8)); ZC(hipMemset(h->ch_gqkv, 0, R * (nqkv / 2 + 1) * 8));
+    ZC(hipMalloc(&h->ch_ga, R * (c.d_model / 2) * 8)); ZC(hipMemset(h->ch_ga, 0, R * (c.d_model / 2) * 8));
+    ZC(hipMalloc(&h->stack_layers, (size_t)c.n_layer * sizeof(StackLayer))); }
   ZC(hipMalloc(&h->ch_gm, R * (c.d_ff / 2 + 1) * 8));
   ZC(hipMemset(h->ch_gm, 0, R * (c.d_ff / 2 + 1) * 8));
   ZC(hipMalloc(&h->ch_epoch, 64));
@@ -236,6 +244,7 @@ extern "C" int zn_create(const zn_config* cfg, const zn_weights* w, int32_t max_
   ZC(hipMalloc(&h->ch_x2, R * c.d_model * 2));
   h->ch_variant = chain_variant_for(c);
   if (const char* e = getenv("ZN_CHAIN")) if (atoi(e) == 0) h->tune[8] = 2;
+  if (const char* e = getenv("ZN_STACK")) if (atoi(e) == 1) h->tune[15] = 3;
   {   // split-K partial tiles + tickets of the small-M projections (batches of 3..8 utterances; short-prompt prefill at any batch)
     ZC(hipMalloc(&h->x_emb, R * c.d_model * 2));
     ZC(hipMalloc(&h->tail_ticket, sizeof(int)));
@@ -597,6 +606,56 @@ static int launch_chain(zn_handle h, int li, const std::vector<const void*>& kv_
   return ZN_OK;
 }
 
+// Whole-step kernel (zn_stack_kernel.h): batch 1 at the Zonos-v0.1 shapes, contexts up to ZN_ST_MAXKEYS keys.  Opt-in for now:
+// zn_debug_tune(15, 3) or ZN_STACK=1 in the environment at zn_create.
+static bool stack_shapes_ok(zn_handle h) {
+  const zn_config& c = h->cfg;
+  if (h->ch_variant != 1 || h->hd != 128 || c.n_heads_kv < 1 || c.n_heads != 4 * c.n_heads_kv) return false;
+  const int natt = 2 * c.n_heads_kv * (h->hd / 32);
+  if (natt > ZN_CH_GRID || !chain_heads_fit(h)) return false;
+  int per_cu = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, stack_kernel<4, 1, 8, 4, 5>, ZN_CH_THREADS, ZN_CH_DYN_LDS) != hipSuccess) { (void)hipGetLastError(); return false; }
+  return per_cu >= 1;
+}
+static bool stack_active(zn_handle h, int rows, int keys_upper_bound) {
+  return chain_active(h, rows) && h->tune[15] == 3 && keys_upper_bound <= ZN_ST_MAXKEYS && h->stack_ok;
+}
+static int launch_stack(zn_handle h, hipStream_t s) {
+  const zn_config& c = h->cfg;
+  ChainArgs a{};
+  a.eps = c.norm_eps; a.F = c.d_ff; a.nqkv = (c.n_heads + 2 * c.n_heads_kv) * h->hd;
+  a.xin = h->x_emb; a.xout = h->x;
+  a.g_y1 = h->ch_gy1; a.g_x1 = h->ch_gx1; a.g_x2 = h->ch_gx2; a.g_m = h->ch_gm; a.g_qkv = h->ch_gqkv; a.g_a = h->ch_ga;
+  a.epoch = h->ch_epoch; a.tmo = &h->st->pad[0];
+  a.stamps = h->ch_stamps; a.stamp_layer = c.n_layer / 2;
+  a.rope = h->rope; a.lengths = h->lengths; a.max_len = h->max_len; a.hd = h->hd; a.n_heads = c.n_heads; a.n_heads_kv = c.n_heads_kv;
+  a.rope_positions = c.rope_positions;
+  a.layers = h->stack_layers; a.n_layer = c.n_layer; a.q0 = h->q; a.scale = (float)(1.0 / std::sqrt((double)h->hd));
+  a.heads_rows = c.n_codebooks * c.vocab_head; a.heads_out = h->logits_raw; a.trace = h->dbg_trace;
+  hipLaunchKernelGGL((stack_kernel<4, 1, 8, 4, 5>), dim3(ZN_CH_GRID), dim3(ZN_CH_THREADS), ZN_CH_DYN_LDS, s, a);
+  return ZN_OK;
+}
+// device table of the whole-step kernel (KV cache pointers of this generation)
+static int build_stack_table(zn_handle h) {
+  const zn_config& c = h->cfg;
+  std::vector<StackLayer> t(c.n_layer);
+  for (int li = 0; li < c.n_layer; ++li) {
+    const zn_layer_weights& lw = h->layers[li];
+    const bool last = li + 1 == c.n_layer;
+    StackLayer& L = t[li];
+    L.W_out = (const bf16_t*)lw.out_proj; L.W_fc1 = (const bf16_t*)lw.fc1; L.W_fc2 = (const bf16_t*)lw.fc2;
+    L.ln2_w = (const bf16_t*)lw.norm2_w; L.ln2_b = (const bf16_t*)lw.norm2_b;
+    L.kv = (const bf16_t*)h->kv_layers[li];
+    if (last) { L.W_in = (const bf16_t*)h->heads; L.lnn_w = (const bf16_t*)h->norm_f_w; L.lnn_b = (const bf16_t*)h->norm_f_b; L.kv_next = nullptr; }
+    else {
+      const zn_layer_weights& nx = h->layers[li + 1];
+      L.W_in = (const bf16_t*)nx.in_proj; L.lnn_w = (const bf16_t*)nx.norm_w; L.lnn_b = (const bf16_t*)nx.norm_b; L.kv_next = (bf16_t*)h->kv_layers[li + 1];
+    }
+  }
+  HIPCHK(h, hipMemcpy(h->stack_layers, t.data(), t.size() * sizeof(StackLayer), hipMemcpyHostToDevice));
+  return ZN_OK;
+}
+
 // All blocks of one decode step on h->x (transformer): launches per op, or in_proj(0) + (attention, chain) per block.
 // x0 != NULL: the residual stream enters the first block from there (the decode step's embedding buffer) instead of h->x.
 // heads_done != NULL: the caller wants the logits too; set when the last block's chain launch has produced them.
@@ -805,7 +864,11 @@ static int enqueue_step(zn_handle h, hipStream_t s) {
     if ((rc = hybrid_token(h, true, s))) return rc;
   } else {
     bool heads_done = false;
-    if ((rc = decode_blocks(h, nullptr, 0, s, fused ? h->x_emb : nullptr, &heads_done))) return rc;
+    if (h->use_stack) {                                    // in_proj of block 0, then every block + the heads in one launch
+      if ((rc = layer_in_proj(h, 0, h->x_emb, (bf16_t*)h->kv_layers[0], h->max_len, h->lengths, h->rows, s))) return rc;
+      if ((rc = launch_stack(h, s))) return rc;
+      heads_done = true;
+    } else if ((rc = decode_blocks(h, nullptr, 0, s, fused ? h->x_emb : nullptr, &heads_done))) return rc;
     if (!heads_done && (rc = heads_logits(h, h->x, h->rows, s))) return rc;
   }
   SampleArgs a = make_sample_args(h, h->sp);
@@ -844,6 +907,10 @@ extern "C" int zn_gen_begin(zn_handle h, int32_t batch, const void* const* kv_la
   h->cfg_scale = cfg_scale; h->sp = *sp;
   h->kv_layers.assign(kv_layers_dev, kv_layers_dev + h->cfg.n_layer);
   h->lengths = lengths_dev; h->codes = delayed_codes_dev;
+  if (h->cfg.arch == 0 && h->ch_variant == 1) {
+    if (!h->stack_checked) { h->stack_ok = stack_shapes_ok(h); h->stack_checked = true; }
+    if (h->stack_ok) { int rc = build_stack_table(h); if (rc) return rc; }
+  }
   GenState st{};
   st.offset = offset0; st.step = 0; st.all_done = 0; st.force_eos_step = h->force_eos_step; st.eos_bias = h->eos_bias;
   HIPCHK(h, hipMemcpyAsync(h->st, &st, sizeof st, hipMemcpyHostToDevice, s));
@@ -1135,8 +1202,9 @@ extern "C" int zn_decode_steps(zn_handle h, int32_t n, zn_stream stream) {
     // this step appends one key per row; a run of ZN_GRAPH_STEPS steps with one launch shape replays the long graph
     const bool fused = attn_fused_for(h, h->len_hi + 1);
     const int run = (n - i >= ZN_GRAPH_STEPS && h->tune[6] > 1 && attn_fused_for(h, h->len_hi + ZN_GRAPH_STEPS) == fused) ? ZN_GRAPH_STEPS : 1;
-    const int k = (fused ? 1 : 0) | (run > 1 ? 2 : 0);
-    h->attn_fused = fused;
+    const bool stack = tail_fused(h) && stack_active(h, h->rows, h->len_hi + run);
+    const int k = (fused ? 1 : 0) | (run > 1 ? 2 : 0) | (stack ? 4 : 0);
+    h->attn_fused = fused; h->use_stack = stack;
     if (!h->graph_exec[k] && !h->graph_tried[k] && n > 1) {
       // capture; every step-varying quantity (column, positions) is read from device memory
       h->graph_tried[k] = true;
@@ -1161,7 +1229,11 @@ extern "C" int zn_decode_steps(zn_handle h, int32_t n, zn_stream stream) {
 }
 
 extern "C" int zn_decode_path(zn_handle h) { return (h && h->gen_active && h->cfg.arch == 0 && chain_active(h, h->rows)) ? 1 : 0; }
-extern "C" int zn_graph_active(zn_handle h) { return (h && (h->graph_exec[0] || h->graph_exec[1] || h->graph_exec[2] || h->graph_exec[3])) ? 1 : 0; }
+extern "C" int zn_graph_active(zn_handle h) {
+  if (!h) return 0;
+  for (int k = 0; k < 8; ++k) if (h->graph_exec[k]) return 1;
+  return 0;
+}
 
 extern "C" int zn_all_stopped(zn_handle h, int32_t* out, zn_stream stream) {
   if (!h || !out) return ZN_ERR_ARG;

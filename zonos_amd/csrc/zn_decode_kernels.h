@@ -70,6 +70,16 @@ ZN_DEVINL float mamba_conv_channel(unsigned& s0, unsigned& s1, unsigned w0, unsi
   return acc / (1.0f + expf(-acc));
 }
 
+// Interleaved-pair rotation in fp32 (_torch.py:57-68): four products and two sums, each rounded on its own.  HIP's __fmul_rn /
+// __fadd_rn are plain operators, which the compiler may fuse into an fma differently from kernel to kernel (it did: one q value
+// in ~10^5 differed by an ulp between two kernels inlining the same expression); contraction is switched off here instead.
+ZN_DEVINL void zn_rope_pair(float x0, float x1, float cs, float sn, float& re, float& im) {
+#pragma clang fp contract(off)
+  const float a = x0 * cs, b = x1 * sn, c = x1 * cs, d = x0 * sn;
+  re = a - b;
+  im = c + d;
+}
+
 // Fused epilogues shared by the GEMV (rows <= 4) and the small-M MFMA kernel (rows <= 16): finishes activation row r
 // for the weight-row pair (rowA, rowB) of work unit u.
 template <int EPI>
@@ -110,8 +120,8 @@ ZN_DEVINL void gemv_epilogue(const GemvArgs& a, int r, int rowA, int rowB, bool 
     const int hd = a.hd, nq = a.n_heads * hd, nk = a.n_heads_kv * hd;
     const float x0 = bfround(vA), x1 = bfround(vB);
     if (rowA < nq + nk) {
-      const float re = __fsub_rn(__fmul_rn(x0, cs), __fmul_rn(x1, sn));
-      const float im = __fadd_rn(__fmul_rn(x1, cs), __fmul_rn(x0, sn));
+      float re, im;
+      zn_rope_pair(x0, x1, cs, sn, re, im);
       if (rowA < nq) *(unsigned*)(a.q_out + (size_t)r * nq + rowA) = pack2(re, im);
       else if (pos < a.max_len)
         *(unsigned*)(a.kv + (((size_t)r * a.max_len + pos) * 2 + 0) * nk + (rowA - nq)) = pack2(re, im);

@@ -303,7 +303,9 @@ __global__ __launch_bounds__(256) void rope_kv_rows_kernel(bf16_t* qkv, bf16_t* 
     if (n < nq + nk) {
       const int i = (n % hd) >> 1;
       const float cs = rope[((size_t)p * (hd >> 1) + i) * 2], sn = rope[((size_t)p * (hd >> 1) + i) * 2 + 1];
-      const unsigned o = pack2(__fsub_rn(__fmul_rn(x0, cs), __fmul_rn(x1, sn)), __fadd_rn(__fmul_rn(x1, cs), __fmul_rn(x0, sn)));
+      float re, im;
+      zn_rope_pair(x0, x1, cs, sn, re, im);
+      const unsigned o = pack2(re, im);
       if (n < nq) *(unsigned*)(row + n) = o;
       else if (pos < max_len) *(unsigned*)(kv + (((size_t)r * max_len + pos) * 2 + 0) * nk + (n - nq)) = o;
     } else if (pos < max_len) {
@@ -335,8 +337,7 @@ __global__ __launch_bounds__(256) void rope_kv_any_kernel(const bf16_t* qkv, bf1
       float o0 = x0, o1 = x1;
       if (mode != 2) {
         const float cs = rope[((size_t)p * hh + i) * 2], sn = rope[((size_t)p * hh + i) * 2 + 1];
-        o0 = __fsub_rn(__fmul_rn(x0, cs), __fmul_rn(x1, sn));
-        o1 = __fadd_rn(__fmul_rn(x1, cs), __fmul_rn(x0, sn));
+        zn_rope_pair(x0, x1, cs, sn, o0, o1);
       }
       if (e0 < nq) { qrow[e0] = f2bf(o0); qrow[e1] = f2bf(o1); }
       else if (in_cache) { krow[e0 - nq] = f2bf(o0); krow[e1 - nq] = f2bf(o1); }
