@@ -25,8 +25,11 @@ for _ in range(3):
     out = model.generate(cond, max_new_tokens=n, sampling_params={"temperature": 0.0})
     torch.cuda.synchronize()
     best = min(best, time.perf_counter() - t0)
+at = stamps.cpu().numpy()[1]
 st = stamps.cpu().numpy()[0]
 names = ["block start", "attn inputs", "scores", "attn result", "a swept = op0 in",
          "o1 res", "o1 pub", "o1 swept", "o1 next", "o2 res", "o2 pub", "o2 swept", "o2 next", "f1 res", "f1 pub", "f1 -", "f1 next",
          "f2 res", "f2 pub", "f2 swept", "f2 next", "ip res", "end"]
+an = ["entry", "q frags", "sc b0", "sc b1", "sc b2", "sc b3", "A2", "pv b0", "pv b1", "pv b2", "pv b3", "reduced", "A3", "end"]
+print("attention (compute wave 0 of workgroup 0, us after block start): " + " ".join(f"{nm}={(at[i] - st[0]) / 100.0:.2f}" for i, nm in enumerate(an) if at[i] > 0))
 print(f"stack: {best * 1e3 / (n + 8):.4f} ms/step, checksum {int(out.sum())}; block 13: " + " ".join(f"{nm}={(st[i] - st[0]) / 100.0:.2f}" for i, nm in enumerate(names)))

@@ -181,7 +181,9 @@ ZN_DEVINL void stack_attn_issue_k_tile(u32x4 (&kk)[4], const bf16_t* kv, int r, 
 // each tile's registers with the next batch's tile as soon as the tile is staged in LDS, and the same batches (virtual wave outer,
 // block inner) for pass 2 with the next batch's value pieces in flight: one set of K registers, two of V.
 ZN_DEVINL void stack_attention(StackAttnLds& S, u32x4 (&kk)[4][4], u32x4 (&vvA)[4], const bf16_t* kv, int r, int kvh, int slice, int L,
-                               int max_len, int n_heads_kv, float scale, int rw, int lane) {
+                               int max_len, int n_heads_kv, float scale, int rw, int lane, unsigned long long* st = nullptr) {
+  auto stamp = [&](int i) { if (st && rw == 0 && lane == 0) st[i] = __builtin_amdgcn_s_memrealtime(); };
+  stamp(0);
   constexpr int HD = 128, G = 4, NW = 8, NR = 4, KST = HD / 32, TPW = 4;
   constexpr int KLD = HD + 8, LPK = HD / 8, KPL = 64 / LPK, NLD = 16 / KPL;
   typedef __attribute__((ext_vector_type(4))) float f32x4_t;
@@ -197,6 +199,7 @@ ZN_DEVINL void stack_attention(StackAttnLds& S, u32x4 (&kk)[4][4], u32x4 (&vvA)[
   }
   bf16_t* kw = &S.k[rw][0];
   const u32x4 knew_piece = *(const u32x4*)&S.knew[kd * 8];
+  stamp(1);
   // ---- scores, batch by batch
 #pragma unroll 1
   for (int b = 0; b < 2 * nb; ++b) {
@@ -240,8 +243,10 @@ ZN_DEVINL void stack_attention(StackAttnLds& S, u32x4 (&kk)[4][4], u32x4 (&vvA)[
       const float m = wave_max(kg == g / 4 ? mx[g % 4] : -INFINITY);
       if (lane == 0) S.bm[j][vw][g] = m;
     }
+    stamp(2 + (b < 4 ? b : 3));
   }
   __syncthreads();                                          // A2: every score and block maximum is in LDS
+  stamp(6);
   // ---- pass 2: virtual wave outer, block inner; batch c = v2 * nb + j
   const int vsub = lane & 3, vkey = lane >> 2, row = lane >> 4;
   const u32x4 vnew_piece = *(const u32x4*)&S.vnew[slice * 32 + vsub * 8];
@@ -338,8 +343,11 @@ ZN_DEVINL void stack_attention(StackAttnLds& S, u32x4 (&kk)[4][4], u32x4 (&vvA)[
       float l3 = row_stride4_sum(lsum); l3 = (readlane_f(l3, 3) + readlane_f(l3, 19)) + (readlane_f(l3, 35) + readlane_f(l3, 51));
       if (lane == 0) { S.l[vw][0] = ls; S.l[vw][1] = l1; S.l[vw][2] = l2; S.l[vw][3] = l3; }
     }
+    stamp(7 + (cb < 4 ? cb : 3));
   }
+  stamp(11);
   __syncthreads();                                          // A3: partial sums of all 8 virtual waves
+  stamp(12);
   const int tid = rw * 64 + lane;
   if (tid < G * 32) {
     const int g = tid >> 5, d = tid & 31;
@@ -350,6 +358,7 @@ ZN_DEVINL void stack_attention(StackAttnLds& S, u32x4 (&kk)[4][4], u32x4 (&vvA)[
     for (int w = 0; w < NW; ++w) l += S.l[w][g];
     S.out[g][d] = f2bf(__fmul_rn(v, 1.0f / l));
   }
+  stamp(13);
 }
 
 // T_* = tiles per compute wave per op (upper bounds; a wave skips the tiles its workgroup does not have).  d_model =

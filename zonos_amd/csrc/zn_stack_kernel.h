@@ -125,7 +125,8 @@ __global__ __launch_bounds__(ZN_CH_THREADS) void stack_kernel(ChainArgs a) {
         stack_attn_issue_k(kk0, Lr.kv, ar, kvh, L, a.max_len, a.n_heads_kv, wave, 0, lane);
         stack_attn_issue_v(vv0, Lr.kv, ar, kvh, slice, L, a.max_len, a.n_heads_kv, wave, 0, lane);
         __syncthreads();                                  // A1: q, newest key and value rows are in LDS
-        stack_attention(AL, kk0, vv0, Lr.kv, ar, kvh, slice, L, a.max_len, a.n_heads_kv, a.scale, wave, lane);   // A2, A3 inside
+        stack_attention(AL, kk0, vv0, Lr.kv, ar, kvh, slice, L, a.max_len, a.n_heads_kv, a.scale, wave, lane,
+                        (a.stamps && li == a.stamp_layer && c == 0) ? a.stamps + 32 : nullptr);   // A2, A3 inside
         __syncthreads();                                  // A4: the result slice is in LDS
       }
       // a tile that does not exist leaves its buffer untouched: tell the compiler that nothing of the block before survives
