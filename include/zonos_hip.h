@@ -168,7 +168,10 @@ int zn_debug_token_override(zn_handle h, const int32_t* tokens_dev, int32_t call
 /* Test hook: 1 = batched prefill (default: MFMA GEMMs + tiled causal attention over all positions), 0 = position by
  * position through the decode kernels (both reproduce the reference's rounding points). */
 int zn_debug_prefill_mode(zn_handle h, int32_t mode);
-/* Tuning hook: target workgroup count of a GEMV class (0 in_proj, 1 out_proj, 2 fc1, 3 fc2, 4 heads). */
+/* Tuning hook: target workgroup count of a GEMV class (0 in_proj, 1 out_proj, 2 fc1, 3 fc2, 4 heads); 5: longest context of the
+ * fused attention launch; 6: 1 = single-step graphs only; 8: 2 = per-op launches instead of the persistent chain kernel (also
+ * ZN_CHAIN=0 at zn_create); 15: 3 = the opt-in whole-step kernel at batch 1 (also ZN_STACK=1 at zn_create), 1 = off.  Every path
+ * gives bit-identical results. */
 int zn_debug_tune(zn_handle h, int32_t key, int32_t value);
 /* Test/benchmark hook: add `bias` to the codebook-0 EOS logit on every step (-inf suppresses EOS so that all
  * max_new_tokens+7 steps run). */
