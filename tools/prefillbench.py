@@ -16,6 +16,9 @@ from zonos_amd.testing import build_model  # noqa: E402
 model, _ = build_model(synth.FULL_CFG, 1234, "cuda:0")
 eng = model.engine(1)
 eng.call("zn_debug_eos_bias", float("-inf"))
+for kv in os.environ.get("ZN_TUNE", "").split(","):
+    if kv:
+        eng.call("zn_debug_tune", int(kv.split(":")[0]), int(kv.split(":")[1]))
 cond = synth.conditioning(1234, "cond", 2, 24, 2048).to("cuda:0")
 
 

@@ -1012,11 +1012,31 @@ static bool run_gemm64s(zn_handle h, const bf16_t* x, const void* W, int N, int 
   if (groups > ZN_G16_MAX_GROUPS) return false;
   int ks = 1;
   while (groups * ks < 256 && ks < 16 && K % (2 * ks * 256) == 0) ks *= 2;
+  // (fc2, K = 8192: the split this picks, 8, against 4 / 16 / 2 forced: prefill 2.71 vs 2.90 / 2.77 / 3.13 ms)
   if ((size_t)ks * 64 * groups * 64 * sizeof(float) > h->g16_part_bytes) return false;
   GemvArgs g{};
   g.W = (const bf16_t*)W; g.N = N; g.K = K; g.x = x; g.out = out; g.resid = resid; g.nrows = M;
   g.part = h->g16_part; g.tickets = h->g16_tickets; g.ksplit = ks;
   hipLaunchKernelGGL((gemm64s_kernel<EPI>), dim3(groups, ks), dim3(256), 0, s, g);
+  return true;
+}
+
+// Short prompts, contractions of 2048 or 4096 with few weight rows (in_proj, both out_proj calls): the decode side's gemm16k_kernel
+// (one 16-row weight tile per workgroup over the whole K, K split over its 8 waves: no cross-workgroup combine; LayerNorm as its
+// prologue) over ceil(M / 16) row groups in ONE launch, instead of gemm64s_kernel's 8-way split-K with a ticketed combine
+// (14.4 us for 8-13 MB) behind a LayerNorm launch.
+template <int PRO, int EPI>
+static bool run_gemm16k_rows(zn_handle h, const bf16_t* x, const void* ln_w, const void* ln_b, const void* W, int N, int K, bf16_t* out, const bf16_t* resid,
+                             int M, hipStream_t s) {
+  if (M > 64 || !gemm16k_fits(h, EPI, N, K) || h->tune[12] == 2) return false;
+  const int nch = K / (ZN_G16K_NKW * ZN_G16K_KCH);
+  if (PRO == PRO_LN && nch != 2) return false;
+  GemvArgs g{};
+  g.W = (const bf16_t*)W; g.N = N; g.K = K; g.x = x; g.out = out; g.resid = resid; g.nrows = M; g.eps = h->cfg.norm_eps;
+  g.ln_w = (const bf16_t*)ln_w; g.ln_b = (const bf16_t*)ln_b;
+  const dim3 grid((N + 15) / 16, (M + 15) / 16), block(ZN_G16K_NKW * 64);
+  if (nch == 2) hipLaunchKernelGGL((gemm16k_kernel<EPI, 2, PRO>), grid, block, 0, s, g);
+  else if constexpr (PRO == PRO_NONE) hipLaunchKernelGGL((gemm16k_kernel<EPI, 4, PRO>), grid, block, 0, s, g);
   return true;
 }
 
@@ -1031,19 +1051,24 @@ static int transformer_prefill_core(zn_handle h, const bf16_t* hidden, int S, in
   for (int li = 0; li < c.n_layer; ++li) {
     const zn_layer_weights& lw = h->layers[li];
     bf16_t* kv = (bf16_t*)kv_layers[li];
+    // short prompts (<= 64 rows): every projection streams its weights through a small-M kernel (10.7 -> ~2.5 ms per prefill)
+    // (LayerNorm as gemm16k's prologue over four row groups: 22.0 us against 4.7 + 9 for the launch pair: 768 workgroups repeat the statistics)
     hipLaunchKernelGGL(layernorm_kernel, dim3(M), dim3(64), 0, s, h->pf_x, (const bf16_t*)lw.norm_w, (const bf16_t*)lw.norm_b, h->pf_n, d, c.norm_eps);
-    // short prompts (<= 64 rows): every projection streams its weights once through gemm64s_kernel (10.7 -> ~2 ms per prefill)
-    if (!run_gemm64s<EPI_STORE>(h, h->pf_n, lw.in_proj, nqkv, d, h->pf_qkv, nullptr, M, s))
+    if (!run_gemm16k_rows<PRO_NONE, EPI_STORE>(h, h->pf_n, nullptr, nullptr, lw.in_proj, nqkv, d, h->pf_qkv, nullptr, M, s) &&
+        !run_gemm64s<EPI_STORE>(h, h->pf_n, lw.in_proj, nqkv, d, h->pf_qkv, nullptr, M, s))
       launch_gemm(h->pf_n, d, (const bf16_t*)lw.in_proj, h->pf_qkv, nqkv, nullptr, M, nqkv, d, s);
     hipLaunchKernelGGL(rope_kv_rows_kernel, dim3(S, R), dim3(256), 0, s, h->pf_qkv, kv, h->rope, S, base, max_len, c.n_heads, c.n_heads_kv, hd, c.rope_positions);
     rc = prefill_attention(h, h->pf_qkv, nqkv, kv, max_len, h->pf_a, nq, S, R, s, base);
     if (rc) return rc;
     if (c.double_out_proj) {
-      if (!run_gemm64s<EPI_STORE>(h, h->pf_a, lw.out_proj, d, nq, h->pf_n, nullptr, M, s))
+      if (!run_gemm16k_rows<PRO_NONE, EPI_STORE>(h, h->pf_a, nullptr, nullptr, lw.out_proj, d, nq, h->pf_n, nullptr, M, s) &&
+          !run_gemm64s<EPI_STORE>(h, h->pf_a, lw.out_proj, d, nq, h->pf_n, nullptr, M, s))
         launch_gemm(h->pf_a, nq, (const bf16_t*)lw.out_proj, h->pf_n, d, nullptr, M, d, nq, s);
-      if (!run_gemm64s<EPI_RESID>(h, h->pf_n, lw.out_proj, d, nq, h->pf_x, h->pf_x, M, s))
+      if (!run_gemm16k_rows<PRO_NONE, EPI_RESID>(h, h->pf_n, nullptr, nullptr, lw.out_proj, d, nq, h->pf_x, h->pf_x, M, s) &&
+          !run_gemm64s<EPI_RESID>(h, h->pf_n, lw.out_proj, d, nq, h->pf_x, h->pf_x, M, s))
         launch_gemm(h->pf_n, d, (const bf16_t*)lw.out_proj, h->pf_x, d, h->pf_x, M, d, nq, s);
-    } else if (!run_gemm64s<EPI_RESID>(h, h->pf_a, lw.out_proj, d, nq, h->pf_x, h->pf_x, M, s))
+    } else if (!run_gemm16k_rows<PRO_NONE, EPI_RESID>(h, h->pf_a, nullptr, nullptr, lw.out_proj, d, nq, h->pf_x, h->pf_x, M, s) &&
+               !run_gemm64s<EPI_RESID>(h, h->pf_a, lw.out_proj, d, nq, h->pf_x, h->pf_x, M, s))
       launch_gemm(h->pf_a, nq, (const bf16_t*)lw.out_proj, h->pf_x, d, h->pf_x, M, d, nq, s);
     hipLaunchKernelGGL(layernorm_kernel, dim3(M), dim3(64), 0, s, h->pf_x, (const bf16_t*)lw.norm2_w, (const bf16_t*)lw.norm2_b, h->pf_n, d, c.norm_eps);
     if (!run_gemm64s<EPI_SILU>(h, h->pf_n, lw.fc1, 2 * F, d, h->pf_m, nullptr, M, s)) {

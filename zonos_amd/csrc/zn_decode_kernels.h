@@ -716,6 +716,15 @@ __global__ __launch_bounds__(ZN_G16K_NKW * 64) void gemm16k_kernel(GemvArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int n = lane & 15, g = lane >> 4;
   const int tile = blockIdx.x, K = a.K, kbeg = wave * KS;
+  // gridDim.y > 1 (short-prompt prefill: up to 64 rows): workgroup (tile, y) serves activation rows 16 y .. 16 y + 15; the tile's
+  // weights are read once per row group (the groups of a tile share blockIdx.x % 8, i.e. an XCD and its L2, when gridDim.x % 8 == 0)
+  if (blockIdx.y) {
+    const size_t r0 = (size_t)blockIdx.y * 16;
+    a.x += r0 * K; a.nrows -= (int)r0;
+    if (a.out) a.out += r0 * a.N;
+    if (a.resid) a.resid += r0 * a.N;
+  }
+  if (a.nrows > 16) a.nrows = 16;
   // epilogue operands first (item = tid < 128: activation row m, weight-row pair pj): their round trips overlap the stream's
   const int em = tid & 15, epj = (tid >> 4) & 7;
   const int erowA = tile * 16 + 2 * epj, erowB = erowA + 1;
