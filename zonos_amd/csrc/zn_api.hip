@@ -1227,7 +1227,9 @@ extern "C" int zn_decode_steps(zn_handle h, int32_t n, zn_stream stream) {
     // this step appends one key per row; a run of ZN_GRAPH_STEPS steps with one launch shape replays the long graph
     const bool fused = attn_fused_for(h, h->len_hi + 1);
     const int run = (n - i >= ZN_GRAPH_STEPS && h->tune[6] > 1 && attn_fused_for(h, h->len_hi + ZN_GRAPH_STEPS) == fused) ? ZN_GRAPH_STEPS : 1;
-    const bool stack = tail_fused(h) && stack_active(h, h->rows, h->len_hi + run);
+    // (the whole-step kernel computes the fused attention launch's arithmetic: it serves exactly the steps that launch would serve,
+    // so that switching it on never changes a result; the two-pass launches of longer contexts sum the scores in another order)
+    const bool stack = fused && tail_fused(h) && stack_active(h, h->rows, h->len_hi + run);
     const int k = (fused ? 1 : 0) | (run > 1 ? 2 : 0) | (stack ? 4 : 0);
     h->attn_fused = fused; h->use_stack = stack;
     if (!h->graph_exec[k] && !h->graph_tried[k] && n > 1) {
