@@ -110,6 +110,13 @@ def test_whole_step_kernel_is_bit_identical_to_the_chain_path():
             eng.call("zn_debug_tune", 15, t15)
             outs.append(model.generate(cond.to("cuda:0"), max_new_tokens=300, sampling_params=GREEDY).cpu())
         assert torch.equal(outs[0], outs[1])
+        # contexts 426 .. 700: the in-chain attention walks two 512-key blocks (second block's K / V requested inside the pass)
+        pre = torch.from_numpy(synth.randint(seed, "prefix", (1, 9, 400), 1024)).to("cuda:0")
+        outs = []
+        for t15 in (1, 3):
+            eng.call("zn_debug_tune", 15, t15)
+            outs.append(model.generate(cond.to("cuda:0"), audio_prefix_codes=pre, max_new_tokens=268, sampling_params=GREEDY).cpu())
+        assert torch.equal(outs[0], outs[1])
     finally:
         eng.call("zn_debug_tune", 15, 1)
         eng.call("zn_debug_eos_bias", 0.0)
