@@ -25,7 +25,10 @@ __global__ __launch_bounds__(ZN_CH_THREADS) void stack_kernel(ChainArgs a) {
   constexpr int S1 = T_OUT, S2 = 2 * T_OUT, S3 = S2 + T_FC1, S4 = S3 + T_FC2, NS = S4 + T_IN;
   constexpr int NOPS = 5;
   constexpr int MASK = ZN_CH_DEFER_MASK;
-  constexpr int NB = ZN_CH_NBUF;
+  // Two tile buffers, not chain_kernel's three: with three the compute waves spilled 27 VGPRs to scratch around the attention.  A
+  // kernel whose hand-offs need every workgroup resident must not depend on scratch-wave slots being granted to all of them at
+  // once (one hand-off timeout was observed in ~10 generations with the spilling build; none since).
+  constexpr int NB = 2;
   constexpr int NL = NS - T_OUT, INIT = T_OUT + 1 < NB ? T_OUT + 1 : NB;
   static_assert(T_IN > 0 && NCH == 4, "stack_kernel: d_model 2048, head size 128");
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
