@@ -1054,11 +1054,22 @@ static int transformer_prefill_core(zn_handle h, const bf16_t* hidden, int S, in
     // short prompts (<= 64 rows): every projection streams its weights through a small-M kernel (10.7 -> ~2.5 ms per prefill)
     // (LayerNorm as gemm16k's prologue over four row groups: 22.0 us against 4.7 + 9 for the launch pair: 768 workgroups repeat the statistics)
     hipLaunchKernelGGL(layernorm_kernel, dim3(M), dim3(64), 0, s, h->pf_x, (const bf16_t*)lw.norm_w, (const bf16_t*)lw.norm_b, h->pf_n, d, c.norm_eps);
-    if (!run_gemm16k_rows<PRO_NONE, EPI_STORE>(h, h->pf_n, nullptr, nullptr, lw.in_proj, nqkv, d, h->pf_qkv, nullptr, M, s) &&
-        !run_gemm64s<EPI_STORE>(h, h->pf_n, lw.in_proj, nqkv, d, h->pf_qkv, nullptr, M, s))
-      launch_gemm(h->pf_n, d, (const bf16_t*)lw.in_proj, h->pf_qkv, nqkv, nullptr, M, nqkv, d, s);
-    hipLaunchKernelGGL(rope_kv_rows_kernel, dim3(S, R), dim3(256), 0, s, h->pf_qkv, kv, h->rope, S, base, max_len, c.n_heads, c.n_heads_kv, hd, c.rope_positions);
-    rc = prefill_attention(h, h->pf_qkv, nqkv, kv, max_len, h->pf_a, nq, S, R, s, base);
+    // short prompts: split, RoPE and the KV append in the projection's epilogue (q compact [M][Hq * hd] in pf_qkv), as in a decode step
+    int ldq = nqkv;
+    if (M <= 64 && gemm16k_fits(h, EPI_ROPE_KV, nqkv, d) && d / (ZN_G16K_NKW * ZN_G16K_KCH) == 2 && h->tune[12] != 2) {
+      GemvArgs g{};
+      g.W = (const bf16_t*)lw.in_proj; g.N = nqkv; g.K = d; g.x = h->pf_n; g.nrows = M; g.eps = c.norm_eps;
+      g.hd = hd; g.n_heads = c.n_heads; g.n_heads_kv = c.n_heads_kv; g.q_out = h->pf_qkv; g.kv = kv; g.rope = h->rope; g.max_len = max_len;
+      g.rope_positions = c.rope_positions; g.pf_S = S; g.pf_base = base;
+      hipLaunchKernelGGL((gemm16k_kernel<EPI_ROPE_KV, 2, PRO_NONE>), dim3((nqkv + 15) / 16, (M + 15) / 16), dim3(ZN_G16K_NKW * 64), 0, s, g);
+      ldq = nq;
+    } else {
+      if (!run_gemm16k_rows<PRO_NONE, EPI_STORE>(h, h->pf_n, nullptr, nullptr, lw.in_proj, nqkv, d, h->pf_qkv, nullptr, M, s) &&
+          !run_gemm64s<EPI_STORE>(h, h->pf_n, lw.in_proj, nqkv, d, h->pf_qkv, nullptr, M, s))
+        launch_gemm(h->pf_n, d, (const bf16_t*)lw.in_proj, h->pf_qkv, nqkv, nullptr, M, nqkv, d, s);
+      hipLaunchKernelGGL(rope_kv_rows_kernel, dim3(S, R), dim3(256), 0, s, h->pf_qkv, kv, h->rope, S, base, max_len, c.n_heads, c.n_heads_kv, hd, c.rope_positions);
+    }
+    rc = prefill_attention(h, h->pf_qkv, ldq, kv, max_len, h->pf_a, nq, S, R, s, base);
     if (rc) return rc;
     if (c.double_out_proj) {
       if (!run_gemm16k_rows<PRO_NONE, EPI_STORE>(h, h->pf_a, nullptr, nullptr, lw.out_proj, d, nq, h->pf_n, nullptr, M, s) &&

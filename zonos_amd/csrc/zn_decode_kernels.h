@@ -44,6 +44,9 @@ struct GemvArgs {
   const bf16_t* conv_b;    // [conv_dim]
   bf16_t* xbc;             // [rows][conv_dim] activated conv output
   int d_inner, conv_dim;
+  // gemm16k_kernel<EPI_ROPE_KV> over the rows of a short prefill (pf_S > 0): activation row m = r * pf_S + s is position pf_base + s of
+  // cache row r (lengths unused); q goes to q_out [m][Hq * hd]
+  int pf_S, pf_base;
 };
 
 // EPI_MAMBA operands of activation row r and the weight-row pair starting at rowA (both rows lie in the same segment:
@@ -725,6 +728,14 @@ __global__ __launch_bounds__(ZN_G16K_NKW * 64) void gemm16k_kernel(GemvArgs a) {
     if (a.resid) a.resid += r0 * a.N;
   }
   if (a.nrows > 16) a.nrows = 16;
+  int pf_r = 0;                                            // prefill rows: cache row of this thread's activation row
+  if constexpr (EPI == EPI_ROPE_KV) {
+    if (a.pf_S > 0) {
+      const int m = (int)blockIdx.y * 16 + (tid & 15);
+      pf_r = m / a.pf_S;
+      a.q_out += (size_t)(m - pf_r) * a.n_heads * a.hd;    // gemv_epilogue indexes q_out and the cache with one row number: q row m, cache row pf_r
+    }
+  }
   // epilogue operands first (item = tid < 128: activation row m, weight-row pair pj): their round trips overlap the stream's
   const int em = tid & 15, epj = (tid >> 4) & 7;
   const int erowA = tile * 16 + 2 * epj, erowB = erowA + 1;
@@ -733,7 +744,7 @@ __global__ __launch_bounds__(ZN_G16K_NKW * 64) void gemm16k_kernel(GemvArgs a) {
   if constexpr (EPI == EPI_RESID) {
     if (e_on) { const size_t o = (size_t)em * a.N + erowA; resid = eb_ok ? *(const unsigned*)(a.resid + o) : (unsigned)a.resid[o]; }
   }
-  if constexpr (EPI == EPI_ROPE_KV) { if (e_on) pos = a.lengths[em]; }
+  if constexpr (EPI == EPI_ROPE_KV) { if (e_on) pos = a.pf_S > 0 ? a.pf_base + ((int)blockIdx.y * 16 + em) % a.pf_S : a.lengths[em]; }
   u32x4 cst = u32x4{0, 0, 0, 0}, cw = u32x4{0, 0, 0, 0};
   if constexpr (EPI == EPI_MAMBA) { if (e_on) mamba_epi_operands(a, em, erowA, resid, cst, cw); }
   // activations (and LayerNorm parameters) are requested first: requests return in order, and the statistics passes then
@@ -847,7 +858,9 @@ __global__ __launch_bounds__(ZN_G16K_NKW * 64) void gemm16k_kernel(GemvArgs a) {
   float vA = 0.f, vB = 0.f;
 #pragma unroll
   for (int w = 0; w < NKW; ++w) { vA += Ct[w][2 * epj][em]; vB += Ct[w][2 * epj + 1][em]; }
-  gemv_epilogue<EPI>(a, em, erowA, erowB, eb_ok, erowA >> 1, vA, eb_ok ? vB : 0.f, resid, cs, sn, pos, cst, cw);
+  int er = em;
+  if constexpr (EPI == EPI_ROPE_KV) { if (a.pf_S > 0) er = pf_r; }
+  gemv_epilogue<EPI>(a, er, erowA, erowB, eb_ok, erowA >> 1, vA, eb_ok ? vB : 0.f, resid, cs, sn, pos, cst, cw);
 }
 
 // ------------------------------------------------------------------------------------------------ attention
