@@ -161,23 +161,46 @@ __global__ __launch_bounds__(256) void gemm64s_kernel(GemvArgs a) {
     }
     __syncthreads();
     if (!s_last) return;
-    // MR * TN / NT = 16 tile elements per thread, four at a time with every slice of the four requested before the first add
-    for (int i0 = 0; i0 < MR * TN / NT; i0 += 4) {
-      float v[4][16];
+    // MR * TN / NT = 16 tile elements per thread; every slice of a batch of elements is requested before the first add: eight
+    // elements at a time with up to 8 slices (two dependent read batches), four with up to 16 (the sums run over the same slices in
+    // the same order either way)
+    if (a.ksplit <= 8) {
+      for (int i0 = 0; i0 < MR * TN / NT; i0 += 8) {
+        float v[8][8];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int item = (i0 + i) * NT + tid, m = item / TN, col = item % TN;
-        const float* q = a.part + (size_t)m * ld + (size_t)grp * TN + col;
+        for (int i = 0; i < 8; ++i) {
+          const int item = (i0 + i) * NT + tid, m = item / TN, col = item % TN;
+          const float* q = a.part + (size_t)m * ld + (size_t)grp * TN + col;
 #pragma unroll
-        for (int y = 0; y < 16; ++y) v[i][y] = (y < a.ksplit) ? ld_wt(q + (size_t)y * MR * ld) : 0.f;
+          for (int y = 0; y < 8; ++y) v[i][y] = (y < a.ksplit) ? ld_wt(q + (size_t)y * MR * ld) : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int item = (i0 + i) * NT + tid, m = item / TN, col = item % TN;
+          float sum = 0.f;
+#pragma unroll
+          for (int y = 0; y < 8; ++y) sum += v[i][y];
+          Ct[col][m] = sum;
+        }
       }
+    } else {
+      for (int i0 = 0; i0 < MR * TN / NT; i0 += 4) {
+        float v[4][16];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int item = (i0 + i) * NT + tid, m = item / TN, col = item % TN;
-        float sum = 0.f;
+        for (int i = 0; i < 4; ++i) {
+          const int item = (i0 + i) * NT + tid, m = item / TN, col = item % TN;
+          const float* q = a.part + (size_t)m * ld + (size_t)grp * TN + col;
 #pragma unroll
-        for (int y = 0; y < 16; ++y) sum += v[i][y];
-        Ct[col][m] = sum;
+          for (int y = 0; y < 16; ++y) v[i][y] = (y < a.ksplit) ? ld_wt(q + (size_t)y * MR * ld) : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int item = (i0 + i) * NT + tid, m = item / TN, col = item % TN;
+          float sum = 0.f;
+#pragma unroll
+          for (int y = 0; y < 16; ++y) sum += v[i][y];
+          Ct[col][m] = sum;
+        }
       }
     }
   } else {
