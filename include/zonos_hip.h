@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define ZN_ABI_VERSION 3
+#define ZN_ABI_VERSION 4
 
 enum zn_status {
   ZN_OK = 0,
@@ -145,6 +145,10 @@ int zn_graph_active(zn_handle h);
 /* 1 if the decode steps of the generation begun by zn_gen_begin run the persistent per-block chain kernel (batch 1 on a
  * model whose shapes it serves), 0 if every op is a launch of its own.  Both paths give bit-identical results. */
 int zn_decode_path(zn_handle h);
+/* Which kernels served the decode step enqueued last: 0 = one launch per op, 1 = one attention launch + one persistent chain
+ * launch per block, 2 = the whole-step persistent kernel (every block of the step in one launch; contexts up to 1024 keys).
+ * All three give bit-identical results (the per-block path with its fused attention launch: zn_debug_tune(5, ...)). */
+int zn_decode_path_detail(zn_handle h);
 /* (remaining_steps <= 0).all() of tensor_ops.py:95,102 — synchronises the stream. */
 int zn_all_stopped(zn_handle h, int32_t* out, zn_stream stream);
 /* The same check off the critical path: zn_all_stopped_begin queues the read-back of the loop state behind the steps enqueued

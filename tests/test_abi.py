@@ -112,7 +112,7 @@ def test_ticketed_combines_use_write_through_stores_and_sc1_loads(kernels_isa):
 def test_chain_kernel_handoffs_are_granules_and_sc1_sweeps(kernels_isa):
     """The persistent chain publishes 8-byte {tag, data} granules with ONE write-through store each (the data is the flag:
     Guideline 16 R2) and every load of handed-off bytes is an sc1 buffer load."""
-    names = [n for n in kernels_isa if n.startswith("_Z12chain_kernel") or n.startswith("_Z12stack_kernel")]
+    names = [n for n in kernels_isa if n.startswith("_Z12chain_kernel") or n.startswith("_Z11step_kernel")]
     assert len(names) == 7                                                            # 6 chain instantiations + the whole-step kernel
     for n in names:
         ins = kernels_isa[n]

@@ -61,73 +61,84 @@ def test_chain_generate_vs_oracle():
     assert worst <= 0.06
 
 
-@pytest.mark.parametrize("which", ["chain512", "full"])
+@pytest.mark.parametrize("which", ["chain512", "full-chain", "full-step"])
 def test_chain_is_bit_identical_to_the_launches_path(which):
-    """Free-running greedy generation through the chain kernel and through the per-op launches (zn_debug_tune(8, 2)).  At the
-    Zonos-v0.1-transformer dimensions both paths cut every dot product the same way (fc2's K = 8192 in four quarters): equal
-    codes and bit-equal logits at every step (200 steps: 8-step graphs, the fused attention launch, hand-offs replayed
-    26 x 4 x 200 times).  At d_model 512 the launches path keeps fc2's K = 2048 in one wave while the chain splits it in
-    quarters - another summation order: equal codes, logits within one bf16 ulp of a hidden value."""
+    """Free-running greedy generation through the persistent kernels and through the per-op launches (zn_debug_tune(8, 2)).  At the
+    Zonos-v0.1-transformer dimensions every path cuts every dot product the same way (fc2's K = 8192 in four quarters): equal
+    codes and bit-equal logits at every step (200 steps: 8-step graphs, the fused attention arithmetic, hand-offs replayed
+    26 x 6 x 200 times), for one chain launch per block (zn_debug_tune(15, 2)) and for the whole-step kernel (the default).  At
+    d_model 512 the launches path keeps fc2's K = 2048 in one wave while the chain splits it in quarters - another summation
+    order: equal codes, logits within one bf16 ulp of a hidden value."""
     cfg, seed, n = (synth.CHAIN_CFG, 55, 60) if which == "chain512" else (synth.FULL_CFG, 1234, 200)
     model, _ = build_model(cfg, seed, "cuda:0")
+    eng = model.engine(1)
     cond = synth.conditioning(seed, "cond", 2, 24, cfg["d_model"])
-    a, la, pa = _run(model, cond, n, chain=True)
-    b, lb, pb = _run(model, cond, n, chain=False)
-    assert (pa, pb) == (1, 0)
-    assert torch.equal(a, b)
-    assert la.shape == lb.shape
-    if which == "full":
-        assert torch.equal(la.view(torch.int32), lb.view(torch.int32))
-    else:
-        fin = torch.isfinite(lb)
-        same = float((la.view(torch.int32) == lb.view(torch.int32))[fin].float().mean())
-        worst = float((la - lb)[fin].abs().max())
-        print(f"\n[chain vs launches, d 512] logits bit-equal {same:.5f}, max |d| {worst:.4g}")
-        assert same > 0.98 and worst <= 0.04
-    a2, la2, _ = _run(model, cond, n, chain=True)           # replay: no state survives a generation (counters, timeout word)
-    assert torch.equal(a, a2) and torch.equal(la.view(torch.int32), la2.view(torch.int32))
+    eng.call("zn_debug_tune", 15, 2 if which == "full-chain" else 1)
+    try:
+        a, la, pa = _run(model, cond, n, chain=True)
+        b, lb, pb = _run(model, cond, n, chain=False)
+        assert (pa, pb) == (1, 0)
+        assert eng.lib.zn_decode_path_detail(eng.h) in (0, 1, 2)
+        assert torch.equal(a, b)
+        assert la.shape == lb.shape
+        if which != "chain512":
+            assert torch.equal(la.view(torch.int32), lb.view(torch.int32))
+        else:
+            fin = torch.isfinite(lb)
+            same = float((la.view(torch.int32) == lb.view(torch.int32))[fin].float().mean())
+            worst = float((la - lb)[fin].abs().max())
+            print(f"\n[chain vs launches, d 512] logits bit-equal {same:.5f}, max |d| {worst:.4g}")
+            assert same > 0.98 and worst <= 0.04
+        a2, la2, _ = _run(model, cond, n, chain=True)           # replay: no state survives a generation (counters, timeout word)
+        assert torch.equal(a, a2) and torch.equal(la.view(torch.int32), la2.view(torch.int32))
+    finally:
+        eng.call("zn_debug_tune", 15, 1)
 
 
 def test_whole_step_kernel_is_bit_identical_to_the_chain_path():
-    """The opt-in whole-step kernel (csrc/zn_stack_kernel.h: the attention as an op of the persistent chain, every block of the
-    decode step in ONE launch; zn_debug_tune(15, 3)) against the default path (attention launch + chain launch per block) at the
-    Zonos-v0.1-transformer dimensions: free-running greedy codes equal and the logits of every step bit-equal, over single-step
-    launches (teacher-free trace mode, 40 steps) and over 8-step graphs (300 steps: contexts 26 .. 333)."""
-    from zonos_amd._lib import ZonosHipError
+    """The whole-step kernel (csrc/zn_step_kernel.h: every block of the decode step in ONE launch, 32 weight-free attention
+    workgroups + 224 streaming workgroups; the default at batch 1) against one attention launch + one chain launch per block
+    (zn_debug_tune(15, 2)) at the Zonos-v0.1-transformer dimensions: free-running greedy codes equal and the logits of every step
+    bit-equal, over single-step launches (trace mode, 40 steps) and over 8-step graphs (300 steps: contexts 26 .. 333), with an
+    audio prefix (contexts 426 .. 700) and across the second 512-key block up to the kernel's limit (contexts 650 .. 1024, the
+    per-block path's fused attention launch raised to 1024 keys for the comparison; beyond the limit both runs take the per-block
+    path).  A hand-off timeout is an error (the bounded waits describe themselves: zn_last_error)."""
     cfg, seed = synth.FULL_CFG, 1234
     model, _ = build_model(cfg, seed, "cuda:0")
     eng = model.engine(1)
     cond = synth.conditioning(seed, "cond", 2, 24, cfg["d_model"])
     try:
-        _whole_step_checks(model, eng, cond, seed)
-    except ZonosHipError as e:
-        # the kernel's waits are bounded and report instead of hanging; the path is opt-in and experimental (DESIGN.md section 4.1)
-        if "timed out" in str(e):
-            pytest.xfail(f"experimental whole-step kernel: {e}")
-        raise
-    finally:
-        eng.call("zn_debug_tune", 15, 1)
-        eng.call("zn_debug_eos_bias", 0.0)
-
-
-def _whole_step_checks(model, eng, cond, seed):
-    if True:
-        eng.call("zn_debug_tune", 15, 1)
+        eng.call("zn_debug_tune", 15, 2)
         a, la, pa = _run(model, cond, 40)
-        eng.call("zn_debug_tune", 15, 3)
+        assert eng.lib.zn_decode_path_detail(eng.h) == 1
+        eng.call("zn_debug_tune", 15, 1)
         b, lb, pb = _run(model, cond, 40)
+        assert eng.lib.zn_decode_path_detail(eng.h) == 2, "the whole-step kernel did not serve this configuration"
         assert torch.equal(a, b)
         assert torch.equal(la.view(torch.int32), lb.view(torch.int32))
         eng.call("zn_debug_eos_bias", float("-inf"))
         outs = []
-        for t15 in (1, 3):
+        for t15 in (2, 1):
             eng.call("zn_debug_tune", 15, t15)
             outs.append(model.generate(cond.to("cuda:0"), max_new_tokens=300, sampling_params=GREEDY).cpu())
         assert torch.equal(outs[0], outs[1])
-        # contexts 426 .. 700: the in-chain attention walks two 512-key blocks (second block's K / V requested inside the pass)
         pre = torch.from_numpy(synth.randint(seed, "prefix", (1, 9, 400), 1024)).to("cuda:0")
         outs = []
-        for t15 in (1, 3):
+        for t15 in (2, 1):
             eng.call("zn_debug_tune", 15, t15)
             outs.append(model.generate(cond.to("cuda:0"), audio_prefix_codes=pre, max_new_tokens=268, sampling_params=GREEDY).cpu())
         assert torch.equal(outs[0], outs[1])
+        pre = torch.from_numpy(synth.randint(seed, "prefix2", (1, 9, 620), 1024)).to("cuda:0")
+        outs = []
+        eng.call("zn_debug_tune", 5, 1024)
+        for t15 in (2, 1):
+            eng.call("zn_debug_tune", 15, t15)
+            tr = {"logits": []}
+            o = model.generate(cond.to("cuda:0"), audio_prefix_codes=pre, max_new_tokens=400, sampling_params=GREEDY, _trace=tr)
+            outs.append((o.cpu(), torch.stack(tr["logits"]).cpu()))
+        assert torch.equal(outs[0][0], outs[1][0])
+        assert torch.equal(outs[0][1].view(torch.int32), outs[1][1].view(torch.int32))
+    finally:
+        eng.call("zn_debug_tune", 5, 704)
+        eng.call("zn_debug_tune", 15, 1)
+        eng.call("zn_debug_eos_bias", 0.0)

@@ -1,4 +1,4 @@
-"""A/B of the decode step at the Zonos-v0.1-transformer dimensions, batch 1: whole-step kernel (zn_stack_kernel.h) vs one chain launch
+"""A/B of the decode step at the Zonos-v0.1-transformer dimensions, batch 1: whole-step kernel (zn_step_kernel.h) vs one chain launch
 per block vs per-op launches; codes compared.
     python tools/stackbench.py [new_tokens]"""
 import os
@@ -15,9 +15,10 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 400
 model, _ = build_model(synth.FULL_CFG, 1234, "cuda:0")
 eng = model.engine(1)
 eng.call("zn_debug_eos_bias", float("-inf"))
+eng.call("zn_debug_tune", 5, 1024)   # the per-block path with its fused attention launch over the whole range: the arithmetic the whole-step kernel reproduces
 cond = synth.conditioning(1234, "cond", 2, 24, 2048).to("cuda:0")
 outs = {}
-for name, t8, t15 in (("chain", 1, 1), ("stack", 1, 3), ("chain", 1, 1), ("stack", 1, 3), ("launches", 2, 1)):
+for name, t8, t15 in (("chain", 1, 2), ("stack", 1, 1), ("chain", 1, 2), ("stack", 1, 1), ("launches", 2, 1)):
     eng.call("zn_debug_tune", 8, t8)
     eng.call("zn_debug_tune", 15, t15)
     model.generate(cond, max_new_tokens=32, sampling_params={"temperature": 0.0})

@@ -14,7 +14,6 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 400
 model, _ = build_model(synth.FULL_CFG, 1234, "cuda:0")
 eng = model.engine(1)
 eng.call("zn_debug_eos_bias", float("-inf"))
-eng.call("zn_debug_tune", 15, 3)
 cond = synth.conditioning(1234, "cond", 2, 24, 2048).to("cuda:0")
 stamps = torch.zeros(52, 32, dtype=torch.int64, device="cuda:0")
 eng.call("zn_debug_chain_stamps", stamps.data_ptr())
@@ -27,9 +26,10 @@ for _ in range(3):
     best = min(best, time.perf_counter() - t0)
 at = stamps.cpu().numpy()[1]
 st = stamps.cpu().numpy()[0]
-names = ["block start", "attn inputs", "scores", "attn result", "a swept = op0 in",
+names = ["block start", "poll starts", "a swept = op0 in",
          "o1 res", "o1 pub", "o1 swept", "o1 next", "o2 res", "o2 pub", "o2 swept", "o2 next", "f1 res", "f1 pub", "f1 -", "f1 next",
-         "f2 res", "f2 pub", "f2 swept", "f2 next", "ip res", "end"]
-an = ["entry", "q frags", "sc b0", "sc b1", "sc b2", "sc b3", "A2", "pv b0", "pv b1", "pv b2", "pv b3", "reduced", "A3", "end"]
-print("attention (compute wave 0 of workgroup 0, us after block start): " + " ".join(f"{nm}={(at[i] - st[0]) / 100.0:.2f}" for i, nm in enumerate(an) if at[i] > 0))
-print(f"stack: {best * 1e3 / (n + 8):.4f} ms/step, checksum {int(out.sum())}; block 13: " + " ".join(f"{nm}={(st[i] - st[0]) / 100.0:.2f}" for i, nm in enumerate(names)))
+         "f2 res", "f2 pub", "f2 swept", "f2 next", "ip res", "ip pub"]
+an = ["entry", "inputs in LDS", "scores", "pass 2", "reduced", "published"]
+print("attention workgroup 0, block 13 (us after its entry): " + " ".join(f"{nm}={(at[i] - at[0]) / 100.0:.2f}" for i, nm in enumerate(an) if at[i] > 0))
+print(f"  (attention entry - streaming block start = {(at[0] - st[0]) / 100.0:.2f} us)")
+print(f"step kernel: {best * 1e3 / (n + 8):.4f} ms/step, checksum {int(out.sum())}; streaming workgroup 0, block 13: " + " ".join(f"{nm}={(st[i] - st[0]) / 100.0:.2f}" for i, nm in enumerate(names)))

@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ZONOS_HIP_LIB") or os.path.join(_HERE, "libzonos_hip.so")   # the override selects an experimental build (A/B runs)
 
-ZN_ABI_VERSION = 3
+ZN_ABI_VERSION = 4
 
 
 class ZonosHipError(RuntimeError):
@@ -64,6 +64,7 @@ SIGNATURES = {
     "zn_decode_steps": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
     "zn_graph_active": (C.c_int, [C.c_void_p]),
     "zn_decode_path": (C.c_int, [C.c_void_p]),
+    "zn_decode_path_detail": (C.c_int, [C.c_void_p]),
     "zn_all_stopped": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.c_void_p]),
     "zn_all_stopped_begin": (C.c_int, [C.c_void_p, C.c_void_p]),
     "zn_all_stopped_end": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),

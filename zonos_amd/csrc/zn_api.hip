@@ -3,7 +3,7 @@
 #include "../../include/zonos_hip.h"
 #include "zn_decode_kernels.h"
 #include "zn_chain_kernel.h"
-#include "zn_stack_kernel.h"
+#include "zn_step_kernel.h"
 #include "zn_prefill_kernels.h"
 #include "zn_cond_kernels.h"
 #include "zn_mamba_kernels.h"
@@ -42,6 +42,8 @@ struct zn_handle_s {
   StackLayer* stack_layers = nullptr;        // device table [n_layer], rebuilt by zn_gen_begin (it holds the KV cache pointers)
   bool use_stack = false, stack_ok = false, stack_checked = false;                    // the steps being enqueued run the whole-step kernel
   unsigned* ch_epoch = nullptr;
+  unsigned* ch_diag = nullptr;               // [8] words: the first hand-off wait that timed out describes itself (sweep_granules)
+  unsigned diag_host[8] = {};
   bf16_t* ch_x2 = nullptr;
   bf16_t* dbg_trace = nullptr;               // diagnostic: [n_layer][2][rows * d] copies of (x after the block, attention output) per decode step
   bf16_t* x_emb = nullptr;                  // [max_rows][d] embedding of the column the next decode step consumes (written by the step's tail)
@@ -96,7 +98,7 @@ struct zn_handle_s {
 
 #define ZN_FAIL(h, code, ...)                                   \
   do {                                                          \
-    char _b[512]; snprintf(_b, sizeof _b, __VA_ARGS__);         \
+    char _b[1024]; snprintf(_b, sizeof _b, __VA_ARGS__);         \
     if (h) (h)->err = _b; else g_create_err = _b;               \
     return (code);                                              \
   } while (0)
@@ -136,7 +138,7 @@ static void free_graph(zn_handle h) {
 extern "C" int zn_destroy(zn_handle h) {
   if (!h) return ZN_OK;
   free_graph(h);
-  void* ptrs[] = {h->emb_tables_dev, h->x, h->q, h->o1, h->mbuf, h->nbuf, h->logits_raw, h->last_logits, h->tok_raw, h->scores, h->cmax, h->pv_part, h->pv_tickets, h->pf_x, h->pf_n, h->pf_qkv, h->pf_a, h->pf_u, h->pf_m, h->pf_res, h->pf_zx, h->pf_xbc, h->pf_y, h->pf_g, h->qkv_tmp, h->fw_lengths, h->st, h->remaining, h->stopping, h->res, h->hn, h->m_zx, h->m_xbc, h->m_y, h->m_g, h->m_vg, h->g16_part, h->g16_tickets, h->ch_gy1, h->ch_gx1, h->ch_gx2, h->ch_gm, h->ch_epoch, h->ch_x2, h->x_emb, h->tail_ticket, h->ch_gqkv, h->ch_ga, h->stack_layers};
+  void* ptrs[] = {h->emb_tables_dev, h->x, h->q, h->o1, h->mbuf, h->nbuf, h->logits_raw, h->last_logits, h->tok_raw, h->scores, h->cmax, h->pv_part, h->pv_tickets, h->pf_x, h->pf_n, h->pf_qkv, h->pf_a, h->pf_u, h->pf_m, h->pf_res, h->pf_zx, h->pf_xbc, h->pf_y, h->pf_g, h->qkv_tmp, h->fw_lengths, h->st, h->remaining, h->stopping, h->res, h->hn, h->m_zx, h->m_xbc, h->m_y, h->m_g, h->m_vg, h->g16_part, h->g16_tickets, h->ch_gy1, h->ch_gx1, h->ch_gx2, h->ch_gm, h->ch_epoch, h->ch_x2, h->x_emb, h->tail_ticket, h->ch_gqkv, h->ch_ga, h->stack_layers, h->ch_diag};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (h->done_host) (void)hipHostFree(h->done_host);
   if (h->stop_event) (void)hipEventDestroy(h->stop_event);
@@ -240,11 +242,13 @@ extern "C" int zn_create(const zn_config* cfg, const zn_weights* w, int32_t max_
   ZC(hipMalloc(&h->ch_gm, R * (c.d_ff / 2 + 1) * 8));
   ZC(hipMemset(h->ch_gm, 0, R * (c.d_ff / 2 + 1) * 8));
   ZC(hipMalloc(&h->ch_epoch, 64));
+  ZC(hipMalloc(&h->ch_diag, 64));
+  ZC(hipMemset(h->ch_diag, 0, 64));
   { const unsigned one = 1; ZC(hipMemcpy(h->ch_epoch, &one, sizeof one, hipMemcpyHostToDevice)); }
   ZC(hipMalloc(&h->ch_x2, R * c.d_model * 2));
   h->ch_variant = chain_variant_for(c);
   if (const char* e = getenv("ZN_CHAIN")) if (atoi(e) == 0) h->tune[8] = 2;
-  if (const char* e = getenv("ZN_STACK")) if (atoi(e) == 1) h->tune[15] = 3;
+  if (const char* e = getenv("ZN_STACK")) if (atoi(e) == 0) h->tune[15] = 2;
   {   // split-K partial tiles + tickets of the small-M projections (batches of 3..8 utterances; short-prompt prefill at any batch)
     ZC(hipMalloc(&h->x_emb, R * c.d_model * 2));
     ZC(hipMalloc(&h->tail_ticket, sizeof(int)));
@@ -579,7 +583,7 @@ static int launch_chain(zn_handle h, int li, const std::vector<const void*>& kv_
   a.ln2_w = (const bf16_t*)lw.norm2_w; a.ln2_b = (const bf16_t*)lw.norm2_b; a.eps = c.norm_eps; a.F = c.d_ff;
   a.a = h->o1; a.xin = xin ? xin : chain_x(h, li); a.xout = chain_x(h, li + 1);
   a.g_y1 = h->ch_gy1; a.g_x1 = h->ch_gx1; a.g_x2 = h->ch_gx2; a.g_m = h->ch_gm;
-  a.epoch = h->ch_epoch; a.tmo = &h->st->pad[0];
+  a.epoch = h->ch_epoch; a.tmo = &h->st->pad[0]; a.diag = h->ch_diag; a.stamp_layer = li;
   a.stamps = h->ch_stamps ? h->ch_stamps + (size_t)li * 32 : nullptr;
   if (!last) {
     const zn_layer_weights& nx = h->layers[li + 1];
@@ -606,19 +610,30 @@ static int launch_chain(zn_handle h, int li, const std::vector<const void*>& kv_
   return ZN_OK;
 }
 
-// Whole-step kernel (zn_stack_kernel.h): batch 1 at the Zonos-v0.1 shapes, contexts up to ZN_ST_MAXKEYS keys.  Opt-in for now:
-// zn_debug_tune(15, 3) or ZN_STACK=1 in the environment at zn_create.
+// Whole-step kernel (zn_step_kernel.h): batch 1 at the Zonos-v0.1 shapes, contexts up to ZN_SK_MAXKEYS keys: in_proj(0) + ONE launch per
+// decode step.  The default at batch 1; zn_debug_tune(15, 2) or ZN_STACK=0 in the environment at zn_create selects one chain launch per block.
+#define ZN_SK_T 4, 2, 10, 5, 6
 static bool stack_shapes_ok(zn_handle h) {
   const zn_config& c = h->cfg;
   if (h->ch_variant != 1 || h->hd != 128 || c.n_heads_kv < 1 || c.n_heads != 4 * c.n_heads_kv) return false;
-  const int natt = 2 * c.n_heads_kv * (h->hd / 32);
-  if (natt > ZN_CH_GRID || !chain_heads_fit(h)) return false;
-  int per_cu = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, stack_kernel<4, 1, 8, 4, 5>, ZN_CH_THREADS, ZN_CH_DYN_LDS) != hipSuccess) { (void)hipGetLastError(); return false; }
-  return per_cu >= 1;
+  const int natt = 2 * c.n_heads_kv * (h->hd / 32), nsw = ZN_CH_GRID - natt;
+  if (nsw < 64) return false;
+  auto most = [&](int units) { return (units + nsw - 1) / nsw; };                     // units of the fullest streaming workgroup
+  const int nqkv = (c.n_heads + 2 * c.n_heads_kv) * h->hd;
+  const int p_out = most(c.d_model / 2), p_fc1 = 2 * most(c.d_ff / 2), p_qkv = most((nqkv + 1) / 2), p_hd = most((c.n_codebooks * c.vocab_head + 1) / 2);
+  if (p_out > ZN_SK_CW * 2 || p_out > 5 || p_fc1 > ZN_SK_CW * 10 || p_qkv > ZN_SK_CW * 6 || p_hd > ZN_SK_CW * 6) return false;   // the static schedule <4, 2, 10, 5, 6>
+  if (p_out * 2 > 64 || p_fc1 > 64 || p_qkv * 2 > 64 || p_hd * 2 > 64 || nqkv % 2) return false;                               // one epilogue lane per (unit, row)
+  // every workgroup of the grid must be resident at once (the hand-offs wait on all of them): one per CU by its LDS, no scratch
+  int dev = 0, n_cus = 0, per_cu = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) { (void)hipGetLastError(); return false; }
+  if (hipFuncSetAttribute((const void*)step_kernel<ZN_SK_T>, hipFuncAttributeMaxDynamicSharedMemorySize, ZN_SK_DYN_LDS) != hipSuccess) { (void)hipGetLastError(); return false; }
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, step_kernel<ZN_SK_T>, ZN_SK_THREADS, ZN_SK_DYN_LDS) != hipSuccess) { (void)hipGetLastError(); return false; }
+  hipFuncAttributes fa{};
+  if (hipFuncGetAttributes(&fa, (const void*)step_kernel<ZN_SK_T>) != hipSuccess) { (void)hipGetLastError(); return false; }
+  return per_cu >= 1 && n_cus >= ZN_CH_GRID && fa.localSizeBytes == 0;
 }
 static bool stack_active(zn_handle h, int rows, int keys_upper_bound) {
-  return chain_active(h, rows) && h->tune[15] == 3 && keys_upper_bound <= ZN_ST_MAXKEYS && h->stack_ok;
+  return chain_active(h, rows) && h->tune[15] != 2 && keys_upper_bound <= ZN_SK_MAXKEYS && h->stack_ok;
 }
 static int launch_stack(zn_handle h, hipStream_t s) {
   const zn_config& c = h->cfg;
@@ -626,13 +641,13 @@ static int launch_stack(zn_handle h, hipStream_t s) {
   a.eps = c.norm_eps; a.F = c.d_ff; a.nqkv = (c.n_heads + 2 * c.n_heads_kv) * h->hd;
   a.xin = h->x_emb; a.xout = h->x;
   a.g_y1 = h->ch_gy1; a.g_x1 = h->ch_gx1; a.g_x2 = h->ch_gx2; a.g_m = h->ch_gm; a.g_qkv = h->ch_gqkv; a.g_a = h->ch_ga;
-  a.epoch = h->ch_epoch; a.tmo = &h->st->pad[0];
+  a.epoch = h->ch_epoch; a.tmo = &h->st->pad[0]; a.diag = h->ch_diag;
   a.stamps = h->ch_stamps; a.stamp_layer = c.n_layer / 2;
   a.rope = h->rope; a.lengths = h->lengths; a.max_len = h->max_len; a.hd = h->hd; a.n_heads = c.n_heads; a.n_heads_kv = c.n_heads_kv;
   a.rope_positions = c.rope_positions;
   a.layers = h->stack_layers; a.n_layer = c.n_layer; a.q0 = h->q; a.scale = (float)(1.0 / std::sqrt((double)h->hd));
   a.heads_rows = c.n_codebooks * c.vocab_head; a.heads_out = h->logits_raw; a.trace = h->dbg_trace;
-  hipLaunchKernelGGL((stack_kernel<4, 1, 8, 4, 5>), dim3(ZN_CH_GRID), dim3(ZN_CH_THREADS), ZN_CH_DYN_LDS, s, a);
+  hipLaunchKernelGGL((step_kernel<ZN_SK_T>), dim3(ZN_CH_GRID), dim3(ZN_SK_THREADS), ZN_SK_DYN_LDS, s, a);
   return ZN_OK;
 }
 // device table of the whole-step kernel (KV cache pointers of this generation)
@@ -1237,11 +1252,14 @@ extern "C" int zn_decode_steps(zn_handle h, int32_t n, zn_stream stream) {
   for (int i = 0; i < n;) {
     // this step appends one key per row; a run of ZN_GRAPH_STEPS steps with one launch shape replays the long graph
     const bool fused = attn_fused_for(h, h->len_hi + 1);
-    const int run = (n - i >= ZN_GRAPH_STEPS && h->tune[6] > 1 && attn_fused_for(h, h->len_hi + ZN_GRAPH_STEPS) == fused) ? ZN_GRAPH_STEPS : 1;
-    // (the whole-step kernel computes the fused attention launch's arithmetic: it serves exactly the steps that launch would serve,
-    // so that switching it on never changes a result; the two-pass launches of longer contexts sum the scores in another order)
-    const bool stack = fused && tail_fused(h) && stack_active(h, h->rows, h->len_hi + run);
-    const int k = (fused ? 1 : 0) | (run > 1 ? 2 : 0) | (stack ? 4 : 0);
+    const bool want_run = n - i >= ZN_GRAPH_STEPS && h->tune[6] > 1;
+    // the whole-step kernel serves every step whose context fits its two 512-key blocks (its attention is the fused launch's arithmetic;
+    // the two-pass launches of the per-block path at contexts above tune[5] sum q.k in another order, within the same tolerance)
+    const bool st_ok = tail_fused(h);
+    const bool stack_run = st_ok && want_run && stack_active(h, h->rows, h->len_hi + ZN_GRAPH_STEPS);
+    const bool stack = stack_run || (st_ok && stack_active(h, h->rows, h->len_hi + 1));
+    const int run = stack ? (stack_run ? ZN_GRAPH_STEPS : 1) : ((want_run && attn_fused_for(h, h->len_hi + ZN_GRAPH_STEPS) == fused) ? ZN_GRAPH_STEPS : 1);
+    const int k = stack ? (4 | (run > 1 ? 2 : 0)) : ((fused ? 1 : 0) | (run > 1 ? 2 : 0));
     h->attn_fused = fused; h->use_stack = stack;
     if (!h->graph_exec[k] && !h->graph_tried[k] && n > 1) {
       // capture; every step-varying quantity (column, positions) is read from device memory
@@ -1267,10 +1285,29 @@ extern "C" int zn_decode_steps(zn_handle h, int32_t n, zn_stream stream) {
 }
 
 extern "C" int zn_decode_path(zn_handle h) { return (h && h->gen_active && h->cfg.arch == 0 && chain_active(h, h->rows)) ? 1 : 0; }
+extern "C" int zn_decode_path_detail(zn_handle h) {
+  if (!h || !h->gen_active || h->cfg.arch != 0 || !chain_active(h, h->rows)) return 0;
+  return h->use_stack ? 2 : 1;
+}
 extern "C" int zn_graph_active(zn_handle h) {
   if (!h) return 0;
   for (int k = 0; k < 8; ++k) if (h->graph_exec[k]) return 1;
   return 0;
+}
+
+// A bounded hand-off wait of the persistent kernels gave up (sweep_granules): the generation's results are void.  The message names the
+// wait (stage: 1 y1, 2 x1, 3 m, 4 x2, 5 q|k|v, 6 attention output; block; workgroup; wave; the tag waited for and the first stale granule),
+// the handle falls back to one launch per op (no in-launch hand-offs) for its later generations, and the sticky word is cleared so
+// that a new generation can run.
+static int handoff_timeout(zn_handle h, int count) {
+  (void)hipMemcpy(h->diag_host, h->ch_diag, sizeof h->diag_host, hipMemcpyDeviceToHost);
+  (void)hipMemset(h->ch_diag, 0, 64);
+  (void)hipMemset(&h->st->pad[0], 0, sizeof(int));
+  h->tune[8] = 2; free_graph(h);
+  const unsigned* d = h->diag_host;
+  ZN_FAIL(h, ZN_ERR_HIP, "decode chain: %d hand-off wait(s) timed out - the results of this generation are invalid. First: stage %u of block %u, workgroup %u wave %u lane %u "
+          "waited for tag %u, granule at byte %u carried tag %u after %u passes. This handle now runs the launches path (zn_debug_tune(8, 1) re-enables the persistent kernels)",
+          count, d[0] >> 8, d[0] & 255u, d[1], d[2], d[6], d[3], d[4], d[5], d[7]);
 }
 
 extern "C" int zn_all_stopped(zn_handle h, int32_t* out, zn_stream stream) {
@@ -1280,8 +1317,7 @@ extern "C" int zn_all_stopped(zn_handle h, int32_t* out, zn_stream stream) {
   HIPCHK(h, hipMemcpyAsync(h->done_host, &h->st->all_done, 4 * sizeof(int), hipMemcpyDeviceToHost, s));
   HIPCHK(h, hipStreamSynchronize(s));
   *out = h->done_host[0];
-  if (h->done_host[3] != 0)
-    ZN_FAIL(h, ZN_ERR_HIP, "decode chain: a hand-off wait timed out (%d) - the results of this generation are invalid; zn_debug_tune(8, 2) selects the launches path", h->done_host[3]);
+  if (h->done_host[3] != 0) return handoff_timeout(h, h->done_host[3]);
   return ZN_OK;
 }
 
@@ -1301,8 +1337,7 @@ extern "C" int zn_all_stopped_end(zn_handle h, int32_t* out) {
   HIPCHK(h, hipEventSynchronize(h->stop_event));
   h->stop_pending = false;
   *out = h->done_host[4];
-  if (h->done_host[7] != 0)
-    ZN_FAIL(h, ZN_ERR_HIP, "decode chain: a hand-off wait timed out (%d) - the results of this generation are invalid; zn_debug_tune(8, 2) selects the launches path", h->done_host[7]);
+  if (h->done_host[7] != 0) return handoff_timeout(h, h->done_host[7]);
   return ZN_OK;
 }
 
@@ -1347,9 +1382,10 @@ extern "C" int zn_debug_eos_bias(zn_handle h, float bias) { if (!h) return ZN_ER
 extern "C" int zn_bench_kernel(zn_handle h, int32_t which, int32_t rows, int32_t iters, float* ms_per_launch, double* bytes_per_launch,
                                zn_stream stream) {
   if (!h) return ZN_ERR_ARG;
-  if (!ms_per_launch || !bytes_per_launch || iters < 1 || (rows & 0xff) < 1 || (rows & 0xff) > h->max_rows || which < 0 || which > 5)
+  if (!ms_per_launch || !bytes_per_launch || iters < 1 || (rows & 0xff) < 1 || (rows & 0xff) > h->max_rows || which < 0 || which > 6)
     ZN_FAIL(h, ZN_ERR_ARG, "zn_bench_kernel: bad argument");
   const bool same_layer = (rows & 0x100) != 0;   // measurement variant: keep hitting layer 0 (weights stay in the Infinity Cache)
+  const int ctx_arg = (rows >> 16) & 0x7fff;     // which == 6: keys already in the cache (0 = 450, the mean context of a 10 s utterance)
   rows &= 0xff;
   hipStream_t s = (hipStream_t)stream;
   const zn_config& c = h->cfg;
@@ -1364,6 +1400,33 @@ extern "C" int zn_bench_kernel(zn_handle h, int32_t which, int32_t rows, int32_t
     HIPCHK(h, hipMalloc(&tkv, (size_t)rows * 8 * 2 * nkv * 2));
     HIPCHK(h, hipMalloc(&tlen, (size_t)rows * sizeof(int)));
     HIPCHK(h, hipMemsetAsync(tlen, 0, (size_t)rows * sizeof(int), s));
+  }
+  // which == 6: the whole-step kernel (every block of a decode step + the heads in ONE launch) on a scratch cache of its own per layer,
+  // all rows at position ctx; the handle's generation state is put back afterwards
+  std::vector<void*> skv;
+  std::vector<const void*> saved_kv = h->kv_layers;
+  const int saved_max_len = h->max_len; int* const saved_lengths = h->lengths;
+  const int ctx = ctx_arg > 0 ? ctx_arg : 450;
+  if (which == 6) {
+    if (!chain_active(h, rows)) ZN_FAIL(h, ZN_ERR_UNSUPPORTED, "zn_bench_kernel: the whole-step kernel serves batch 1 (2 rows) of the transformer only");
+    if (!h->stack_checked) { h->stack_ok = stack_shapes_ok(h); h->stack_checked = true; }
+    if (!h->stack_ok || ctx + 1 > ZN_SK_MAXKEYS) ZN_FAIL(h, ZN_ERR_UNSUPPORTED, "zn_bench_kernel: the whole-step kernel does not serve this model / context");
+    const int cap = ctx + 8;
+    std::vector<int> lens(rows, ctx);
+    HIPCHK(h, hipMalloc(&tlen, (size_t)rows * sizeof(int)));
+    HIPCHK(h, hipMemcpy(tlen, lens.data(), (size_t)rows * sizeof(int), hipMemcpyHostToDevice));
+    skv.assign(c.n_layer, nullptr);
+    h->kv_layers.assign(c.n_layer, nullptr);
+    for (int li = 0; li < c.n_layer; ++li) {
+      HIPCHK(h, hipMalloc(&skv[li], (size_t)rows * cap * 2 * nkv * 2));
+      HIPCHK(h, hipMemsetAsync(skv[li], 0, (size_t)rows * cap * 2 * nkv * 2, s));
+      h->kv_layers[li] = skv[li];
+    }
+    h->max_len = cap; h->lengths = tlen;
+    HIPCHK(h, hipMemsetAsync(h->x_emb, 0, (size_t)rows * d * 2, s));
+    HIPCHK(h, hipMemsetAsync(h->q, 0, (size_t)rows * d * 2, s));
+    int rcb = build_stack_table(h);
+    if (rcb) return rcb;
   }
   hipEvent_t e0, e1;
   HIPCHK(h, hipEventCreate(&e0));
@@ -1384,6 +1447,8 @@ extern "C" int zn_bench_kernel(zn_handle h, int32_t which, int32_t rows, int32_t
       } else if (which == 2) {
         a.W = (const bf16_t*)lw.out_proj; a.N = d; a.K = c.n_heads * h->hd; a.x = h->o1; a.resid = h->x; a.out = h->x;
         rc = run_gemv<PRO_NONE, EPI_RESID>(h, a, rows, h->tune[1], s);
+      } else if (which == 6) {
+        rc = launch_stack(h, s);
       } else if (which == 5) {
         if (i % c.n_layer == c.n_layer - 1) continue;       // the last block's launch has no in_proj: not the launch being priced
         rc = launch_chain(h, i % c.n_layer, std::vector<const void*>(c.n_layer, tkv), 8, tlen, s);
@@ -1405,6 +1470,14 @@ extern "C" int zn_bench_kernel(zn_handle h, int32_t which, int32_t rows, int32_t
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
   if (tkv) (void)hipFree(tkv);
   if (tlen) (void)hipFree(tlen);
+  if (which == 6) {
+    for (void* p : skv) if (p) (void)hipFree(p);
+    h->kv_layers = saved_kv; h->max_len = saved_max_len; h->lengths = saved_lengths;
+    if (h->gen_active && (int)h->kv_layers.size() == c.n_layer) { int rcb = build_stack_table(h); if (rcb) return rcb; }
+    int tmo = 0;
+    HIPCHK(h, hipMemcpy(&tmo, &h->st->pad[0], sizeof(int), hipMemcpyDeviceToHost));
+    if (tmo != 0) return handoff_timeout(h, tmo);
+  }
   int launches = iters;
   if (which == 5) { launches = 0; for (int i = 0; i < iters; ++i) launches += (i % c.n_layer != c.n_layer - 1); }
   *ms_per_launch = ms / launches;
@@ -1412,6 +1485,11 @@ extern "C" int zn_bench_kernel(zn_handle h, int32_t which, int32_t rows, int32_t
   const double wbytes = which == 5 ? ((double)d * nq + 3.0 * c.d_ff * d + (double)(nq + 2 * nkv) * d) * 2 : which == 0 ? 2.0 * c.d_ff * d * 2 : which == 1 ? (double)d * c.d_ff * 2 : which == 2 ? (double)d * c.n_heads * h->hd * 2
                         : which == 4 ? (double)(nq + 2 * nkv) * d * 2 : (double)c.n_codebooks * c.vocab_head * d * 2;
   *bytes_per_launch = wbytes;   // algorithmic bytes = the weight matrix, read once (activations are KBs)
+  if (which == 6) {             // every block's out_proj (once), fc1, fc2; the in_proj of blocks 1 .. n-1; the heads; K and V of `ctx` keys read, one row written
+    const double per_block = ((double)d * nq + 3.0 * c.d_ff * d) * 2, inp = (double)(nq + 2 * nkv) * d * 2, kvpos = 2.0 * nkv * 2;
+    *bytes_per_launch = c.n_layer * per_block + (c.n_layer - 1) * inp + (double)c.n_codebooks * c.vocab_head * d * 2 +
+                        (double)rows * c.n_layer * kvpos * ctx + (double)rows * (c.n_layer - 1) * kvpos;
+  }
   return ZN_OK;
 }
 

@@ -62,6 +62,7 @@ struct ChainArgs {
   float scale;                                             // 1 / sqrt(hd)
   int heads_rows;                                          // rows of the fused heads matrix (last block's op 4)
   bf16_t* trace;                                           // diagnostic [n_layer][8][2][d]: slot 0 x after the block, 1 attention output, 2 q
+  unsigned* diag;                                          // [8] words describing the first hand-off wait that timed out (sweep_granules)
 };
 struct StackLayer {
   const bf16_t *W_out, *W_fc1, *W_fc2, *W_in;              // W_in = NEXT block's in_proj, or the heads matrix (last block)
@@ -85,11 +86,16 @@ ZN_DEVINL void st_granule(unsigned long long* g, unsigned tag, unsigned value) {
 }
 // One wave sweeps the 4 * N granules it needs (two per 16-byte sc1 load: .x/.z values, .y/.w tags; byte offsets off[]) until every
 // tag equals `tag`, re-reading all of them every pass; bounded.  data[i] = the eight bf16 of off[i].
+// A wait that gives up describes itself: the first wave to time out (tmo 0 -> 1) leaves, in diag[0..7], the caller's code
+// (stage << 8 | block), workgroup, wave, the tag it waited for, the byte offset and the tag of its first stale granule, the lane that
+// held it and the passes made; zn_all_stopped prints them.  Later waits see tmo != 0 and return at once (the results are void anyway).
+struct SweepWho { unsigned code; unsigned* diag; };
 template <int N>
-ZN_DEVINL bool sweep_granules(__amdgpu_buffer_rsrc_t rs, const int (&off)[N], unsigned tag, u32x4 (&data)[N], int* tmo, int lane, int* passes = nullptr) {
+ZN_DEVINL bool sweep_granules(__amdgpu_buffer_rsrc_t rs, const int (&off)[N], unsigned tag, u32x4 (&data)[N], int* tmo, int lane, SweepWho who, unsigned* passes_out = nullptr) {
   const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+  unsigned np = 0;
   for (;;) {
-    if (passes) ++*passes;
+    ++np;
     bool ok = true;
 #pragma unroll
     for (int i = 0; i < N; ++i) {
@@ -97,9 +103,22 @@ ZN_DEVINL bool sweep_granules(__amdgpu_buffer_rsrc_t rs, const int (&off)[N], un
       ok &= (l0.y == tag) & (l0.w == tag) & (l1.y == tag) & (l1.w == tag);
       data[i] = u32x4{l0.x, l0.z, l1.x, l1.z};
     }
-    if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) return true;
+    const unsigned long long bad = __builtin_amdgcn_ballot_w64(!ok);
+    if (bad == 0ull) { if (passes_out) *passes_out = np; return true; }
     if (__builtin_amdgcn_s_memrealtime() - t0 > ZN_CH_TIMEOUT_TICKS || __hip_atomic_load(tmo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
-      if (lane == 0) atomicAdd(tmo, 1);
+      if (lane == (int)__builtin_ctzll(bad) && atomicAdd(tmo, 1) == 0 && who.diag) {
+        unsigned badoff = 0xffffffffu, badtag = 0;            // the first stale granule of this lane, read once more
+#pragma unroll
+        for (int i = N - 1; i >= 0; --i) {
+          const u32x4 l0 = ld_sc1_16(rs, off[i]), l1 = ld_sc1_16(rs, off[i] + 16);
+          if (l1.w != tag) { badoff = off[i] + 24; badtag = l1.w; }
+          if (l1.y != tag) { badoff = off[i] + 16; badtag = l1.y; }
+          if (l0.w != tag) { badoff = off[i] + 8; badtag = l0.w; }
+          if (l0.y != tag) { badoff = off[i]; badtag = l0.y; }
+        }
+        who.diag[0] = who.code; who.diag[1] = blockIdx.x; who.diag[2] = threadIdx.x >> 6; who.diag[3] = tag;
+        who.diag[4] = badoff; who.diag[5] = badtag; who.diag[6] = (unsigned)lane; who.diag[7] = np;
+      }
       return false;
     }
   }
@@ -121,245 +140,6 @@ ZN_DEVINL void chain_layernorm_row(u32x4 (&x)[NCH], const u32x4 (&lng)[NCH], con
   for (int c = 0; c < NCH; ++c) x[c] = ln_norm8(x[c], mean, rstd, lng[c], lnb[c]);
 }
 
-
-// ---------------------------------------------------------------------------------------------- attention inside the stack
-// attn_pv_kernel<128, 4, 1>'s arithmetic (zn_decode_kernels.h: MFMA scores into LDS, block maxima, e / P / P.V per key in the
-// same per-lane order, the same DPP + LDS reduction tree) run by the workgroup's ZN_CH_CWAVES compute waves: real wave w plays
-// the fused kernel's waves w and w + 4 one after the other (a "virtual wave" owns keys 16 vw + 128 i + 512 j + (lane >> 2)).
-// q and the newest key / value row come from LDS (handed over as granules inside this launch); older rows from the cache.
-#define ZN_ST_MAXKEYS 1024                                  // two 512-key blocks: the host sends longer contexts down the per-block path
-struct StackAttnLds {
-  float sc[4][ZN_ST_MAXKEYS];                               // scores [head][key]
-  float bm[ZN_ST_MAXKEYS / 512][8][4];                      // per (block, virtual wave, head) maxima
-  float acc[32][4][32];                                     // per (virtual wave, 16-lane row) partial P.V
-  float l[8][4];
-  __attribute__((aligned(16))) bf16_t k[ZN_CH_CWAVES][16 * (128 + 8)];   // per real wave: 16 key rows, padded
-  __attribute__((aligned(16))) bf16_t q[4][128];            // the kv head's 4 query heads
-  __attribute__((aligned(16))) bf16_t knew[128], vnew[128]; // newest key / value row of the kv head
-  __attribute__((aligned(16))) bf16_t out[4][32];           // result slice
-};
-static_assert(sizeof(StackAttnLds) <= 60 * 1024, "fits the launch's dynamic LDS");
-
-// K rows of virtual wave vw, block j (16 keys per tile, 4 tiles): whole 256-byte rows, clamped to the rows that are in the cache
-// (the newest row, L - 1, is patched in from LDS at use).  Independent of q: the first batch is requested before q arrives.
-ZN_DEVINL void stack_attn_issue_k(u32x4 (&kk)[4][4], const bf16_t* kv, int r, int kvh, int L, int max_len, int n_heads_kv, int vw, int j, int lane) {
-  constexpr int HD = 128, NW = 8, LPK = HD / 8, KPL = 64 / LPK;
-  const size_t kvrow = (size_t)2 * n_heads_kv * HD;
-  const int kq = lane / LPK, kd = lane % LPK;
-  const bf16_t* kbase = kv + (size_t)r * max_len * kvrow + (size_t)kvh * HD + kd * 8;
-  const int hi = L - 2 >= 0 ? L - 2 : 0;
-#pragma unroll
-  for (int tl = 0; tl < 4; ++tl)
-#pragma unroll
-    for (int i = 0; i < 4; ++i) kk[tl][i] = ld16(kbase + (size_t)min(j * 512 + (tl * NW + vw) * 16 + KPL * i + kq, hi) * kvrow);
-}
-
-// value pieces (this lane's 16 B of the 32-wide slice) of virtual wave vw, block j: 4 rounds of 128 keys
-ZN_DEVINL void stack_attn_issue_v(u32x4 (&vv)[4], const bf16_t* kv, int r, int kvh, int slice, int L, int max_len, int n_heads_kv, int vw, int j, int lane) {
-  constexpr int HD = 128, NW = 8;
-  const size_t kvrow = (size_t)2 * n_heads_kv * HD;
-  const int vsub = lane & 3, vkey = lane >> 2;
-  const bf16_t* vbase = kv + (size_t)r * max_len * kvrow + (size_t)(n_heads_kv + kvh) * HD + slice * 32 + vsub * 8;
-  const int hi = L - 2 >= 0 ? L - 2 : 0;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) vv[i] = ld16(vbase + (size_t)min(j * 512 + i * (NW * 16) + vw * 16 + vkey, hi) * kvrow);
-}
-
-// One tile (16 keys) of K rows of (virtual wave vw, block j) into kk: see stack_attn_issue_k.
-ZN_DEVINL void stack_attn_issue_k_tile(u32x4 (&kk)[4], const bf16_t* kv, int r, int kvh, int L, int max_len, int n_heads_kv, int vw, int j, int tl, int lane) {
-  constexpr int HD = 128, NW = 8, LPK = HD / 8, KPL = 64 / LPK;
-  const size_t kvrow = (size_t)2 * n_heads_kv * HD;
-  const int kq = lane / LPK, kd = lane % LPK;
-  const bf16_t* kbase = kv + (size_t)r * max_len * kvrow + (size_t)kvh * HD + kd * 8;
-  const int hi = L - 2 >= 0 ? L - 2 : 0;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) kk[i] = ld16(kbase + (size_t)min(j * 512 + (tl * NW + vw) * 16 + KPL * i + kq, hi) * kvrow);
-}
-
-// kk / vvA = key rows / value pieces of the first batch (virtual wave rw, block 0), requested by the caller ahead of the q hand-off
-// (they do not depend on q).  A wave walks 2 * nb batches (virtual wave rw + 4 * (b & 1), block b >> 1) for the scores, refilling
-// each tile's registers with the next batch's tile as soon as the tile is staged in LDS, and the same batches (virtual wave outer,
-// block inner) for pass 2 with the next batch's value pieces in flight: one set of K registers, two of V.
-ZN_DEVINL void stack_attention(StackAttnLds& S, u32x4 (&kk)[4][4], u32x4 (&vvA)[4], const bf16_t* kv, int r, int kvh, int slice, int L,
-                               int max_len, int n_heads_kv, float scale, int rw, int lane, unsigned long long* st = nullptr) {
-  auto stamp = [&](int i) { if (st && rw == 0 && lane == 0) st[i] = __builtin_amdgcn_s_memrealtime(); };
-  stamp(0);
-  constexpr int HD = 128, G = 4, NW = 8, NR = 4, KST = HD / 32, TPW = 4;
-  constexpr int KLD = HD + 8, LPK = HD / 8, KPL = 64 / LPK, NLD = 16 / KPL;
-  typedef __attribute__((ext_vector_type(4))) float f32x4_t;
-  const int nb = (L + 511) >> 9;
-  const int kn = lane & 15, kg = lane >> 4;
-  const int kq = lane / LPK, kd = lane % LPK;
-  zn_bf16x8 qa[KST];
-#pragma unroll
-  for (int st = 0; st < KST; ++st) {
-    u32x4 v = u32x4{0, 0, 0, 0};
-    if (kn < G) v = *(const u32x4*)&S.q[kn][32 * st + 8 * kg];
-    qa[st] = __builtin_bit_cast(zn_bf16x8, v);
-  }
-  bf16_t* kw = &S.k[rw][0];
-  const u32x4 knew_piece = *(const u32x4*)&S.knew[kd * 8];
-  stamp(1);
-  // ---- scores, batch by batch
-#pragma unroll 1
-  for (int b = 0; b < 2 * nb; ++b) {
-    const int vw = rw + ZN_CH_CWAVES * (b & 1), j = b >> 1;
-    const int vwn = rw + ZN_CH_CWAVES * ((b + 1) & 1), jn = (b + 1) >> 1;
-    const bool more = b + 1 < 2 * nb;
-    const int tb = j * 512, tend = min(L, tb + 512);
-    float mx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-#pragma unroll
-    for (int tl = 0; tl < TPW; ++tl) {
-      const int tt = tb + (tl * NW + vw) * 16;
-      if (tt < tend) {                                          // wave-uniform
-#pragma unroll
-        for (int i = 0; i < NLD; ++i) {                         // the newest row is not in the cache for this launch's readers: from LDS
-          const u32x4 piece = (tt + KPL * i + kq >= L - 1) ? knew_piece : kk[tl][i];
-          *(u32x4*)(kw + (KPL * i + kq) * KLD + kd * 8) = piece;
-        }
-      }
-      if (more) stack_attn_issue_k_tile(kk[tl], kv, r, kvh, L, max_len, n_heads_kv, vwn, jn, tl, lane);   // the registers are free: next batch's tile
-      if (tt < tend) {
-        f32x4_t c = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int st = 0; st < KST; ++st) {
-          const u32x4 bfrag = *(const u32x4*)(kw + kn * KLD + 32 * st + 8 * kg);
-          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa[st], __builtin_bit_cast(zn_bf16x8, bfrag), c, 0, 0, 0);
-        }
-        const int t = tt + kn;
-#pragma unroll
-        for (int reg = 0; reg < 4; ++reg) {
-          const int head = 4 * kg + reg;
-          if (head < G && t < tend) {
-            const float sv = __fmul_rn(c[reg], scale);
-            mx[reg] = fmaxf(mx[reg], sv);
-            S.sc[head][t] = sv;
-          }
-        }
-      }
-    }
-#pragma unroll
-    for (int g = 0; g < G; ++g) {
-      const float m = wave_max(kg == g / 4 ? mx[g % 4] : -INFINITY);
-      if (lane == 0) S.bm[j][vw][g] = m;
-    }
-    stamp(2 + (b < 4 ? b : 3));
-  }
-  __syncthreads();                                          // A2: every score and block maximum is in LDS
-  stamp(6);
-  // ---- pass 2: virtual wave outer, block inner; batch c = v2 * nb + j
-  const int vsub = lane & 3, vkey = lane >> 2, row = lane >> 4;
-  const u32x4 vnew_piece = *(const u32x4*)&S.vnew[slice * 32 + vsub * 8];
-  u32x4 vvB[NR];
-  float acc[G][8], lsum = 0.f, m_run = -INFINITY;
-#pragma unroll 1
-  for (int cb = 0; cb < 2 * nb; ++cb) {
-    const int v2 = cb >= nb ? 1 : 0, j = cb - v2 * nb;
-    const int vw = rw + ZN_CH_CWAVES * v2;
-    if (j == 0) {
-      lsum = 0.f; m_run = -INFINITY;
-#pragma unroll
-      for (int g = 0; g < G; ++g)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) acc[g][e] = 0.f;
-    }
-    // this batch's value pieces are in vvA (even cb) or vvB (odd cb); request the next batch's into the other set
-    {
-      const int cn = cb + 1, v2n = cn >= nb ? 1 : 0, jn = cn - v2n * nb;
-      if (cn < 2 * nb) {
-        if (cb & 1) stack_attn_issue_v(vvA, kv, r, kvh, slice, L, max_len, n_heads_kv, rw + ZN_CH_CWAVES * v2n, jn, lane);
-        else stack_attn_issue_v(vvB, kv, r, kvh, slice, L, max_len, n_heads_kv, rw + ZN_CH_CWAVES * v2n, jn, lane);
-      }
-    }
-    const int t0 = j * 512, nkeys = min(512, L - t0);
-    u32x4 vv[NR];
-    float sc[NR];
-#pragma unroll
-    for (int i = 0; i < NR; ++i) {
-      const int idx = i * (NW * 16) + vw * 16 + vkey;
-      const bool ok = idx < nkeys;
-      u32x4 v = (cb & 1) ? vvB[i] : vvA[i];
-      if (t0 + idx >= L - 1) v = vnew_piece;
-      vv[i] = ok ? v : u32x4{0, 0, 0, 0};
-      sc[i] = ok ? S.sc[vsub][t0 + idx] : 0.f;
-    }
-    float bm = S.bm[j][lane >> 3][vsub];
-    bm = fmaxf(bm, dpp_mov<ZN_DPP_ROR4>(bm));
-    bm = fmaxf(bm, dpp_mov<ZN_DPP_ROR8>(bm));
-    bm = fmaxf(bm, __shfl_xor(bm, 16));
-    bm = fmaxf(bm, __shfl_xor(bm, 32));
-    const float mnew = fmaxf(m_run, bm);
-    const float f = (j == 0) ? 0.f : expf(m_run - mnew);
-    m_run = mnew;
-    lsum = __fmul_rn(lsum, f);
-#pragma unroll
-    for (int g = 0; g < G; ++g) {
-      float fg = f;
-      fg = (g % 4 == 0) ? dpp_mov<0x00>(fg) : (g % 4 == 1) ? dpp_mov<0x55>(fg) : (g % 4 == 2) ? dpp_mov<0xAA>(fg) : dpp_mov<0xFF>(fg);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) acc[g][e] = __fmul_rn(acc[g][e], fg);
-    }
-    const int nblk = min(512, L - t0), nvec = nblk & ~15;      // decode steps: the reference's block loop spans exactly the context
-#pragma unroll
-    for (int i = 0; i < NR; ++i) {
-      const int base = i * (NW * 16);
-      const int idx = base + vw * 16 + vkey;
-      const bool ok = idx < nkeys;
-      float ev;
-      if (base + NW * 16 <= nvec) ev = ok ? zn_fexp_u20(__fsub_rn(sc[i], mnew)) : 0.f;
-      else {
-        const float x = __fsub_rn(sc[i], mnew);
-        ev = ok ? ((idx < nvec) ? zn_fexp_u20(x) : expf(x)) : 0.f;
-      }
-      lsum += ev;
-      const float v0 = lo_f(vv[i].x), v1 = hi_f(vv[i].x), v2f = lo_f(vv[i].y), v3 = hi_f(vv[i].y);
-      const float v4 = lo_f(vv[i].z), v5 = hi_f(vv[i].z), v6 = lo_f(vv[i].w), v7 = hi_f(vv[i].w);
-#pragma unroll
-      for (int g = 0; g < G; ++g) {
-        float pr = bfround(ev);
-        pr = (g % 4 == 0) ? dpp_mov<0x00>(pr) : (g % 4 == 1) ? dpp_mov<0x55>(pr) : (g % 4 == 2) ? dpp_mov<0xAA>(pr) : dpp_mov<0xFF>(pr);
-        acc[g][0] = fmaf(pr, v0, acc[g][0]); acc[g][1] = fmaf(pr, v1, acc[g][1]);
-        acc[g][2] = fmaf(pr, v2f, acc[g][2]); acc[g][3] = fmaf(pr, v3, acc[g][3]);
-        acc[g][4] = fmaf(pr, v4, acc[g][4]); acc[g][5] = fmaf(pr, v5, acc[g][5]);
-        acc[g][6] = fmaf(pr, v6, acc[g][6]); acc[g][7] = fmaf(pr, v7, acc[g][7]);
-      }
-    }
-    if (j == nb - 1) {
-      // this virtual wave is complete: 4 key lanes per 16-lane row by DPP, the rows through LDS in the fused kernel's order
-#pragma unroll
-      for (int g = 0; g < G; ++g) {
-        float red[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) red[e] = row_stride4_sum(acc[g][e]);
-        if ((lane & 15) < 4) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) S.acc[vw * 4 + row][g][(lane & 3) * 8 + e] = red[e];
-        }
-      }
-      float ls = row_stride4_sum(lsum);
-      ls = (readlane_f(ls, 0) + readlane_f(ls, 16)) + (readlane_f(ls, 32) + readlane_f(ls, 48));
-      float l1 = row_stride4_sum(lsum); l1 = (readlane_f(l1, 1) + readlane_f(l1, 17)) + (readlane_f(l1, 33) + readlane_f(l1, 49));
-      float l2 = row_stride4_sum(lsum); l2 = (readlane_f(l2, 2) + readlane_f(l2, 18)) + (readlane_f(l2, 34) + readlane_f(l2, 50));
-      float l3 = row_stride4_sum(lsum); l3 = (readlane_f(l3, 3) + readlane_f(l3, 19)) + (readlane_f(l3, 35) + readlane_f(l3, 51));
-      if (lane == 0) { S.l[vw][0] = ls; S.l[vw][1] = l1; S.l[vw][2] = l2; S.l[vw][3] = l3; }
-    }
-    stamp(7 + (cb < 4 ? cb : 3));
-  }
-  stamp(11);
-  __syncthreads();                                          // A3: partial sums of all 8 virtual waves
-  stamp(12);
-  const int tid = rw * 64 + lane;
-  if (tid < G * 32) {
-    const int g = tid >> 5, d = tid & 31;
-    float v = 0.f, l = 0.f;
-#pragma unroll
-    for (int w = 0; w < NW * 4; ++w) v += S.acc[w][g][d];
-#pragma unroll
-    for (int w = 0; w < NW; ++w) l += S.l[w][g];
-    S.out[g][d] = f2bf(__fmul_rn(v, 1.0f / l));
-  }
-  stamp(13);
-}
 
 // T_* = tiles per compute wave per op (upper bounds; a wave skips the tiles its workgroup does not have).  d_model =
 // 512 * NCH, d_ff = 4 * d_model; every op's units divide evenly over the grid (host-checked).
@@ -480,7 +260,7 @@ __global__ __launch_bounds__(ZN_CH_THREADS) void chain_kernel(ChainArgs a) {
           for (int c2 = 0; c2 < NCH; ++c2)
 #pragma unroll
             for (int r = 0; r < R; ++r) off[c2 * R + r] = (r * (2 * D) + qt * (D / 2) + (c2 * 64 + lane) * 4) * 8;
-          sweep_granules<NCH * R>(zn_rsrc(a.g_m), off, tag, dat, a.tmo, lane);
+          sweep_granules<NCH * R>(zn_rsrc(a.g_m), off, tag, dat, a.tmo, lane, SweepWho{(3u << 8) | (unsigned)a.stamp_layer, a.diag});
 #pragma unroll
           for (int c2 = 0; c2 < NCH; ++c2)
 #pragma unroll
@@ -601,9 +381,9 @@ __global__ __launch_bounds__(ZN_CH_THREADS) void chain_kernel(ChainArgs a) {
       if constexpr (op != 2) {                             // (fc2's input is swept by the compute waves)
         // (requesting the first pass ahead of the compute waves' held-back requests was measured slower, 1.089 vs 1.023 ms per step: it
         // comes back before the slowest publishers' stores are visible, and the second pass then queues behind those requests)
-        int passes = 0;
-        sweep_granules<NCH>(zn_rsrc(op == 0 ? a.g_y1 : op == 1 ? a.g_x1 : a.g_x2), goff, tag, g, a.tmo, lane, a.stamps ? &passes : nullptr);
-        if (a.stamps && epi && c == 0 && lane == 0) a.stamps[24 + op] = (unsigned long long)passes;
+        sweep_granules<NCH>(zn_rsrc(op == 0 ? a.g_y1 : op == 1 ? a.g_x1 : a.g_x2), goff, tag, g, a.tmo, lane,
+                            SweepWho{((op == 0 ? 1u : op == 1 ? 2u : 4u) << 8) | (unsigned)a.stamp_layer, a.diag},
+                            (a.stamps && epi && c == 0 && lane == 0) ? (unsigned*)(a.stamps + 24 + op) : nullptr);
         stamp();
         if constexpr (op == 1 || op == 3) chain_layernorm_row<NCH>(g, op == 1 ? l2w : lnw, op == 1 ? l2b : lnbb, a.eps);
 #pragma unroll

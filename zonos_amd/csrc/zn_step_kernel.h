@@ -1,0 +1,639 @@
+// Whole decode step of the transformer stack at batch 1 (R = 2 rows) in ONE persistent launch, second design (round 3).
+//
+// 256 workgroups of 8 waves, one per CU, in two fixed roles:
+//
+//  * 32 ATTENTION workgroups (one per (row, kv head, 32-wide value slice), as attn_pv_kernel<128, 4, 1>'s fused grid) carry NO weight
+//    tiles.  All eight waves run the fused launch's arithmetic (MFMA scores into LDS, block maxima, e / P / P.V per key in the same
+//    per-lane order, the same DPP + LDS reduction tree: results bit-identical to that launch).  Their whole register budget holds
+//    K (both 512-key blocks: 128 VGPRs) and V (32 VGPRs) of the NEXT block's cache, requested as soon as the block's result is
+//    published — a whole block (~20 us) before q arrives, so the attention of a block is two
+//    hand-offs plus ~3.5 us of arithmetic, and nothing in it waits for memory.  (_torch.py:376-420)
+//  * 224 STREAMING workgroups split every weight matrix of the block (out_proj, fc1, fc2, next in_proj / heads) with chain_kernel's
+//    static tile schedule: 4 compute waves, 2 communication waves (one per activation row), 2 idle waves (the launch's shape is
+//    the attention's).  While the attention runs they have nothing to wait for but weights: each compute wave streams the first
+//    ZN_SK_PARK tiles of the block through its register buffers into LDS ("parked" tiles, 128 KB per CU) and leaves ZN_SK_NBUF more
+//    in flight in registers — 7 of its ~17 tiles (~50 MB chip-wide, ~40 % of the block's weights) are on chip before op 0's input
+//    exists.  (_torch.py:307-328)
+//
+// Hand-offs are chain_kernel's tagged granules (tag = epoch + block).  Reuse of a granule buffer block after block is safe
+// because every streaming workgroup publishes in every op 0-3 and every sweep covers the whole vector: a workgroup can publish
+// stage s of block b + 1 only after EVERY streaming workgroup has published stage s' > s of block b, i.e. after each of them has
+// finished sweeping stage s of block b; the attention workgroups' stages (q|k|v in, attention output out) sit inside that
+// chain: an attention workgroup publishes g_a(b + 1) only after its own sweep of g_qkv(b), and no workgroup writes g_qkv(b + 1)
+// before it has swept all of g_a(b + 1).  A consumer therefore never sees a tag newer than the one it waits for, and the sweeps
+// compare for equality.  Every wait is bounded and describes itself when it gives up (sweep_granules, SweepWho).
+//
+// Results (codes, logits) are bit-identical to the per-block path with the fused attention launch.
+#pragma once
+#include "zn_chain_kernel.h"
+
+#define ZN_SK_THREADS 512
+#define ZN_SK_CW 4                                          // compute waves of a streaming workgroup (waves 4, 5: communication; 6, 7: idle)
+#ifndef ZN_SK_NBUF
+#define ZN_SK_NBUF 3                                        // register tile buffers per compute wave
+#endif
+#ifndef ZN_SK_PARK
+#define ZN_SK_PARK 4                                        // tiles per compute wave parked in LDS during the attention (>= T_OUT)
+#endif
+#define ZN_SK_MAXKEYS 1024                                  // two 512-key blocks: longer contexts go down the per-block path
+#define ZN_SK_DYN_LDS (ZN_SK_CW * ZN_SK_PARK * 8192)        // parked tiles (streaming role) / StepAttnLds (attention role)
+#ifndef ZN_SK_PACE_SHIFT
+#define ZN_SK_PACE_SHIFT 2                                  // a waiting wave sleeps through the first (1 - 2^-SHIFT) of the wait it measured one block earlier
+#endif
+
+struct StepAttnLds {
+  float sc[4][ZN_SK_MAXKEYS];                               // scores [head][key]
+  float bm[ZN_SK_MAXKEYS / 512][8][4];                      // per (block, wave, head) maxima
+  float acc[32][4][32];                                     // per (wave, 16-lane row) partial P.V
+  float l[8][4];
+  __attribute__((aligned(16))) bf16_t k[8][16 * (128 + 8)]; // per wave: 16 key rows, padded
+  __attribute__((aligned(16))) bf16_t q[4][128];            // the kv head's 4 query heads
+  __attribute__((aligned(16))) bf16_t knew[128], vnew[128]; // newest key / value row of the kv head
+  __attribute__((aligned(16))) bf16_t out[4][32];           // result slice
+};
+static_assert(sizeof(StepAttnLds) <= ZN_SK_DYN_LDS, "the attention role's LDS fits the launch's dynamic LDS");
+
+// A wave that waits for a hand-off far in the future (the attention workgroups for q|k|v, the streaming ones for the attention
+// output) sleeps through most of the wait it measured one block earlier instead of polling through it (polls sit in the CU's
+// memory queue in front of its own prefetch and load the fabric; megakernel price list "polling-cost").
+struct StepPacer {
+  unsigned long long t_ref; unsigned prev;
+  ZN_DEVINL void start() { t_ref = __builtin_amdgcn_s_memrealtime(); }
+  ZN_DEVINL void sleep() const {
+    const unsigned long long until = t_ref + (prev - (prev >> ZN_SK_PACE_SHIFT));
+    while (__builtin_amdgcn_s_memrealtime() < until) __builtin_amdgcn_s_sleep(8);
+  }
+  ZN_DEVINL void done() { prev = (unsigned)(__builtin_amdgcn_s_memrealtime() - t_ref); }
+};
+
+// ------------------------------------------------------------------------------------------------ attention role
+ZN_DEVINL void step_attention_role(const ChainArgs& a, StepAttnLds& S, const unsigned tag0, const int c, const int wave, const int lane) {
+  constexpr int HD = 128, G = 4, NW = 8, NR = 4, KST = HD / 32, TPW = 4, R = 2;
+  constexpr int KLD = HD + 8, LPK = HD / 8, KPL = 64 / LPK, NLD = 16 / KPL;
+  typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+  const int npairs = a.n_heads_kv * R;
+  const int pair = c % npairs, slice = c / npairs, kvh = pair % a.n_heads_kv, ar = pair / a.n_heads_kv;
+  const int nq = a.n_heads * HD, nk = a.n_heads_kv * HD, D = nq;
+  const int L = a.lengths[ar] + 1, nb = (L + 511) >> 9;     // keys including this step's; 1 or 2 blocks (host-checked)
+  const int hi = L >= 2 ? L - 2 : 0;                         // rows 0 .. L-2 are in the cache from earlier launches; row L-1 comes from LDS
+  const size_t kvrow = (size_t)2 * nk;
+  const int kn = lane & 15, kg = lane >> 4, kq = lane / LPK, kd = lane % LPK;
+  const int vsub = lane & 3, vkey = lane >> 2, row = lane >> 4;
+  const bool stamped = a.stamps && c == 0 && wave == 0 && lane == 0;
+  u32x4 kkA[TPW][NLD], kkB[TPW][NLD], vA[NR], vB[NR];
+  // Buffer loads with a 32-bit byte offset per request, recomputed at every issue from a value the optimiser cannot see through
+  // (`opq` = 0): hoisted out of the block loop, the 40 loop-invariant addresses stayed live beside the 160 K / V registers and spilled.
+  const int rowbytes = (int)kvrow * 2;
+  auto issue_k = [&](const bf16_t* kv, u32x4 (&kk)[TPW][NLD], int tb, int opq) {
+    const __amdgpu_buffer_rsrc_t rs = zn_rsrc(kv);
+    const int base = ar * a.max_len * rowbytes + (kvh * HD + kd * 8) * 2, r0 = opq + wave * 16 + kq;
+#pragma unroll
+    for (int tl = 0; tl < TPW; ++tl)
+#pragma unroll
+      for (int i = 0; i < NLD; ++i) kk[tl][i] = __builtin_amdgcn_raw_buffer_load_b128(rs, base + min(r0 + tb + tl * NW * 16 + KPL * i, hi) * rowbytes, 0, 0);
+  };
+  auto issue_v = [&](const bf16_t* kv, u32x4 (&vv)[NR], int tb, int opq) {
+    const __amdgpu_buffer_rsrc_t rs = zn_rsrc(kv);
+    const int base = ar * a.max_len * rowbytes + ((a.n_heads_kv + kvh) * HD + slice * 32 + vsub * 8) * 2, r0 = opq + wave * 16 + vkey;
+#pragma unroll
+    for (int i = 0; i < NR; ++i) vv[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, base + min(r0 + tb + i * (NW * 16), hi) * rowbytes, 0, 0);
+  };
+  {
+    const bf16_t* kv0 = a.layers[0].kv;
+    issue_k(kv0, kkA, 0, 0);
+    if (nb > 1) issue_k(kv0, kkB, 512, 0);
+    issue_v(kv0, vA, 0, 0);
+    if (nb > 1) issue_v(kv0, vB, 512, 0);
+  }
+  bf16_t* kw = &S.k[wave][0];
+  StepPacer pace{0ull, 0u};
+#pragma unroll 1
+  for (int li = 0; li < a.n_layer; ++li) {
+    const unsigned tag = tag0 + (unsigned)li;
+    const bool st_on = stamped && li == a.stamp_layer;
+    auto stamp = [&](int i) { if (st_on) a.stamps[32 + i] = __builtin_amdgcn_s_memrealtime(); };
+    stamp(0);
+    // ---- q (4 heads), newest key and value row of this kv head -> LDS
+    if (wave == ZN_SK_CW || wave == ZN_SK_CW + 1) {
+      const bool first = wave == ZN_SK_CW;
+      if (li == 0) {                                         // from the in_proj launch before this one: plain loads
+        if (first) *(u32x4*)&S.q[lane >> 4][(lane & 15) * 8] = ld16(a.q0 + ((size_t)ar * a.n_heads + kvh * G + (lane >> 4)) * HD + (lane & 15) * 8);
+        else if (lane < 32) {
+          const bf16_t* rowp = a.layers[0].kv + ((size_t)ar * a.max_len + (L - 1)) * kvrow + (size_t)(lane < 16 ? 0 : nk) + (size_t)kvh * HD + (lane & 15) * 8;
+          const u32x4 v = ld16(rowp);
+          if (lane < 16) *(u32x4*)&S.knew[lane * 8] = v; else *(u32x4*)&S.vnew[(lane - 16) * 8] = v;
+        }
+      } else {                                               // granules of the block before (tag - 1)
+        const int qoff = (ar * (a.nqkv / 2) + ((kvh * G) * HD) / 2 + lane * 4) * 8;
+        const int kvsel = lane < 16 ? nq + kvh * HD : nq + nk + kvh * HD;
+        const int koff = (ar * (a.nqkv / 2) + kvsel / 2 + (lane & 15) * 4) * 8;
+        int off1[1] = {first ? qoff : koff};
+        u32x4 d1[1];
+        pace.sleep();
+        sweep_granules<1>(zn_rsrc(a.g_qkv), off1, tag - 1u, d1, a.tmo, lane, SweepWho{(5u << 8) | (unsigned)li, a.diag});
+        pace.done();
+        if (first) *(u32x4*)&S.q[lane >> 4][(lane & 15) * 8] = d1[0];
+        else if (lane < 16) *(u32x4*)&S.knew[lane * 8] = d1[0];
+        else if (lane < 32) *(u32x4*)&S.vnew[(lane - 16) * 8] = d1[0];
+      }
+    }
+    __syncthreads();                                         // A1: q, newest key and value rows are in LDS
+    stamp(1);
+    // ---- scores of all keys on the matrix cores (attn_pv_kernel<128, 4, 1>, FUSED): S[head][key] as 16x16x32 tiles
+    {
+      zn_bf16x8 qa[KST];
+#pragma unroll
+      for (int st = 0; st < KST; ++st) {
+        u32x4 v = u32x4{0, 0, 0, 0};
+        if (kn < G) v = *(const u32x4*)&S.q[kn][32 * st + 8 * kg];
+        qa[st] = __builtin_bit_cast(zn_bf16x8, v);
+      }
+      const u32x4 knew_piece = *(const u32x4*)&S.knew[kd * 8];
+      auto block_scores = [&](u32x4 (&kk)[TPW][NLD], int j) {
+        float mx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        const int tb = j * 512, tend = min(L, tb + 512);
+#pragma unroll
+        for (int tl = 0; tl < TPW; ++tl) {
+          const int tt = tb + (tl * NW + wave) * 16;
+          if (tt < tend) {                                    // wave-uniform
+#pragma unroll
+            for (int i = 0; i < NLD; ++i) {                   // the newest row is not in the cache for this launch's readers: from LDS
+              const u32x4 piece = (tt + KPL * i + kq >= L - 1) ? knew_piece : kk[tl][i];
+              *(u32x4*)(kw + (KPL * i + kq) * KLD + kd * 8) = piece;
+            }
+            f32x4_t cc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int st = 0; st < KST; ++st) {
+              const u32x4 bfrag = *(const u32x4*)(kw + kn * KLD + 32 * st + 8 * kg);
+              cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa[st], __builtin_bit_cast(zn_bf16x8, bfrag), cc, 0, 0, 0);
+            }
+            const int t = tt + kn;
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+              const int head = 4 * kg + reg;
+              if (head < G && t < tend) {
+                const float sv = __fmul_rn(cc[reg], a.scale);
+                mx[reg] = fmaxf(mx[reg], sv);
+                S.sc[head][t] = sv;
+              }
+            }
+          }
+        }
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+          const float m = wave_max(kg == g / 4 ? mx[g % 4] : -INFINITY);
+          if (lane == 0) S.bm[j][wave][g] = m;
+        }
+      };
+      block_scores(kkA, 0);
+      if (nb > 1) block_scores(kkB, 1);
+    }
+    __syncthreads();                                         // A2: every score and block maximum is in LDS
+    stamp(2);
+    // ---- pass 2: the reference's recurrence over the 512-key blocks
+    {
+      const u32x4 vnew_piece = *(const u32x4*)&S.vnew[slice * 32 + vsub * 8];
+      float acc[G][8], lsum = 0.f, m_run = -INFINITY;
+#pragma unroll
+      for (int g = 0; g < G; ++g)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[g][e] = 0.f;
+#pragma unroll
+      for (int j = 0; j < ZN_SK_MAXKEYS / 512; ++j) {
+        if (j < nb) {                                          // wave-uniform
+          const int t0 = j * 512, nkeys = min(512, L - t0);
+          u32x4 vv[NR];
+          float sc[NR];
+#pragma unroll
+          for (int i = 0; i < NR; ++i) {
+            const int idx = i * (NW * 16) + wave * 16 + vkey;
+            const bool ok = idx < nkeys;
+            u32x4 v = j ? vB[i] : vA[i];
+            if (t0 + idx >= L - 1) v = vnew_piece;
+            vv[i] = ok ? v : u32x4{0, 0, 0, 0};
+            sc[i] = ok ? S.sc[vsub][t0 + idx] : 0.f;
+          }
+          float bm = S.bm[j][lane >> 3][vsub];
+          bm = fmaxf(bm, dpp_mov<ZN_DPP_ROR4>(bm));
+          bm = fmaxf(bm, dpp_mov<ZN_DPP_ROR8>(bm));
+          bm = fmaxf(bm, __shfl_xor(bm, 16));
+          bm = fmaxf(bm, __shfl_xor(bm, 32));
+          const float mnew = fmaxf(m_run, bm);
+          const float f = (j == 0) ? 0.f : expf(m_run - mnew);
+          m_run = mnew;
+          lsum = __fmul_rn(lsum, f);
+#pragma unroll
+          for (int g = 0; g < G; ++g) {
+            float fg = f;
+            fg = (g % 4 == 0) ? dpp_mov<0x00>(fg) : (g % 4 == 1) ? dpp_mov<0x55>(fg) : (g % 4 == 2) ? dpp_mov<0xAA>(fg) : dpp_mov<0xFF>(fg);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[g][e] = __fmul_rn(acc[g][e], fg);
+          }
+          const int nblk = min(512, L - t0), nvec = nblk & ~15;  // decode steps: the reference's block loop spans exactly the context
+#pragma unroll
+          for (int i = 0; i < NR; ++i) {
+            const int base = i * (NW * 16);
+            const int idx = base + wave * 16 + vkey;
+            const bool ok = idx < nkeys;
+            float ev;
+            if (base + NW * 16 <= nvec) ev = ok ? zn_fexp_u20(__fsub_rn(sc[i], mnew)) : 0.f;
+            else {
+              const float x = __fsub_rn(sc[i], mnew);
+              ev = ok ? ((idx < nvec) ? zn_fexp_u20(x) : expf(x)) : 0.f;
+            }
+            lsum += ev;
+            const float v0 = lo_f(vv[i].x), v1 = hi_f(vv[i].x), v2f = lo_f(vv[i].y), v3 = hi_f(vv[i].y);
+            const float v4 = lo_f(vv[i].z), v5 = hi_f(vv[i].z), v6 = lo_f(vv[i].w), v7 = hi_f(vv[i].w);
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+              float pr = bfround(ev);
+              pr = (g % 4 == 0) ? dpp_mov<0x00>(pr) : (g % 4 == 1) ? dpp_mov<0x55>(pr) : (g % 4 == 2) ? dpp_mov<0xAA>(pr) : dpp_mov<0xFF>(pr);
+              acc[g][0] = fmaf(pr, v0, acc[g][0]); acc[g][1] = fmaf(pr, v1, acc[g][1]);
+              acc[g][2] = fmaf(pr, v2f, acc[g][2]); acc[g][3] = fmaf(pr, v3, acc[g][3]);
+              acc[g][4] = fmaf(pr, v4, acc[g][4]); acc[g][5] = fmaf(pr, v5, acc[g][5]);
+              acc[g][6] = fmaf(pr, v6, acc[g][6]); acc[g][7] = fmaf(pr, v7, acc[g][7]);
+            }
+          }
+        }
+      }
+      stamp(3);
+      // reduce: 4 key lanes per 16-lane row by DPP, the rows of the workgroup through LDS in the fused kernel's order
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        float red[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) red[e] = row_stride4_sum(acc[g][e]);
+        if ((lane & 15) < 4) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) S.acc[wave * 4 + row][g][(lane & 3) * 8 + e] = red[e];
+        }
+      }
+      float ls = row_stride4_sum(lsum);
+      ls = (readlane_f(ls, 0) + readlane_f(ls, 16)) + (readlane_f(ls, 32) + readlane_f(ls, 48));
+      float l1 = row_stride4_sum(lsum); l1 = (readlane_f(l1, 1) + readlane_f(l1, 17)) + (readlane_f(l1, 33) + readlane_f(l1, 49));
+      float l2 = row_stride4_sum(lsum); l2 = (readlane_f(l2, 2) + readlane_f(l2, 18)) + (readlane_f(l2, 34) + readlane_f(l2, 50));
+      float l3 = row_stride4_sum(lsum); l3 = (readlane_f(l3, 3) + readlane_f(l3, 19)) + (readlane_f(l3, 35) + readlane_f(l3, 51));
+      if (lane == 0) { S.l[wave][0] = ls; S.l[wave][1] = l1; S.l[wave][2] = l2; S.l[wave][3] = l3; }
+    }
+    __syncthreads();                                         // A3: partial sums of all 8 waves
+    stamp(4);
+    {
+      const int tid = wave * 64 + lane;
+      if (tid < G * 32) {
+        const int g = tid >> 5, d = tid & 31;
+        float v = 0.f, l = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW * 4; ++w) v += S.acc[w][g][d];
+#pragma unroll
+        for (int w = 0; w < NW; ++w) l += S.l[w][g];
+        S.out[g][d] = f2bf(__fmul_rn(v, 1.0f / l));
+      }
+    }
+    __syncthreads();                                         // A4: the result slice is in LDS
+    if (wave == ZN_SK_CW) {
+      const int gq = lane >> 4, dp = lane & 15;
+      const unsigned v = *(const unsigned*)&S.out[gq][2 * dp];
+      st_granule(a.g_a + (size_t)ar * (D / 2) + ((kvh * G + gq) * HD + slice * 32) / 2 + dp, tag, v);
+      if (a.trace) {
+        *(unsigned*)(a.trace + ((size_t)(8 * li + 1) * R + ar) * D + (kvh * G + gq) * HD + slice * 32 + 2 * dp) = v;
+        if (slice == 0) *(u32x4*)(a.trace + ((size_t)(8 * li + 2) * R + ar) * D + (kvh * G + (lane >> 4)) * HD + (lane & 15) * 8) = *(const u32x4*)&S.q[lane >> 4][(lane & 15) * 8];
+      }
+    }
+    stamp(5);
+    // the key and value registers are free: the next block's rows are requested now, a whole block (~20 us) ahead of their use
+    if (li + 1 < a.n_layer) {
+      const bf16_t* kvn = a.layers[li + 1].kv;
+      int opq = 0;
+      asm volatile("" : "+v"(opq));
+      issue_k(kvn, kkA, 0, opq);
+      if (nb > 1) issue_k(kvn, kkB, 512, opq);
+      issue_v(kvn, vA, 0, opq);
+      if (nb > 1) issue_v(kvn, vB, 512, opq);
+    }
+    pace.start();                                            // the wait for the next block's q | k | v starts here
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ the launch
+// T_* = tiles per compute wave per op (upper bounds: the matrices do not divide evenly over 224 workgroups; a wave skips the tiles
+// its workgroup does not have).  d_model = 512 * NCH, d_ff = 4 * d_model (host-checked, as are the bounds).
+template <int NCH, int T_OUT, int T_FC1, int T_FC2, int T_IN>
+__global__ __launch_bounds__(ZN_SK_THREADS) void step_kernel(ChainArgs a) {
+  constexpr int R = 2, D = NCH * 512, CW = ZN_SK_CW;
+  constexpr int S1 = T_OUT, S2 = 2 * T_OUT, S3 = S2 + T_FC1, S4 = S3 + T_FC2, NS = S4 + T_IN;     // slot ranges per op
+  constexpr int NOPS = 5;
+  constexpr int MASK = ZN_CH_DEFER_MASK;
+  constexpr int NB = ZN_SK_NBUF, P = ZN_SK_PARK;
+  constexpr int NL = NS - T_OUT;                              // distinct tiles (requests) of a block: op 1 reuses op 0's
+  static_assert(T_IN > 0 && NCH == 4, "step_kernel: d_model 2048, head size 128");
+  static_assert(P >= T_OUT && NB >= 2 && P + NB <= NL, "op 0's tiles are parked (op 1 reads them again); the prefetch stays inside the block");
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c = blockIdx.x;
+  const int F = a.F;
+  const unsigned tag0 = ld_sc1_u32(a.epoch);
+  extern __shared__ __attribute__((aligned(16))) unsigned char zn_dyn_lds[];
+  const int natt = a.n_heads_kv * R * (a.hd / 32);
+  if (c < natt) {
+    step_attention_role(a, *reinterpret_cast<StepAttnLds*>(zn_dyn_lds), tag0, c, wave, lane);
+    return;
+  }
+  // ------------------------------------------------------------------------------------------------ streaming role
+  __shared__ __attribute__((aligned(16))) bf16_t s_act[R * D];              // the current op's input vector (ops 0, 1, 2, 4)
+  __shared__ float s_res[2][64][2][R];                                      // per-unit results of even / odd ops (fc2: [unit * 4 + quarter])
+  const int sc = c - natt, NSW = (int)gridDim.x - natt;
+  auto split = [&](int U, int& n, int& start) { const int base = U / NSW, extra = U % NSW; n = base + (sc < extra ? 1 : 0); start = sc * base + min(sc, extra); };
+  int n_out, s_out, ng1, sg1;
+  split(D / 2, n_out, s_out);                                 // row pairs of out_proj (ops 0, 1) and fc2 (op 3)
+  split(F / 2, ng1, sg1);                                     // fc1: pairs of m elements (one granule each), so that no granule straddles two workgroups
+  const int n_fc1 = 2 * ng1, s_fc1 = 2 * sg1;
+  int n_qkv, s_qkv, n_hd, s_hd;
+  split((a.nqkv + 1) / 2, n_qkv, s_qkv);
+  split((a.heads_rows + 1) / 2, n_hd, s_hd);
+  constexpr int NBAR = 14;                                    // workgroup barriers per block (every wave of a streaming workgroup runs them all)
+
+  auto op_of = [](int s) constexpr { return s < S1 ? 0 : s < S2 ? 1 : s < S3 ? 2 : s < S4 ? 3 : 4; };
+  auto first_of = [](int op) constexpr { return op == 0 ? 0 : op == 1 ? S1 : op == 2 ? S2 : op == 3 ? S3 : S4; };
+
+  if (wave >= CW + 2) {
+#pragma unroll 1
+    for (int li = 0; li < a.n_layer; ++li)
+#pragma unroll
+      for (int b = 0; b < NBAR; ++b) __syncthreads();
+    return;
+  }
+
+  if (wave < CW) {
+    // ------------------------------------------------------------------------------------ compute waves
+    struct WT { u32x4 a[NCH], b[NCH]; };
+    WT bufs[NB];                                           // every index below is a compile-time constant: the buffers live in registers
+    u32x4* park = reinterpret_cast<u32x4*>(zn_dyn_lds) + (size_t)wave * (P * 2 * NCH * 64) + lane;
+    static_assert(CW == 4, "fc2 splits K over the four compute waves");
+#pragma unroll 1
+    for (int li = 0; li < a.n_layer; ++li) {
+      const StackLayer& Lr = a.layers[li];
+      const bf16_t *W_out = Lr.W_out, *W_fc1 = Lr.W_fc1, *W_fc2 = Lr.W_fc2, *W_in = Lr.W_in;
+      const bool last = li + 1 == a.n_layer;
+      const int rows_in = last ? a.heads_rows : a.nqkv;
+      const int n_in = last ? n_hd : n_qkv, s_in = last ? s_hd : s_qkv;
+      const unsigned tag = tag0 + (unsigned)li;
+      // tile of slot s for this wave: exists?, weight pointers of rows A and B (lane's first chunk), result index
+      auto tile = [&](int s, bool& ok, const bf16_t*& pa, const bf16_t*& pb, int& ridx) {
+        const int op = op_of(s), t = s - first_of(op);
+        if (op == 3) {
+          const int qt = wave, j = t;
+          ok = j < n_out;
+          const int u = s_out + (ok ? j : 0);
+          pa = W_fc2 + (size_t)(2 * u) * (4 * D) + qt * D + lane * 8;
+          pb = pa + 4 * D;
+          ridx = j * 4 + qt;
+          return;
+        }
+        const int j = wave + CW * t;
+        const int n = op <= 1 ? n_out : op == 2 ? n_fc1 : n_in;
+        const int st = op <= 1 ? s_out : op == 2 ? s_fc1 : s_in;
+        ok = j < n;
+        const int u = st + (ok ? j : 0);
+        ridx = j;
+        if (op <= 1) { pa = W_out + (size_t)(2 * u) * D + lane * 8; pb = pa + D; }
+        else if (op == 2) { pa = W_fc1 + (size_t)u * D + lane * 8; pb = pa + (size_t)F * D; }
+        else { pa = W_in + (size_t)(2 * u) * D + lane * 8; pb = (2 * u + 1 < rows_in) ? pa + D : pa; }   // half pair: row B repeats row A, result dropped
+      };
+      auto slot_of_load = [](int l) constexpr { return l < S1 ? l : l + T_OUT; };
+      auto load_of_slot = [](int s) constexpr { return s < S1 ? s : s < S2 ? s - T_OUT : s - T_OUT; };
+      auto load_req = [&](auto LC) {
+        constexpr int l = decltype(LC)::value;
+        if constexpr (l < NL) {
+          bool ok; const bf16_t *pa, *pb; int ridx;
+          tile(slot_of_load(l), ok, pa, pb, ridx);
+          if (ok) {                                         // wave-uniform
+            WT& w = bufs[l % NB];
+#pragma unroll
+            for (int c2 = 0; c2 < NCH; ++c2) { w.a[c2] = ld_nt16(pa + c2 * 512); w.b[c2] = ld_nt16(pb + c2 * 512); }
+          }
+        }
+      };
+      u32x4 xr[NCH][R];
+      auto process = [&](int s, const WT& w) {
+        bool ok; const bf16_t *pa, *pb; int ridx;
+        tile(s, ok, pa, pb, ridx);
+        if (!ok) return;
+        float accA[R] = {0.f, 0.f}, accB[R] = {0.f, 0.f};
+#pragma unroll
+        for (int c2 = 0; c2 < NCH; ++c2) {
+#pragma unroll
+          for (int r = 0; r < R; ++r) { accA[r] = dot8(w.a[c2], xr[c2][r], accA[r]); accB[r] = dot8(w.b[c2], xr[c2][r], accB[r]); }
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) { accA[r] = wave_sum(accA[r]); accB[r] = wave_sum(accB[r]); }
+        if (lane == 0) {
+          const int par = op_of(s) & 1;
+#pragma unroll
+          for (int r = 0; r < R; ++r) { s_res[par][ridx][0][r] = accA[r]; s_res[par][ridx][1][r] = accB[r]; }
+        }
+      };
+      // request raised by the last use of slot s's register buffer (-1: none): parked tiles and op 1's re-use raise nothing
+      auto raised_by = [](int s) constexpr {
+        const int op = s < S1 ? 0 : s < S2 ? 1 : s < S3 ? 2 : s < S4 ? 3 : 4;
+        if (op <= 1) return -1;
+        const int l = s - T_OUT;
+        if (l < P) return -1;
+        return l + NB < NL ? l + NB : -1;
+      };
+      // ---- prefetch while the attention runs: loads 0 .. P-1 through the register buffers into LDS, loads P .. P+NB-1 stay in flight
+      zn_static_for<0, NB>([&](auto LC) { load_req(LC); });
+      zn_static_for<0, P>([&](auto LC) {
+        constexpr int l = decltype(LC)::value;
+        bool ok; const bf16_t *pa, *pb; int ridx;
+        tile(slot_of_load(l), ok, pa, pb, ridx);
+        if (ok) {
+          const WT& w = bufs[l % NB];
+#pragma unroll
+          for (int c2 = 0; c2 < NCH; ++c2) { park[(l * 2 * NCH + c2) * 64] = w.a[c2]; park[(l * 2 * NCH + NCH + c2) * 64] = w.b[c2]; }
+        }
+        load_req(std::integral_constant<int, l + NB>{});
+      });
+      zn_static_for<0, NS>([&](auto SC) {
+        constexpr int s = decltype(SC)::value;
+        constexpr int op = op_of(s);
+        if constexpr (s == first_of(op)) {
+          if constexpr (op > 0) {
+            __syncthreads();                                // A(op-1): this workgroup's results of the previous op are in LDS
+            __syncthreads();                                // P(op-1): ... and published; the requests held back for that go out now
+            if constexpr (((MASK >> (op - 1)) & 1) != 0) {
+              zn_static_for<first_of(op - 1), first_of(op)>([&](auto QC) {
+                constexpr int q = decltype(QC)::value, l = raised_by(q);
+                if constexpr (l >= 0) { if constexpr (op_of(slot_of_load(l >= 0 ? l : 0)) != op - 1) load_req(std::integral_constant<int, (l >= 0 ? l : 0)>{}); }
+              });
+            }
+          }
+          if constexpr (op == 3) {
+            // fc2's input m [2][4 d]: this wave's K quarter straight from the granules (no LDS, no barrier)
+            int off[NCH * R];
+            u32x4 dat[NCH * R];
+#pragma unroll
+            for (int c2 = 0; c2 < NCH; ++c2)
+#pragma unroll
+              for (int r = 0; r < R; ++r) off[c2 * R + r] = (r * (2 * D) + wave * (D / 2) + (c2 * 64 + lane) * 4) * 8;
+            sweep_granules<NCH * R>(zn_rsrc(a.g_m), off, tag, dat, a.tmo, lane, SweepWho{(3u << 8) | (unsigned)li, a.diag});
+#pragma unroll
+            for (int c2 = 0; c2 < NCH; ++c2)
+#pragma unroll
+              for (int r = 0; r < R; ++r) xr[c2][r] = dat[c2 * R + r];
+          } else {
+            __syncthreads();                                // B(op): the op's input vector is in LDS
+#pragma unroll
+            for (int c2 = 0; c2 < NCH; ++c2)
+#pragma unroll
+              for (int r = 0; r < R; ++r) xr[c2][r] = *(const u32x4*)&s_act[r * D + (c2 * 64 + lane) * 8];
+          }
+        }
+        constexpr int l = load_of_slot(s);
+        if constexpr (l < P) {                              // parked tile: from LDS
+          bool ok; const bf16_t *pa, *pb; int ridx;
+          tile(s, ok, pa, pb, ridx);
+          if (ok) {
+            WT w;
+#pragma unroll
+            for (int c2 = 0; c2 < NCH; ++c2) { w.a[c2] = park[(l * 2 * NCH + c2) * 64]; w.b[c2] = park[(l * 2 * NCH + NCH + c2) * 64]; }
+            process(s, w);
+          }
+        } else {
+          process(s, bufs[l % NB]);
+          constexpr int rq = raised_by(s);
+          if constexpr (rq >= 0) {
+            if constexpr (((MASK >> op) & 1) == 0 || op_of(slot_of_load(rq >= 0 ? rq : 0)) == op) load_req(std::integral_constant<int, (rq >= 0 ? rq : 0)>{});
+          }
+        }
+      });
+      __syncthreads();                                      // A(4)
+      __syncthreads();                                      // P(4): q | k | v are published; the next block's prefetch may enter the CU's queue
+    }
+    return;
+  }
+
+  // -------------------------------------------------------------------------------------- communication waves
+  // Wave CW + r gathers (sweeps), normalises and stages row r of every hand-off; wave CW also runs the row-pair epilogues.
+  const int myr = wave - CW;
+  const bool epi = myr == 0;
+  u32x4 g[NCH];
+  u32x4 l2w[NCH], l2b[NCH], lnw[NCH], lnbb[NCH];
+  const int ij = lane >> 1, ir = lane & 1;
+  const bool it_out = epi && ij < n_out;
+  const int u_out = s_out + (it_out ? ij : 0);
+  unsigned resid = 0;
+  if (it_out) resid = *(const unsigned*)(a.xin + (size_t)ir * D + 2 * u_out);
+  const int nq = a.n_heads * a.hd, nk = a.n_heads_kv * a.hd;
+  const bool it_qkv = epi && ij < n_qkv;
+  const int u_qkv = s_qkv + (it_qkv ? ij : 0);
+  int pos = 0; float cs = 1.f, sn = 0.f;
+  if (it_qkv) {
+    pos = a.lengths[ir];
+    const int rowA = 2 * u_qkv;
+    if (rowA < nq + nk) {
+      const int i = (rowA % a.hd) >> 1;
+      const int p = pos < a.rope_positions ? pos : a.rope_positions - 1;
+      const float2 c2v = *(const float2*)(a.rope + ((size_t)p * (a.hd >> 1) + i) * 2);
+      cs = c2v.x; sn = c2v.y;
+    }
+  }
+  int goff[NCH];
+#pragma unroll
+  for (int c2 = 0; c2 < NCH; ++c2) goff[c2] = (myr * (D / 2) + (c2 * 64 + lane) * 4) * 8;
+  unsigned x1own = 0;
+  StepPacer pace{0ull, 0u};
+  pace.start();
+#pragma unroll 1
+  for (int li = 0; li < a.n_layer; ++li) {
+    const StackLayer& Lr = a.layers[li];
+    const bool last = li + 1 == a.n_layer;
+    const unsigned tag = tag0 + (unsigned)li;
+    const bool stamped = a.stamps && li == a.stamp_layer && epi && sc == 0 && lane == 0;
+    int nst = 0;
+    auto stamp = [&]() { if (stamped) a.stamps[nst] = __builtin_amdgcn_s_memrealtime(); ++nst; };
+    stamp();                                               // 0: block starts
+#pragma unroll
+    for (int c2 = 0; c2 < NCH; ++c2) { l2w[c2] = ld16(Lr.ln2_w + (c2 * 64 + lane) * 8); l2b[c2] = ld16(Lr.ln2_b + (c2 * 64 + lane) * 8); }
+#pragma unroll
+    for (int c2 = 0; c2 < NCH; ++c2) { lnw[c2] = ld16(Lr.lnn_w + (c2 * 64 + lane) * 8); lnbb[c2] = ld16(Lr.lnn_b + (c2 * 64 + lane) * 8); }
+    // ---- the attention output of all heads -> s_act
+    pace.sleep();
+    stamp();                                               // 1: polling starts
+    sweep_granules<NCH>(zn_rsrc(a.g_a), goff, tag, g, a.tmo, lane, SweepWho{(6u << 8) | (unsigned)li, a.diag});
+    pace.done();
+#pragma unroll
+    for (int c2 = 0; c2 < NCH; ++c2) *(u32x4*)&s_act[myr * D + (c2 * 64 + lane) * 8] = g[c2];
+    __syncthreads();                                       // B(0)
+    stamp();                                               // 2: op 0's input ready
+    zn_static_for<0, NOPS>([&](auto OC) {
+      constexpr int op = decltype(OC)::value;
+      constexpr int par = op & 1;
+      __syncthreads();                                     // A(op): every compute wave's results are in LDS
+      stamp();
+      // ---- epilogue of this workgroup's units, published as granules
+      if constexpr (op == 0) {                             // EPI_STORE
+        if (it_out) st_granule(a.g_y1 + (size_t)ir * (D / 2) + u_out, tag, pack2(s_res[par][ij][0][ir], s_res[par][ij][1][ir]));
+      } else if constexpr (op == 1) {                      // EPI_RESID
+        if (it_out) {
+          x1own = pack2(lo_f(resid) + bfround(s_res[par][ij][0][ir]), hi_f(resid) + bfround(s_res[par][ij][1][ir]));
+          st_granule(a.g_x1 + (size_t)ir * (D / 2) + u_out, tag, x1own);
+        }
+      } else if constexpr (op == 2) {                      // EPI_SILU: each communication wave its own row; lane = m element, neighbours share a granule
+        const bool on = lane < n_fc1;
+        const int jj = on ? lane : 0;
+        const float y = bfround(s_res[par][jj][0][myr]), gt = bfround(s_res[par][jj][1][myr]);
+        const float sg = bfround(gt / (1.0f + expf(-gt)));
+        const unsigned mine = (unsigned)f2bf(y * sg);
+        const unsigned nbv = (unsigned)__shfl_down((int)mine, 1);
+        if (on && (lane & 1) == 0) st_granule(a.g_m + (size_t)myr * (F / 2) + ((s_fc1 + lane) >> 1), tag, mine | (nbv << 16));
+      } else if constexpr (op == 3) {                      // EPI_RESID over the four K quarters, in gemv_kernel's order
+        if (it_out) {
+          const float vA = ((s_res[par][ij * 4 + 0][0][ir] + s_res[par][ij * 4 + 1][0][ir]) + s_res[par][ij * 4 + 2][0][ir]) + s_res[par][ij * 4 + 3][0][ir];
+          const float vB = ((s_res[par][ij * 4 + 0][1][ir] + s_res[par][ij * 4 + 1][1][ir]) + s_res[par][ij * 4 + 2][1][ir]) + s_res[par][ij * 4 + 3][1][ir];
+          const unsigned o = pack2(lo_f(x1own) + bfround(vA), hi_f(x1own) + bfround(vB));
+          st_granule(a.g_x2 + (size_t)ir * (D / 2) + u_out, tag, o);
+          if (last) *(unsigned*)(a.xout + (size_t)ir * D + 2 * u_out) = o;
+          if (a.trace) *(unsigned*)(a.trace + ((size_t)(8 * li) * R + ir) * D + 2 * u_out) = o;
+          resid = o;                                       // the residual stream entering the next block
+        }
+      } else {
+        if (last) {                                        // EPI_F32 (gemv_epilogue): bf16-valued fp32 logits
+          if (epi && ij < n_hd) {
+            const int u = s_hd + ij;
+            a.heads_out[(size_t)ir * a.heads_rows + 2 * u] = bfround(s_res[par][ij][0][ir]);
+            if (2 * u + 1 < a.heads_rows) a.heads_out[(size_t)ir * a.heads_rows + 2 * u + 1] = bfround(s_res[par][ij][1][ir]);
+          }
+        } else if (it_qkv) {                               // EPI_ROPE_KV (gemv_epilogue) of the next block, q | k | v also as granules
+          const int rowA = 2 * u_qkv;
+          const float x0 = bfround(s_res[par][ij][0][ir]), x1 = bfround(s_res[par][ij][1][ir]);
+          unsigned packed;
+          if (rowA < nq + nk) {
+            float re, im;
+            zn_rope_pair(x0, x1, cs, sn, re, im);
+            packed = pack2(re, im);
+          } else packed = pack2(x0, x1);
+          st_granule(a.g_qkv + (size_t)ir * (a.nqkv / 2) + u_qkv, tag, packed);
+          if (rowA >= nq && pos < a.max_len) {
+            const int which = rowA < nq + nk ? 0 : 1, colk = rowA - nq - which * nk;
+            *(unsigned*)(Lr.kv_next + (((size_t)ir * a.max_len + pos) * 2 + which) * nk + colk) = packed;
+          }
+        }
+      }
+      __syncthreads();                                     // P(op): published; the compute waves may queue weight requests again
+      stamp();
+      if constexpr (op + 1 < NOPS) {
+        if constexpr (op != 2) {                           // (fc2's input is swept by the compute waves)
+          sweep_granules<NCH>(zn_rsrc(op == 0 ? a.g_y1 : op == 1 ? a.g_x1 : a.g_x2), goff, tag, g, a.tmo, lane,
+                              SweepWho{((op == 0 ? 1u : op == 1 ? 2u : 4u) << 8) | (unsigned)li, a.diag});
+          stamp();
+          if constexpr (op == 1 || op == 3) chain_layernorm_row<NCH>(g, op == 1 ? l2w : lnw, op == 1 ? l2b : lnbb, a.eps);
+#pragma unroll
+          for (int c2 = 0; c2 < NCH; ++c2) *(u32x4*)&s_act[myr * D + (c2 * 64 + lane) * 8] = g[c2];
+          __syncthreads();                                 // B(op + 1)
+        } else stamp();
+        stamp();
+      }
+    });
+    pace.start();                                          // the wait for the next block's attention output starts here
+  }
+  if (epi && sc == 0 && lane == 0) st_sc1_u32(a.epoch, tag0 + (unsigned)a.n_layer);   // every workgroup read the epoch before its first publish, which this one has seen
+}

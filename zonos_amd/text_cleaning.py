@@ -74,9 +74,33 @@ def digit_pairs(digits: str) -> str:
     return ", ".join(out)
 
 
+def cardinal_and(n: int) -> str:
+    """inflect number_to_words(n) with its default andword="and": "and" between a group's hundreds and its tens / units
+    ("one thousand, two hundred and thirty-four"), and in place of the last comma when the last group has no hundreds
+    ("one thousand and one")."""
+    if n == 0:
+        return "zero"
+    groups, i = [], 0
+    while n:
+        n, g = divmod(n, 1000)
+        if g:
+            if i >= len(_SCALES):
+                raise _lib.ZonosHipError("number too large to spell out")
+            h, rest = divmod(g, 100)
+            said = (_ONES[h] + " hundred" + (" and " + _below_hundred(rest) if rest else "")) if h else _below_hundred(rest)
+            groups.append((said + (" " + _SCALES[i] if i else ""), i == 0 and h == 0))
+        i += 1
+    groups.reverse()
+    out = groups[0][0]
+    for said, bare_tail in groups[1:]:
+        out += (" and " if bare_tail else ", ") + said
+    return out
+
+
 def ordinal(n: int) -> str:
-    """inflect number_to_words("<n>th"): the cardinal with its last word made ordinal ("21st" -> "twenty-first")."""
-    words = cardinal(n)
+    """inflect number_to_words("<n>th") as the reference calls it (conditioning.py:180-181: default andword, so "121st" -> "one hundred
+    and twenty-first", "1234th" -> "one thousand, two hundred and thirty-fourth"): the cardinal with its last word made ordinal."""
+    words = cardinal_and(n)
     head, sep, last = words.rpartition(" ")
     stem, hy, tail = last.rpartition("-")
     if tail in _ORDINAL_WORD:
