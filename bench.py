@@ -30,8 +30,9 @@ sys.path.insert(0, ROOT)
 
 FRAME_RATE = 44100 / 512          # 86.1328 DAC frames per second of audio
 HBM_PEAK = 8.0e12                 # B/s, MI355X spec (MI355X_MICROARCH.md)
-PMC_FILE = os.path.join(ROOT, "profiles", "pmc_chain.json")
-KERNEL_SOURCES = ("zonos_amd/csrc/zn_chain_kernel.h", "zonos_amd/csrc/zn_decode_kernels.h", "zonos_amd/csrc/zn_common.h")
+PMC_FILES = {5: os.path.join(ROOT, "profiles", "pmc_chain.json"), 6: os.path.join(ROOT, "profiles", "pmc_step_kernel.json")}
+KERNEL_SOURCES = ("zonos_amd/csrc/zn_step_kernel.h", "zonos_amd/csrc/zn_chain_kernel.h", "zonos_amd/csrc/zn_decode_kernels.h", "zonos_amd/csrc/zn_common.h")
+STEP_KERNEL_CTX = 450             # keys in the cache for the whole-step kernel's roofline launches: the mean context of a 10 s utterance
 
 
 def algorithmic_bytes_per_step(cfg, B, L):
@@ -229,19 +230,26 @@ def run_rank(args) -> int:
         result["ar_only"] = {"s_per_utterance": round(t_ar, 4), "ms_per_decode_step": round(1e3 * t_ar / (steps_per_utt + 1), 4),
                              "audio_sec_per_sec": round(B * max_new / FRAME_RATE / t_ar, 3)}
         result["hipgraph_step"] = bool(eng.lib.zn_graph_active(eng.h))
-        result["chain_kernel_path"] = bool(eng.lib.zn_decode_path(eng.h))     # the generation just run: persistent chain or launches
+        result["chain_kernel_path"] = bool(eng.lib.zn_decode_path(eng.h))     # the generation just run: persistent kernels or launches
+        result["decode_path"] = int(eng.lib.zn_decode_path_detail(eng.h))      # 0 launches, 1 chain launch per block, 2 whole-step kernel
     if rank == 0 and not dry:
         from zonos_amd import _lib
         # ---- roofline of the dominant kernel, HIP events on the launch stream; the launches cycle over the 26 layers' weights so
         # that each streams from HBM.  Batch 1: the persistent chain launch (out_proj x2, LayerNorm+fc1+SiLU, fc2, next in_proj:
         # ~70 % of the decode step's GPU time); larger batches: the LayerNorm + fc1 + SiLU-gate GEMM of the launches path.
         ms, by = C.c_float(0), C.c_double(0)
-        chain = B == 1 and bool(result.get("chain_kernel_path"))
-        eng.call("zn_bench_kernel", 5 if chain else 0, 2 * B, 260, C.byref(ms), C.byref(by), _lib.stream_ptr())
+        path = result.get("decode_path", 0)
+        which = (6 if path == 2 else 5 if path == 1 else 0) if B == 1 else 0
+        if which == 6:       # one launch = every block of a decode step + the heads at a context of STEP_KERNEL_CTX keys
+            eng.call("zn_bench_kernel", 6, 2 | (STEP_KERNEL_CTX << 16), 80, C.byref(ms), C.byref(by), _lib.stream_ptr())
+        else:
+            eng.call("zn_bench_kernel", which, 2 * B, 260, C.byref(ms), C.byref(by), _lib.stream_ptr())
         ach = by.value / (ms.value * 1e-3)
-        traffic, traffic_note = pmc_traffic() if chain else (None, "PMC summary covers the batch-1 chain launch only")
-        kname = ("chain_kernel<NCH=4,T_OUT=1,T_FC1=8,T_FC2=4,T_IN=2> (out_proj x2 + LayerNorm+fc1+SiLU-gate + fc2 + next block's LayerNorm+in_proj+RoPE+KV append, one persistent launch)"
-                 if chain else "gemm16s/gemv LayerNorm+fc1+SiLU-gate")
+        traffic, traffic_note = pmc_traffic(which) if which in PMC_FILES else (None, "PMC summaries cover the batch-1 persistent kernels only")
+        kname = {6: "step_kernel<NCH=4,T_OUT=2,T_FC1=10,T_FC2=5,T_IN=6> (whole decode step in one persistent launch: per block attention, out_proj x2, LayerNorm+fc1+SiLU-gate, fc2, "
+                    f"next block's LayerNorm+in_proj+RoPE+KV append; norm_f + heads; context {STEP_KERNEL_CTX} keys)",
+                 5: "chain_kernel<NCH=4,T_OUT=1,T_FC1=8,T_FC2=4,T_IN=2> (out_proj x2 + LayerNorm+fc1+SiLU-gate + fc2 + next block's LayerNorm+in_proj+RoPE+KV append, one persistent launch)",
+                 0: "gemm16s/gemv LayerNorm+fc1+SiLU-gate"}[which]
         result["roofline"] = {"bound": "hbm", "kernel": kname,
                               "achieved": round(ach / 1e9, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": round(ach / HBM_PEAK, 4),
                               "traffic": traffic, "traffic_note": traffic_note, "bytes_per_launch": by.value, "us_per_launch": round(ms.value * 1e3, 3)}
@@ -319,15 +327,16 @@ def kernel_source_hash() -> str:
     return h.hexdigest()[:16]
 
 
-def pmc_traffic():
+def pmc_traffic(which=5):
     """HBM bytes per launch of the dominant kernel from the PMC passes (FETCH_SIZE x2 + WRITE_SIZE; separate rocprofv3
-    --pmc runs of tools/pmc_kernel.py 5, summarised by tools/pmc_summary.py into profiles/pmc_chain.json).  The summary
+    --pmc runs of tools/pmc_kernel.py <which>, summarised by tools/pmc_summary.py into profiles/pmc_*.json).  The summary
     records the kernel's name and a hash of the kernel sources it was measured on: a summary of another kernel state is
     refused (traffic = null), never reported."""
+    f = PMC_FILES[which]
     try:
-        rec = json.load(open(PMC_FILE))
+        rec = json.load(open(f))
     except Exception:
-        return None, "no PMC summary (profiles/pmc_chain.json)"
+        return None, f"no PMC summary ({os.path.relpath(f, ROOT)})"
     if rec.get("kernel_source_sha256_16") != kernel_source_hash():
         return None, f"PMC summary is stale: measured on kernel sources {rec.get('kernel_source_sha256_16')}, current {kernel_source_hash()}"
     return rec["traffic_bytes_per_launch"], f"{rec.get('kernel_name')}; rocprofv3 --pmc passes of {rec.get('date', '?')}"

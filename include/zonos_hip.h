@@ -149,6 +149,16 @@ int zn_decode_path(zn_handle h);
  * launch per block, 2 = the whole-step persistent kernel (every block of the step in one launch; contexts up to 1024 keys).
  * All three give bit-identical results (the per-block path with its fused attention launch: zn_debug_tune(5, ...)). */
 int zn_decode_path_detail(zn_handle h);
+/* Ends the generation begun by zn_gen_begin: releases the device's persistent-kernel tenancy (below) so that another handle's next
+ * generation may take it.  The handle's state stays readable (zn_decode_path, zn_get_step_outputs); further steps need a new
+ * zn_gen_begin.  Optional: zn_gen_begin of the same handle and zn_destroy release too. */
+int zn_gen_end(zn_handle h);
+/* One generation per device and process owns the persistent decode kernels (their in-launch hand-offs need every workgroup of the
+ * grid resident: two such grids on one device could starve each other).  zn_gen_begin claims the device for `h`; a generation that
+ * begins while another handle holds it runs the launches path (bit-identical results).  The two primitives are exported for the
+ * host-side tests: try_claim returns 1 when `owner` holds the device afterwards, release 1 when `owner` held it. */
+int zn_tenant_try_claim(int32_t device, const void* owner);
+int zn_tenant_release(int32_t device, const void* owner);
 /* (remaining_steps <= 0).all() of tensor_ops.py:95,102 — synchronises the stream. */
 int zn_all_stopped(zn_handle h, int32_t* out, zn_stream stream);
 /* The same check off the critical path: zn_all_stopped_begin queues the read-back of the loop state behind the steps enqueued

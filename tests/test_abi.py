@@ -52,6 +52,52 @@ def test_bad_arguments_return_status_not_crash(lib):
     assert lib.zn_destroy(None) == 0
 
 
+def test_persistent_kernel_tenancy_is_one_owner_per_device(lib):
+    """Two handles on one device cannot both select the persistent kernels at once (their hand-offs need every workgroup of the grid
+    resident): the second generation to begin gets the launches path.  Host logic only - zn_gen_begin / zn_gen_end / zn_destroy go
+    through these two primitives."""
+    a, b = C.c_void_p(0x1000), C.c_void_p(0x2000)
+    dev = 63                                   # a device index no test engine uses
+    assert lib.zn_tenant_try_claim(dev, a) == 1
+    assert lib.zn_tenant_try_claim(dev, a) == 1, "re-claiming one's own device is idempotent"
+    assert lib.zn_tenant_try_claim(dev, b) == 0, "a second owner must be refused while the first holds the device"
+    assert lib.zn_tenant_try_claim(dev - 1, b) == 1, "tenancy is per device"
+    assert lib.zn_tenant_release(dev, b) == 0, "only the owner releases"
+    assert lib.zn_tenant_release(dev, a) == 1
+    assert lib.zn_tenant_try_claim(dev, b) == 1
+    assert lib.zn_tenant_release(dev, b) == 1 and lib.zn_tenant_release(dev - 1, b) == 1
+    assert lib.zn_tenant_try_claim(64, a) == 0 and lib.zn_tenant_try_claim(-1, a) == 0 and lib.zn_tenant_try_claim(0, None) == 0
+
+
+def test_persistent_kernels_use_no_scratch_and_fit_one_workgroup_per_cu(lib, tmp_path):
+    """The persistent kernels' hand-offs wait on every workgroup of the grid: all 256 must be resident at once, whatever else the
+    queue's scratch pool is doing.  Build-time facts checked on the shipped code object: no private segment (no scratch-wave slots
+    involved in residency), no spills, and LDS + waves of ONE workgroup fit a CU (160 KB, 8 waves of <= 256 VGPRs)."""
+    import shutil
+    import subprocess
+    readelf = "/opt/rocm/lib/llvm/bin/llvm-readelf"
+    if not (os.path.exists(OBJDUMP) and os.path.exists(readelf)):
+        pytest.skip("llvm tools not available")
+    so = shutil.copy(_lib.LIB_PATH, tmp_path / "lib.so")
+    subprocess.run([OBJDUMP, "--offloading", str(so)], check=True, capture_output=True, cwd=tmp_path)
+    seen = {}
+    for co in sorted(tmp_path.glob("lib.so.*gfx950*")):
+        notes = subprocess.run([readelf, "--notes", str(co)], check=True, capture_output=True, text=True).stdout
+        for k in notes.split("- .agpr_count:")[1:]:
+            name = re.search(r"\.name:\s+(\S+)", k).group(1)
+            if name.startswith("_Z12chain_kernel") or name.startswith("_Z11step_kernel"):
+                g = lambda key: int(re.search(r"\.%s:\s+(\d+)" % key, k).group(1))
+                seen[name] = dict(scratch=g("private_segment_fixed_size"), spill=g("vgpr_spill_count"), vgpr=g("vgpr_count"),
+                                  lds=g("group_segment_fixed_size"), threads=g("max_flat_workgroup_size"))
+    assert len(seen) == 7, sorted(seen)
+    for name, r in seen.items():
+        assert r["scratch"] == 0 and r["spill"] == 0, (name, r)
+        waves = r["threads"] // 64
+        assert waves * r["vgpr"] <= 4 * 512, (name, r)                       # the CU's four SIMDs hold 512 VGPRs per lane each
+        dyn = 128 * 1024 if name.startswith("_Z11step_kernel") else 64 * 1024    # ZN_SK_DYN_LDS / ZN_CH_DYN_LDS of the launch
+        assert r["lds"] + dyn <= 160 * 1024, (name, r)
+
+
 # ---------------------------------------------------------------------------------------------- emitted hand-off ISA
 # The cross-workgroup hand-offs (split-K combines of gemm16s_kernel / gemm64s_kernel, per-block combine of the split P.V pass, the
 # persistent chain's granules) order relaxed agent-scope accesses by instruction selection, not by fences: partial results leave by
@@ -117,6 +163,13 @@ def test_chain_kernel_handoffs_are_granules_and_sc1_sweeps(kernels_isa):
     for n in names:
         ins = kernels_isa[n]
         sweeps = [l for l in ins if l.startswith("buffer_load_dwordx4")]
+        if n.startswith("_Z11step_kernel"):
+            # the attention workgroups' K / V prefetch reads cache rows written by EARLIER launches (the newest row comes through
+            # granules): plain buffer loads, 16 + 16 + 4 + 4 per issue site, two sites (kernel start, end of a block)
+            plain = [l for l in sweeps if " sc1" not in l]
+            assert len(plain) == 80, (n, len(plain))
+            sweeps = [l for l in sweeps if " sc1" in l]
+            assert len(sweeps) >= 20, n
         assert sweeps and all(" sc1" in l for l in sweeps), n
         granules = [l for l in ins if l.startswith("global_store_dwordx2") and " sc1" in l]
         assert len(granules) >= 3, n                                                  # y1, x1, m (+ x2 when the next in_proj follows)

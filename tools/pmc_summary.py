@@ -1,7 +1,8 @@
 """Summarise rocprofv3 --pmc passes (separate FETCH_SIZE and WRITE_SIZE runs, --output-format csv) into the JSON files bench.py and
 DESIGN.md quote.
 
-    python tools/pmc_summary.py kernel <fetch_dir> <write_dir> [out.json]     # dominant kernel (tools/pmc_kernel.py 5) -> profiles/pmc_chain.json
+    python tools/pmc_summary.py stepkernel <fetch_dir> <write_dir> [out.json] # dominant kernel (tools/pmc_kernel.py 6) -> profiles/pmc_step_kernel.json
+    python tools/pmc_summary.py kernel <fetch_dir> <write_dir> [out.json]     # the per-block chain launch (tools/pmc_kernel.py 5) -> profiles/pmc_chain.json
     python tools/pmc_summary.py step <fetch_dir> <write_dir> <decode_steps> [out.json]   # whole decode steps (tools/pmc_step.py)
 
 Counter units are KB; FETCH_SIZE is doubled (gfx950 reports half the bytes of wide coalesced reads, MI355X_MICROARCH.md, HBM).
@@ -31,17 +32,24 @@ def read_counter(d, counter):
     return rows
 
 
-def kernel_summary(fetch_dir, write_dir, out):
-    from bench import kernel_source_hash
-    want = "chain_kernel<4, 1, 8, 4, 2>"
-    alg = int((2048 * 2048 + 3 * 8192 * 2048 + 3072 * 2048) * 2)          # out_proj (once) + fc1 + fc2 + next in_proj, bf16
-    f = [v for n, v, *_ in read_counter(fetch_dir, "FETCH_SIZE") if want in n][8:]     # 8 warm-up launches dropped
-    w = [v for n, v, *_ in read_counter(write_dir, "WRITE_SIZE") if want in n][8:]
+def kernel_summary(fetch_dir, write_dir, out, which=5):
+    from bench import STEP_KERNEL_CTX, kernel_source_hash
+    if which == 6:
+        want, drop = "step_kernel<4, 2, 10, 5, 6>", 8
+        d, F, nqkv, nl, kvpos = 2048, 8192, 3072, 26, 2 * 512 * 2
+        alg = int(nl * (d * d + 3 * F * d) * 2 + (nl - 1) * nqkv * d * 2 + 9 * 1025 * d * 2 + 2 * nl * kvpos * STEP_KERNEL_CTX + 2 * (nl - 1) * kvpos)
+        what = f"whole decode step at {STEP_KERNEL_CTX} keys of context: 26 x (attention, out_proj x2, LayerNorm+fc1+SiLU-gate, fc2, next LayerNorm+in_proj+RoPE+KV append), norm_f + heads"
+    else:
+        want, drop = "chain_kernel<4, 1, 8, 4, 2>", 8
+        alg = int((2048 * 2048 + 3 * 8192 * 2048 + 3072 * 2048) * 2)          # out_proj (once) + fc1 + fc2 + next in_proj, bf16
+        what = "out_proj x2, LayerNorm+fc1+SiLU-gate, fc2, next LayerNorm+in_proj+RoPE+KV append"
+    f = [v for n, v, *_ in read_counter(fetch_dir, "FETCH_SIZE") if want in n][drop:]     # warm-up launches dropped
+    w = [v for n, v, *_ in read_counter(write_dir, "WRITE_SIZE") if want in n][drop:]
     fm, wm = sum(f) / len(f), sum(w) / len(w)
-    rec = {"kernel_name": f"void {want}(ChainArgs)  (out_proj x2, LayerNorm+fc1+SiLU-gate, fc2, next LayerNorm+in_proj+RoPE+KV append)", "kernel_source_sha256_16": kernel_source_hash(),
+    rec = {"kernel_name": f"void {want}(ChainArgs)  ({what})", "kernel_source_sha256_16": kernel_source_hash(),
            "date": time.strftime("%Y-%m-%d"), "launches": len(f),
-           "command": "rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d <dir> -- python3 tools/pmc_kernel.py 5   (second pass: --pmc WRITE_SIZE)",
-           "notes": "counter units KB; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half the bytes of wide coalesced reads); 8 warm-up launches dropped",
+           "command": f"rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d <dir> -- python3 tools/pmc_kernel.py {which}   (second pass: --pmc WRITE_SIZE)",
+           "notes": f"counter units KB; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half the bytes of wide coalesced reads); {drop} warm-up launches dropped",
            "fetch_size_kb_mean": round(fm, 1), "write_size_kb_mean": round(wm, 1), "hbm_read_bytes_per_launch": int(2 * fm * 1024),
            "hbm_write_bytes_per_launch": int(wm * 1024), "traffic_bytes_per_launch": int(2 * fm * 1024 + wm * 1024), "algorithmic_bytes_per_launch": alg}
     json.dump(rec, open(out, "w"), indent=1)
@@ -54,7 +62,7 @@ def step_summary(fetch_dir, write_dir, steps, out):
         fetch[n].append(v)
     for n, v, *_ in read_counter(write_dir, "WRITE_SIZE"):
         write[n].append(v)
-    decode = [n for n in fetch if any(k in n for k in ("gemv_kernel", "attn_", "embed_kernel", "sample_kernel", "frame_update_kernel", "chain_kernel"))]
+    decode = [n for n in fetch if any(k in n for k in ("gemv_kernel", "attn_", "embed_kernel", "sample_kernel", "frame_update_kernel", "chain_kernel", "step_kernel"))]
     per_kernel = {}
     total_r = total_w = 0.0
     for n in sorted(decode, key=lambda k: -sum(fetch[k])):
@@ -77,5 +85,7 @@ def step_summary(fetch_dir, write_dir, steps, out):
 if __name__ == "__main__":
     if sys.argv[1] == "kernel":
         kernel_summary(sys.argv[2], sys.argv[3], sys.argv[4] if len(sys.argv) > 4 else os.path.join(ROOT, "profiles", "pmc_chain.json"))
+    elif sys.argv[1] == "stepkernel":
+        kernel_summary(sys.argv[2], sys.argv[3], sys.argv[4] if len(sys.argv) > 4 else os.path.join(ROOT, "profiles", "pmc_step_kernel.json"), which=6)
     else:
         step_summary(sys.argv[2], sys.argv[3], int(sys.argv[4]), sys.argv[5] if len(sys.argv) > 5 else os.path.join(ROOT, "profiles", "r02_pmc_step.json"))

@@ -63,6 +63,9 @@ SIGNATURES = {
     "zn_sample_first": (C.c_int, [C.c_void_p, C.c_void_p]),
     "zn_decode_steps": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
     "zn_graph_active": (C.c_int, [C.c_void_p]),
+    "zn_gen_end": (C.c_int, [C.c_void_p]),
+    "zn_tenant_try_claim": (C.c_int, [C.c_int32, C.c_void_p]),
+    "zn_tenant_release": (C.c_int, [C.c_int32, C.c_void_p]),
     "zn_decode_path": (C.c_int, [C.c_void_p]),
     "zn_decode_path_detail": (C.c_int, [C.c_void_p]),
     "zn_all_stopped": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.c_void_p]),

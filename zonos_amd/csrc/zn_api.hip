@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -51,6 +52,8 @@ struct zn_handle_s {
   bool emb_valid = false;                   // x_emb holds the embedding of column st->offset
   unsigned long long* at_stamps = nullptr;   // diagnostic: [n_layer][8] timeline of the fused attention launch (second half of the chain stamp buffer)
   unsigned long long* ch_stamps = nullptr;   // diagnostic: [n_layer][32] timeline stamps of workgroup 0 (zn_debug_chain_stamps)
+  int device = 0;              // the HIP device the handle was created on
+  bool persist_ok = true;      // this handle may launch the persistent kernels (zn_gen_begin: it holds the device's tenancy, or nobody competes)
   int ch_variant = 0;          // 0 = shapes do not fit (launches path), 1 = <4,1,8,4,2> (Zonos-v0.1 dims), 2 = <1,1,2,1,1> (d_model 512)
   float* g16_part = nullptr;   // gemm16s_kernel: split-K partial tiles
   int* g16_tickets = nullptr;
@@ -75,6 +78,7 @@ struct zn_handle_s {
   bool stop_pending = false;
   // per-generation state (host mirror)
   bool gen_active = false;
+  bool gen_ended = false;      // zn_gen_end was called: the state stays readable, no further steps until the next zn_gen_begin
   int batch = 0, rows = 0, max_len = 0, t_total = 0, offset0 = 0, max_new = 0;
   float cfg_scale = 2.f;
   zn_sampling sp{};
@@ -135,8 +139,31 @@ static void free_graph(zn_handle h) {
   }
 }
 
+// The persistent kernels' hand-offs wait on EVERY workgroup of their grid, one per CU: two such launches on one device at the same time
+// (two handles generating concurrently, on any streams) could each hold part of the CUs and wait for the rest until the bounded
+// waits give up.  One generation per device owns the persistent kernels; a generation that begins while another handle's is active
+// on the same device runs the launches path (same results, no in-launch hand-offs).  Single-tenant per PROCESS: other processes
+// sharing the GPU are outside this library's reach.
+static std::mutex g_tenant_mu;
+static const void* g_tenant[64] = {};
+extern "C" int zn_tenant_try_claim(int32_t device, const void* owner) {
+  if (device < 0 || device >= 64 || !owner) return 0;
+  std::lock_guard<std::mutex> lk(g_tenant_mu);
+  if (g_tenant[device] && g_tenant[device] != owner) return 0;
+  g_tenant[device] = owner;
+  return 1;
+}
+extern "C" int zn_tenant_release(int32_t device, const void* owner) {
+  if (device < 0 || device >= 64) return 0;
+  std::lock_guard<std::mutex> lk(g_tenant_mu);
+  if (g_tenant[device] != owner) return 0;
+  g_tenant[device] = nullptr;
+  return 1;
+}
+
 extern "C" int zn_destroy(zn_handle h) {
   if (!h) return ZN_OK;
+  (void)zn_tenant_release(h->device, h);
   free_graph(h);
   void* ptrs[] = {h->emb_tables_dev, h->x, h->q, h->o1, h->mbuf, h->nbuf, h->logits_raw, h->last_logits, h->tok_raw, h->scores, h->cmax, h->pv_part, h->pv_tickets, h->pf_x, h->pf_n, h->pf_qkv, h->pf_a, h->pf_u, h->pf_m, h->pf_res, h->pf_zx, h->pf_xbc, h->pf_y, h->pf_g, h->qkv_tmp, h->fw_lengths, h->st, h->remaining, h->stopping, h->res, h->hn, h->m_zx, h->m_xbc, h->m_y, h->m_g, h->m_vg, h->g16_part, h->g16_tickets, h->ch_gy1, h->ch_gx1, h->ch_gx2, h->ch_gm, h->ch_epoch, h->ch_x2, h->x_emb, h->tail_ticket, h->ch_gqkv, h->ch_ga, h->stack_layers, h->ch_diag};
   for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -203,6 +230,7 @@ extern "C" int zn_create(const zn_config* cfg, const zn_weights* w, int32_t max_
   if (c.rope_mode < 0 || c.rope_mode > 2) ZN_FAIL((zn_handle) nullptr, ZN_ERR_ARG, "zn_create: rope_mode must be 0, 1 or 2");
   zn_handle h = new zn_handle_s();
   h->cfg = c; h->max_rows = max_rows; h->hd = hd; h->G = G;
+  if (hipGetDevice(&h->device) != hipSuccess) { (void)hipGetLastError(); h->device = 0; }
   if (c.arch == 1) {
     h->m_nheads = c.m_d_inner / c.m_headdim;
     h->m_conv_dim = c.m_d_inner + 2 * c.m_ngroups * c.m_d_state;
@@ -558,7 +586,7 @@ static int layer_decode(zn_handle h, int li, bf16_t* x, bf16_t* kv, int max_len,
 
 // The persistent chain serves the step when the model fits an instantiation, at batch 1 (two rows), unless switched off
 // (zn_debug_tune(8, 2), or ZN_CHAIN=0 in the environment at zn_create): 1.07 vs 1.16 ms per decode step at the Zonos-v0.1 dimensions.
-static bool chain_active(zn_handle h, int rows) { return h->ch_variant != 0 && rows == 2 && h->tune[8] != 2; }
+static bool chain_active(zn_handle h, int rows) { return h->ch_variant != 0 && rows == 2 && h->tune[8] != 2 && h->persist_ok; }
 
 // The chain never updates the residual stream in place (zn_chain_kernel.h): block li reads it from one buffer and leaves it
 // in the other.
@@ -922,6 +950,8 @@ extern "C" int zn_gen_begin(zn_handle h, int32_t batch, const void* const* kv_la
   h->cfg_scale = cfg_scale; h->sp = *sp;
   h->kv_layers.assign(kv_layers_dev, kv_layers_dev + h->cfg.n_layer);
   h->lengths = lengths_dev; h->codes = delayed_codes_dev;
+  // batch 1 on a model the persistent kernels serve: claim the device for them, or run this generation on the launches path
+  h->persist_ok = !(h->cfg.arch == 0 && h->ch_variant != 0 && batch == 1) || zn_tenant_try_claim(h->device, h) != 0;
   if (h->cfg.arch == 0 && h->ch_variant == 1) {
     if (!h->stack_checked) { h->stack_ok = stack_shapes_ok(h); h->stack_checked = true; }
     if (h->stack_ok) { int rc = build_stack_table(h); if (rc) return rc; }
@@ -938,6 +968,7 @@ extern "C" int zn_gen_begin(zn_handle h, int32_t batch, const void* const* kv_la
   h->len_hi = 0;
   for (int v : len0) if (v > h->len_hi) h->len_hi = v;
   h->gen_active = true;
+  h->gen_ended = false;
   h->stop_pending = false;
   h->emb_valid = false;
   return ZN_OK;
@@ -1184,7 +1215,7 @@ extern "C" int zn_debug_prefill_mode(zn_handle h, int32_t mode) { if (!h) return
 
 extern "C" int zn_prefill(zn_handle h, const void* hidden_dev, int32_t S, zn_stream stream) {
   if (!h) return ZN_ERR_ARG;
-  if (!h->gen_active) ZN_FAIL(h, ZN_ERR_STATE, "zn_prefill before zn_gen_begin");
+  if (!h->gen_active || h->gen_ended) ZN_FAIL(h, ZN_ERR_STATE, "zn_prefill before zn_gen_begin");
   if (!hidden_dev || S < 1 || S > h->max_len) ZN_FAIL(h, ZN_ERR_ARG, "zn_prefill: bad S=%d (max_len %d)", S, h->max_len);
   hipStream_t s = (hipStream_t)stream;
   const zn_config& c = h->cfg;
@@ -1242,7 +1273,7 @@ extern "C" int zn_sample_first(zn_handle h, zn_stream stream) {
 
 extern "C" int zn_decode_steps(zn_handle h, int32_t n, zn_stream stream) {
   if (!h) return ZN_ERR_ARG;
-  if (!h->gen_active) ZN_FAIL(h, ZN_ERR_STATE, "zn_decode_steps before zn_gen_begin");
+  if (!h->gen_active || h->gen_ended) ZN_FAIL(h, ZN_ERR_STATE, "zn_decode_steps before zn_gen_begin");
   if (n < 0) ZN_FAIL(h, ZN_ERR_ARG, "n < 0");
   hipStream_t s = (hipStream_t)stream;
   if (n > 0 && tail_fused(h) && !h->emb_valid) {   // first step of the generation: later ones find the embedding their predecessor's tail left
@@ -1281,6 +1312,13 @@ extern "C" int zn_decode_steps(zn_handle h, int32_t n, zn_stream stream) {
     i += run; h->len_hi += run;
   }
   HIPCHK(h, hipGetLastError());
+  return ZN_OK;
+}
+
+extern "C" int zn_gen_end(zn_handle h) {
+  if (!h) return ZN_ERR_ARG;
+  (void)zn_tenant_release(h->device, h);
+  h->gen_ended = true;
   return ZN_OK;
 }
 

@@ -206,6 +206,26 @@ class Zonos(nn.Module):
         kv_ptrs = (C.c_void_p * self.config.backbone.n_layer)(*[ip.key_value_memory_dict[i][0].data_ptr() for i in range(self.config.backbone.n_layer)])
         eng.call("zn_gen_begin", B, kv_ptrs, ip.max_seqlen, ip.lengths_per_sample.data_ptr(), delayed.data_ptr(), t_total, offset,
                  max_new_tokens, float(cfg_scale), C.byref(sp), st)
+        try:
+            offset = self._decode_loop(eng, ip, delayed, prefix_conditioning, offset, t_total, B, nq, callback, _trace, st)
+        finally:
+            # the device's persistent-kernel tenancy goes back once this generation's kernels have drained (include/zonos_hip.h)
+            torch.cuda.current_stream(dev).synchronize()
+            eng.call("zn_gen_end")
+        out = revert_delay_pattern(delayed.to(torch.int64)).cpu()     # one device->host copy (model.py:511)
+        valid_length = offset - nq
+        window = min(50, valid_length // 4)
+        for pos in range(max(0, valid_length - window), valid_length):   # model.py:516-528
+            if int((out[:, :, pos] == self.eos_token_id).sum()) >= nq // 2:
+                valid_length = pos
+                break
+        out = torch.where(out > 1024, 512, out)
+        out = torch.where(out == 1024, 0, out)
+        return torch.clamp(out[..., :valid_length], 0, 1023).to(dev)
+
+    def _decode_loop(self, eng, ip, delayed, prefix_conditioning, offset, t_total, B, nq, callback, _trace, st) -> int:
+        """Prefill, first frame and the hot loop (model.py:421-509); returns the final column offset."""
+        dev = self.device
         # prefill (generation_utils.py:236-244): [cond ‖ uncond] conditioning + embed(delayed[..., :P+1]) for both halves
         emb = self.embed_codes(delayed[..., :offset])
         hidden = torch.cat([prefix_conditioning.to(device=dev, dtype=torch.bfloat16), emb.repeat(2, 1, 1)], dim=1).contiguous()
@@ -265,16 +285,7 @@ class Zonos(nn.Module):
             if done.value:
                 offset = begun_at
         eng.call("zn_all_stopped", C.byref(done), st)      # also surfaces a timed-out in-kernel hand-off of the last steps
-        out = revert_delay_pattern(delayed.to(torch.int64)).cpu()     # one device->host copy (model.py:511)
-        valid_length = offset - nq
-        window = min(50, valid_length // 4)
-        for pos in range(max(0, valid_length - window), valid_length):   # model.py:516-528
-            if int((out[:, :, pos] == self.eos_token_id).sum()) >= nq // 2:
-                valid_length = pos
-                break
-        out = torch.where(out > 1024, 512, out)
-        out = torch.where(out == 1024, 0, out)
-        return torch.clamp(out[..., :valid_length], 0, 1023).to(dev)
+        return offset
 
     def _step_logits(self, eng: HipEngine, B: int, nq: int) -> torch.Tensor:
         buf = torch.empty(B, nq, 1025, dtype=torch.float32, device=self.device)
