@@ -51,7 +51,9 @@ def parse_args(argv=None):
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--seconds", type=float, default=10.0, help="target audio length per utterance")
-    ap.add_argument("--batch-per-gpu", type=int, default=1, help="utterances per GPU (default 1 = BASELINE config 2; 8 = config 3's share)")
+    ap.add_argument("--batch-per-gpu", type=int, default=1,
+                    help="utterances per GPU (default 1 = BASELINE config 2).  BASELINE config 3 (64 utterances over 8 GPUs) is "
+                         "`--gpus 8 --batch-per-gpu 8`; its one-GPU share is `--batch-per-gpu 8`")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dac", action="store_true")
     ap.add_argument("--dry-run", action="store_true",
@@ -74,7 +76,8 @@ def spawn_ranks(n: int, argv: list[str]) -> int:
     log("spawning: " + " ".join(cmd))
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    env.setdefault("OMP_NUM_THREADS", "8")
+    # the ranks build 1.6 B synthetic parameters on the host before the timed region: N ranks x all cores would oversubscribe it
+    env.setdefault("OMP_NUM_THREADS", str(max(1, min(8, (os.cpu_count() or 8) // max(1, n)))))
     p = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
     line = None
     for ln in p.stdout:
@@ -132,6 +135,24 @@ def run_rank(args) -> int:
                 dist.barrier(device_ids=[local_rank])
         if not dry:
             torch.cuda.synchronize()
+
+    # who is here: one line per rank on stderr, and ranks_seen in the JSON line, so that a scaling record proves N ranks on N devices
+    if world > 1 and "OMP_NUM_THREADS" not in os.environ:
+        torch.set_num_threads(max(1, min(8, (os.cpu_count() or 8) // world)))
+    me = {"rank": rank, "local_rank": local_rank, "device": "cpu (dry run)" if dry else torch.cuda.get_device_name(local_rank),
+          "host_threads": torch.get_num_threads()}
+    log(f"rank {rank}/{world}: device {me['device']}, {me['host_threads']} host threads")
+    ranks_seen = [me]
+    if dist is not None:
+        gathered = [None] * world
+        dist.all_gather_object(gathered, me)
+        ranks_seen = gathered
+        if rank == 0 and not dry:
+            try:
+                v = torch.cuda.nccl.version()
+                log(f"world_size {world}, backend nccl = RCCL {'.'.join(str(x) for x in v)}")
+            except Exception as e:                                # version query is informational only
+                log(f"world_size {world}, backend nccl (RCCL version unavailable: {e})")
 
     max_new = int(round(args.seconds * FRAME_RATE))             # 861 for 10 s
     l_c, B = 24, args.batch_per_gpu
@@ -215,6 +236,7 @@ def run_rank(args) -> int:
         "dac_tokens_per_sec": round(world * B * args.steps * steps_per_utt * 9 / elapsed, 1),
         "frames_per_sec": round(frames / elapsed, 1),
         "setup_s": round(setup_s, 1),
+        "ranks_seen": ranks_seen,
     }
     if dry:
         result["dry_run"] = True

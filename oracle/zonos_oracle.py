@@ -198,9 +198,13 @@ def rotary_half(x: torch.Tensor, cs: torch.Tensor) -> torch.Tensor:
     return torch.cat([x1 * cos - x2 * sin, x2 * cos + x1 * sin], dim=-1).to(x.dtype)
 
 
-def mamba2_step(w: dict, p: str, n: torch.Tensor, conv_state: torch.Tensor, ssm_state: torch.Tensor, m: dict, eps: float = 1e-5):
+def mamba2_step(w: dict, p: str, n: torch.Tensor, conv_state: torch.Tensor, ssm_state: torch.Tensor, m: dict, eps: float = 1e-5,
+                state32: torch.Tensor | None = None):
     """One token through a Mamba2 mixer (mamba_ssm Mamba2.step; Mamba-2 paper eq. for the SSD recurrence
-    h_t = exp(dt A) h_{t-1} + dt B x_t, y_t = C h_t + D x_t).  n [R, d] bf16; states updated in place."""
+    h_t = exp(dt A) h_{t-1} + dt B x_t, y_t = C h_t + D x_t).  n [R, d] bf16; states updated in place.
+    state32 (fp32, same shape as ssm_state): the state of a PREFILL in progress - the reference's S > 1 path
+    (Mamba2.forward -> mamba_chunk_scan_combined) carries the state in fp32 over the whole sequence and casts only the final
+    state into the bf16 cache, whereas Mamba2.step reads and writes the bf16 cache every token."""
     R = n.shape[0]
     di, H, P, N, G = m["d_inner"], m["nheads"], m["headdim"], m["d_state"], m["ngroups"]
     zxbcdt = F.linear(n, w[p + "in_proj.weight"])                                   # bf16 [R, 2*di + 2*G*N + H]
@@ -222,8 +226,12 @@ def mamba2_step(w: dict, p: str, n: torch.Tensor, conv_state: torch.Tensor, ssm_
     xh = x.float().view(R, H, P)
     Bg = Bm.float().view(R, G, N).repeat_interleave(H // G, dim=1)                   # [R, H, N]
     Cg = Cm.float().view(R, G, N).repeat_interleave(H // G, dim=1)
-    new_state = ssm_state.float() * dA[:, :, None, None] + (Bg * dtv[:, :, None])[:, :, None, :] * xh[:, :, :, None]
-    ssm_state.copy_(new_state.to(ssm_state.dtype))
+    prev = ssm_state.float() if state32 is None else state32
+    new_state = prev * dA[:, :, None, None] + (Bg * dtv[:, :, None])[:, :, None, :] * xh[:, :, :, None]
+    if state32 is None:
+        ssm_state.copy_(new_state.to(ssm_state.dtype))
+    else:
+        state32.copy_(new_state)
     y = (new_state * Cg[:, :, None, :]).sum(-1) + xh * w[p + "D"].float()[None, :, None]
     y = y.reshape(R, di).to(n.dtype)
     # RMSNormGated(norm_before_gate=False): rmsnorm(y * silu(z)) * weight, per group of d_inner / ngroups
@@ -242,8 +250,13 @@ def hybrid_backbone_forward(w: dict, x: torch.Tensor, cache: Cache, cfg: dict) -
     m = mamba2_dims(cfg)
     ao = attn_options(cfg)
     rms, res32 = bool(cfg.get("rms_norm")), bool(cfg.get("residual_in_fp32"))
-    rot = (lambda t, c: rope_apply(t, c)) if ao["mode"] == 0 else (lambda t, c: rotary_half(t, c)) if ao["mode"] == 1 else (lambda t, c: t)
+    # flash_attn's RotaryEmbedding (what mamba_ssm's MHA applies) caches cos / sin in the activations' dtype, for the interleaved
+    # form as for the half-split one
+    rot = ((lambda t, c: rope_apply(t, c.to(torch.bfloat16).float())) if ao["mode"] == 0 else (lambda t, c: rotary_half(t, c)) if ao["mode"] == 1
+           else (lambda t, c: t))
     outs = []
+    # a prefill (S > 1) carries every Mamba2 layer's SSM state in fp32 across its positions and rounds it into the cache once
+    st32 = {li: cache.kv[li][1][:R].float() for li in range(cfg["n_layer"]) if li not in cfg["attn_layer_idx"]} if S > 1 else {}
     for s_i in range(S):
         h, res = x[:, s_i], None
         pos = cache.lengths[:R].long() + s_i
@@ -269,9 +282,11 @@ def hybrid_backbone_forward(w: dict, x: torch.Tensor, cache: Cache, cfg: dict) -
                 h = F.linear(val * F.silu(gate), w[p + "mlp.fc2.weight"])
             else:
                 conv_state, ssm_state = cache.kv[li]
-                h = mamba2_step(w, p + "mixer.", n, conv_state[:R], ssm_state[:R], m, eps)
+                h = mamba2_step(w, p + "mixer.", n, conv_state[:R], ssm_state[:R], m, eps, state32=st32.get(li))
         out, _ = add_norm(h, res, w["backbone.norm_f.weight"], w["backbone.norm_f.bias"], eps, rms, res32)      # norm_f keeps its bias
         outs.append(out)
+    for li, s32 in st32.items():
+        cache.kv[li][1][:R].copy_(s32.to(cache.kv[li][1].dtype))
     return torch.stack(outs, dim=1)
 
 

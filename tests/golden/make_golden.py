@@ -182,10 +182,41 @@ def main():
             ip = InferenceParams(904, R, L - 1, 0, {0: (kv, None)}, torch.full((R,), L - 1, dtype=torch.int32))
             model.backbone.freqs_cis = model.backbone.allocate_inference_cache_pure(1, 8)[1]
             fc = model.backbone.freqs_cis[ip.lengths_per_sample.long().unsqueeze(-1)]
+            # per-op intermediates of the reference block (forward hooks on ITS modules; data only): n1 = norm(x), qkv = in_proj(n1),
+            # a = the SDPA output entering out_proj, o1 / o2 = the two out_proj calls (_torch.py:419-420), n2 = norm2(x1), u = fc1(n2),
+            # m = y * silu(gate) entering fc2, f = fc2(m); x1 = x + o2 follows from them
+            blk = model.backbone.layers[0]
+            rec, hooks = {}, []
+            def keep(name, multi=False):
+                def hook(mod, inp, outp):
+                    if multi:
+                        rec.setdefault(name, []).append((inp[0].detach().clone(), outp.detach().clone()))
+                    else:
+                        rec[name] = (inp[0].detach().clone(), outp.detach().clone())
+                return hook
+            hooks.append(blk.norm.register_forward_hook(keep("norm")))
+            hooks.append(blk.mixer.in_proj.register_forward_hook(keep("in_proj")))
+            hooks.append(blk.mixer.out_proj.register_forward_hook(keep("out_proj", multi=True)))
+            hooks.append(blk.norm2.register_forward_hook(keep("norm2")))
+            hooks.append(blk.mlp.fc1.register_forward_hook(keep("fc1")))
+            hooks.append(blk.mlp.fc2.register_forward_hook(keep("fc2")))
             with torch.inference_mode():
-                y = model.backbone.layers[0](x, ip, fc)
+                y = blk(x, ip, fc)
+            for h_ in hooks:
+                h_.remove()
             out[f"y_{L}"] = bf16_bits(y)
             out[f"knew_{L}"] = bf16_bits(kv[:, L - 1, 0])
+            out[f"vnew_{L}"] = bf16_bits(kv[:, L - 1, 1])
+            out[f"n1_{L}"] = bf16_bits(rec["norm"][1])
+            out[f"qkv_{L}"] = bf16_bits(rec["in_proj"][1])
+            out[f"a_{L}"] = bf16_bits(rec["out_proj"][0][0])
+            out[f"o1_{L}"] = bf16_bits(rec["out_proj"][0][1])
+            out[f"o2_{L}"] = bf16_bits(rec["out_proj"][1][1])
+            out[f"x1_{L}"] = bf16_bits(rec["norm2"][0])
+            out[f"n2_{L}"] = bf16_bits(rec["norm2"][1])
+            out[f"u_{L}"] = bf16_bits(rec["fc1"][1])
+            out[f"m_{L}"] = bf16_bits(rec["fc2"][0])
+            out[f"f_{L}"] = bf16_bits(rec["fc2"][1])
         np.savez_compressed(f"{HERE}/full_layer0.npz", seed=seed, **out)
         print("ops done")
 

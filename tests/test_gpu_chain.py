@@ -142,3 +142,30 @@ def test_whole_step_kernel_is_bit_identical_to_the_chain_path():
         eng.call("zn_debug_tune", 5, 704)
         eng.call("zn_debug_tune", 15, 1)
         eng.call("zn_debug_eos_bias", 0.0)
+
+
+def test_second_generation_on_the_device_takes_the_launches_path():
+    """One generation per device owns the persistent kernels (their hand-offs need every workgroup of the grid resident): a
+    generation that begins on ANOTHER handle while the first is still running gets the launches path, with the same codes; once
+    the first has ended (zn_gen_end) the device is free again."""
+    cfg = synth.CHAIN_CFG
+    m1, _ = build_model(cfg, 55, "cuda:0")
+    m2, _ = build_model(cfg, 55, "cuda:0")
+    cond = synth.conditioning(55, "cond", 2, 9, cfg["d_model"]).to("cuda:0")
+    e1, e2 = m1.engine(1), m2.engine(1)
+    alone = m2.generate(cond, max_new_tokens=12, sampling_params=GREEDY).cpu()
+    assert e2.lib.zn_decode_path(e2.h) == 1
+    seen = {}
+
+    def nested(frame, step, max_steps):
+        if step == 3:
+            seen["codes"] = m2.generate(cond, max_new_tokens=12, sampling_params=GREEDY).cpu()
+            seen["path"] = e2.lib.zn_decode_path(e2.h)
+        return True
+    out1 = m1.generate(cond, max_new_tokens=12, sampling_params=GREEDY, callback=nested).cpu()
+    assert e1.lib.zn_decode_path(e1.h) == 1, "the first generation keeps the persistent kernels"
+    assert seen["path"] == 0, "the generation begun meanwhile must run the launches path"
+    assert torch.equal(seen["codes"][..., :8], alone[..., :8])       # d 512: the two paths cut fc2's K differently (one ulp of a logit late in the run)
+    assert torch.equal(out1, alone)
+    again = m2.generate(cond, max_new_tokens=12, sampling_params=GREEDY).cpu()
+    assert e2.lib.zn_decode_path(e2.h) == 1 and torch.equal(again, alone)

@@ -75,28 +75,52 @@ def test_hybrid_backbone_forward_like_the_reference_loop(form):
         assert eq > 0.8 and err <= 0.13
 
 
-def test_hybrid_prefill_scan_is_bit_identical_to_single_steps():
-    """The sequence conv + selective scan kernels against the single-step kernels: an all-Mamba2 stack, the projections
-    row by row through the step's GEMV (prefill mode 2) so that both paths see the same operands: outputs of all
-    positions, conv windows and SSM states bit for bit equal; the batched projections (mode 1, MFMA GEMMs) stay
-    within one bf16 ulp of a few outputs."""
+def test_hybrid_prefill_scan_carries_the_state_in_fp32_like_the_reference_prefill():
+    """The sequence conv + selective scan kernels of a hybrid prefill (S > 1) on an all-Mamba2 stack.  The reference's prefill
+    (Mamba2.forward -> mamba_chunk_scan_combined) carries the SSM state in fp32 over the whole sequence and casts the final
+    state into the bf16 cache, its single step (Mamba2.step) rounds the cached state every token - so a prefill is compared with
+    the ORACLE's prefill (fp32 state; parity unpinned like everything hybrid), stepping with the oracle's stepping, and the two
+    differ from each other (reported).  The conv window is exact integer shifting either way: bit-identical between the paths.
+    Projections row by row through the step's GEMV (prefill mode 2) and batched through the MFMA GEMMs (mode 1)."""
     cfg = dict(synth.HYBRID_TINY_CFG, n_layer=3, attn_layer_idx=[])
     model, w = build_model(cfg, 43, "cuda:0")
     bb, d, R, S = model.backbone, cfg["d_model"], 2, 37
-    x = synth.conditioning(43, "scan.x", R, S, d).to("cuda:0")
+    x = synth.conditioning(43, "scan.x", R, S, d)
     eng = bb.engine(R)
     res = {}
     for mode in (0, 2, 1):
         eng.call("zn_debug_prefill_mode", mode)
         kv = bb.allocate_inference_cache(R, 64)
         ip = InferenceParams(64, R, 0, 0, kv, torch.zeros(R, dtype=torch.int32, device="cuda:0"))
-        out = bb(x, ip).cpu()
+        out = bb(x.to("cuda:0"), ip).cpu()
         res[mode] = (out, [(kv[i][0].cpu().clone(), kv[i][1].cpu().clone()) for i in range(cfg["n_layer"])])
     eng.call("zn_debug_prefill_mode", 1)
-    assert torch.equal(_bits(res[0][0]), _bits(res[2][0]))
-    for (c0, s0), (c2, s2) in zip(res[0][1], res[2][1]):
-        assert torch.equal(_bits(c0), _bits(c2)) and torch.equal(_bits(s0), _bits(s2))
-    eq = float((_bits(res[0][0]) == _bits(res[1][0])).float().mean())
-    st = min(float((_bits(a[1]) == _bits(b[1])).float().mean()) for a, b in zip(res[0][1], res[1][1]))
-    print(f"\n[hybrid prefill] batched projections vs single steps: outputs bit-equal {eq:.4f}, SSM state bit-equal >= {st:.4f}")
-    assert eq > 0.98 and st > 0.98
+    # the oracle, both ways
+    cache_p = zo.hybrid_setup_cache(cfg, R, 64)
+    ref_p = zo.backbone_forward(w, x, cache_p, cfg)                                   # one call with S > 1: fp32 state
+    cache_s = zo.hybrid_setup_cache(cfg, R, 64)
+    ref_s = []
+    for s_i in range(S):
+        ref_s.append(zo.backbone_forward(w, x[:, s_i:s_i + 1], cache_s, cfg))
+        cache_s.seqlen_offset += 1
+        cache_s.lengths[:] += 1
+    ref_s = torch.cat(ref_s, 1)
+
+    def eq(a, b):
+        return float((_bits(a) == _bits(b)).float().mean())
+    # layer 0 sees the same inputs on both paths: its conv window (exact shifting) is bit-identical; deeper layers already see
+    # the two paths' different outputs
+    assert torch.equal(_bits(res[0][1][0][0]), _bits(res[2][1][0][0])), "conv window of layer 0: sequence kernel vs single steps"
+    o_scan, o_step = eq(res[2][0], ref_p), eq(res[0][0], ref_s)
+    s_scan = min(eq(res[2][1][i][1], cache_p.kv[i][1]) for i in range(cfg["n_layer"]))
+    s_step = min(eq(res[0][1][i][1], cache_s.kv[i][1]) for i in range(cfg["n_layer"]))
+    o_b, s_b = eq(res[1][0], ref_p), min(eq(res[1][1][i][1], cache_p.kv[i][1]) for i in range(cfg["n_layer"]))
+    cross = min(eq(res[2][1][i][1], res[0][1][i][1]) for i in range(cfg["n_layer"]))
+    print(f"\n[hybrid prefill, parity unpinned] scan vs oracle prefill: outputs bit-equal {o_scan:.4f}, final SSM state {s_scan:.4f}; "
+          f"steps vs oracle steps: {o_step:.4f} / {s_step:.4f}; batched projections vs oracle prefill: {o_b:.4f} / {s_b:.4f}; "
+          f"prefill state vs stepped state bit-equal {cross:.4f} (they differ by design: fp32 carry vs per-token bf16 rounding)")
+    assert o_scan > 0.97 and s_scan > 0.99
+    assert o_step > 0.97 and s_step > 0.99
+    assert o_b > 0.95 and s_b > 0.98
+    err = float((res[2][0].float() - ref_p.float()).abs().max())
+    assert err <= 0.07

@@ -7,6 +7,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ZONOS_HIP_LIB") or os.path.join(_HERE, "libzonos_hip.so")   # the override selects an experimental build (A/B runs)
@@ -115,12 +116,20 @@ def load() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    path = os.environ.get("ZONOS_HIP_LIB_VARIANT")      # development only (tools/build_variants.py: A/B of compile-time kernel parameters)
+    if path:
+        path = os.path.join(os.path.dirname(os.path.dirname(LIB_PATH)), "build", "variants", f"libzonos_hip_{path}.so")
+        if not os.path.exists(path):
+            raise ZonosHipError(f"{path} not found (ZONOS_HIP_LIB_VARIANT)")
+        print(f"[zonos_amd] loading variant library {path}", file=sys.stderr, flush=True)
+    else:
+        path = LIB_PATH
     if not os.path.exists(LIB_PATH):
         raise ZonosHipError(f"{LIB_PATH} not found: build it with `python -m zonos_amd.build` "
                             "(the HIP library is the only execution path; there is no CPU fallback)")
     import torch  # noqa: F401  -- must come first: the library shares torch's HIP runtime (same libamdhip64 SONAME);
     #                      loading /opt/rocm's copy before torch's leaves two runtimes in the process
-    lib = C.CDLL(LIB_PATH)
+    lib = C.CDLL(path)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the .so does not export it
         fn.restype, fn.argtypes = res, args

@@ -145,8 +145,9 @@ class HipEngine:
         h, hkv = ao["num_heads"], ao["num_heads_kv"]
         self.head_dim = cfg.d_model // h
         rope = rope_table(ROPE_POSITIONS, self.head_dim)
-        if cfg.ssm_cfg and ao["rope_mode"] == 1:
-            # flash_attn's RotaryEmbedding (what mamba_ssm's MHA applies) caches cos / sin in the activations' dtype
+        if cfg.ssm_cfg and ao["rope_mode"] in (0, 1):
+            # flash_attn's RotaryEmbedding (what mamba_ssm's MHA applies) caches cos / sin in the activations' dtype, for the
+            # interleaved form as for the half-split one (the transformer stack's own RoPE, _torch.py:29-68, stays fp32)
             rope = rope.to(torch.bfloat16).float()
         self.rope = rope.to(dev)
         zc = _lib.zn_config(d_model=cfg.d_model, n_layer=cfg.n_layer, n_heads=h, n_heads_kv=hkv, d_ff=cfg.attn_mlp_d_intermediate,

@@ -262,8 +262,8 @@ __global__ __launch_bounds__(256) void mamba_gated_norm_kernel(MambaArgs a) {
 // ------------------------------------------------------------------------------------------------ Mamba2 over a sequence
 // Prefill of S positions (the reference calls mamba_chunk_scan_combined there, _mamba_ssm.py:106-119 -> Mamba2.forward; its
 // chunked SSD form computes the same recurrence): rows of every [.][S] operand are position-major inside an utterance
-// row, index r * S + s.  Both kernels repeat the single-step kernels' arithmetic statement for statement, so a prefill of
-// S positions leaves the conv window, the SSM state and every output bit-identical to S single steps on the same inputs.
+// row, index r * S + s.  The conv kernel repeats the single-step arithmetic statement for statement (window and outputs bit-identical
+// to S single steps); the scan keeps its state in fp32 across the positions, as the reference's prefill does (below).
 
 // causal conv + SiLU along the sequence: one thread per (row, channel) walks the S positions with the window in registers
 __global__ __launch_bounds__(256) void mamba_conv_seq_kernel(MambaArgs a, int S) {
@@ -305,9 +305,12 @@ __global__ __launch_bounds__(256) void mamba_conv_seq_kernel(MambaArgs a, int S)
   *(u32x2_t*)sp = st;
 }
 
-// selective scan: one workgroup per (row, head) keeps its 64 x N state tile in registers (bf16-rounded after every
-// position, as the cache holds it between single steps) and walks the positions; the next position's B, C, x, dt
-// are requested while the current one is computed.
+// selective scan: one workgroup per (row, head) keeps its 64 x N state tile in fp32 registers across the whole sequence and rounds it
+// to the cache's bf16 ONCE, when it is stored: that is what the reference's S > 1 path does (Mamba2.forward ->
+// mamba_chunk_scan_combined carries the state in fp32 and casts the final state into the cache, _mamba_ssm.py:106-119), unlike its
+// S == 1 path (Mamba2.step -> selective_state_update on the bf16 cache: one rounding per token, mamba_ssm_kernel above).  A prefill is
+// therefore NOT bit-identical to stepping the same tokens one by one (it is more accurate); position s's output uses the
+// unrounded state either way.  The next position's B, C, x, dt are requested while the current one is computed.
 template <int N>
 __global__ __launch_bounds__(256) void mamba_scan_kernel(MambaArgs a, int S) {
   constexpr int P = 64, NT = N / 4, NV = NT / 8;
@@ -315,9 +318,13 @@ __global__ __launch_bounds__(256) void mamba_scan_kernel(MambaArgs a, int S) {
   const int p = tid >> 2, q = tid & 3;
   const int grp = h / (a.nheads / a.ngroups);
   bf16_t* sp = a.ssm_state + (((size_t)r * a.nheads + h) * P + p) * N + q * NT;
-  u32x4 sv[NV];
+  float sf[NT];
 #pragma unroll
-  for (int i = 0; i < NV; ++i) sv[i] = ld16(sp + i * 8);
+  for (int i = 0; i < NV; ++i) {
+    const u32x4 v = ld16(sp + i * 8);
+    sf[8 * i + 0] = lo_f(v.x); sf[8 * i + 1] = hi_f(v.x); sf[8 * i + 2] = lo_f(v.y); sf[8 * i + 3] = hi_f(v.y);
+    sf[8 * i + 4] = lo_f(v.z); sf[8 * i + 5] = hi_f(v.z); sf[8 * i + 6] = lo_f(v.w); sf[8 * i + 7] = hi_f(v.w);
+  }
   const float A = -expf(bf2f(a.A_log[h]));
   const float Dh = bf2f(a.D[h]);
   const float dtb = bf2f(a.dt_bias[h]);
@@ -346,24 +353,22 @@ __global__ __launch_bounds__(256) void mamba_scan_kernel(MambaArgs a, int S) {
     float y = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-      const unsigned sw[4] = {sv[i].x, sv[i].y, sv[i].z, sv[i].w};
       const unsigned bw[4] = {bv[i].x, bv[i].y, bv[i].z, bv[i].w};
       const unsigned cw[4] = {cv[i].x, cv[i].y, cv[i].z, cv[i].w};
-      unsigned ow[4];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const float n0 = __fadd_rn(__fmul_rn(lo_f(sw[e]), dA), __fmul_rn(__fmul_rn(lo_f(bw[e]), dtv), x));
-        const float n1 = __fadd_rn(__fmul_rn(hi_f(sw[e]), dA), __fmul_rn(__fmul_rn(hi_f(bw[e]), dtv), x));
+        const float n0 = __fadd_rn(__fmul_rn(sf[8 * i + 2 * e], dA), __fmul_rn(__fmul_rn(lo_f(bw[e]), dtv), x));
+        const float n1 = __fadd_rn(__fmul_rn(sf[8 * i + 2 * e + 1], dA), __fmul_rn(__fmul_rn(hi_f(bw[e]), dtv), x));
         y = fmaf(n0, lo_f(cw[e]), y);
         y = fmaf(n1, hi_f(cw[e]), y);
-        ow[e] = pack2(n0, n1);
+        sf[8 * i + 2 * e] = n0; sf[8 * i + 2 * e + 1] = n1;
       }
-      sv[i] = u32x4{ow[0], ow[1], ow[2], ow[3]};
     }
     y += dpp_mov<ZN_DPP_XOR1>(y);
     y += dpp_mov<ZN_DPP_XOR2>(y);
     if (q == 0) a.y[((size_t)r * S + s) * a.d_inner + h * P + p] = f2bf(__fadd_rn(y, __fmul_rn(x, Dh)));
   }
 #pragma unroll
-  for (int i = 0; i < NV; ++i) *(u32x4*)(sp + i * 8) = sv[i];
+  for (int i = 0; i < NV; ++i)
+    *(u32x4*)(sp + i * 8) = u32x4{pack2(sf[8 * i], sf[8 * i + 1]), pack2(sf[8 * i + 2], sf[8 * i + 3]), pack2(sf[8 * i + 4], sf[8 * i + 5]), pack2(sf[8 * i + 6], sf[8 * i + 7])};
 }

@@ -35,6 +35,13 @@
 #ifndef ZN_SK_PARK
 #define ZN_SK_PARK 4                                        // tiles per compute wave parked in LDS during the attention (>= T_OUT)
 #endif
+#ifndef ZN_SK_HELP
+#define ZN_SK_HELP 0                                        // tiles per compute wave that a helper wave (6, 7) holds in ITS registers during the attention and
+#endif                                                      // drops into the LDS slots op 1 has left (0: helper waves only run the barriers).  Measured, 400 tokens:
+                                                            // 2 at block start 0.8773 ms per step vs 0.8771 without; 2 after P(0) 0.8871 (y1 hand-off 2.3 -> 3.4 us)
+#ifndef ZN_SK_HELP_AT
+#define ZN_SK_HELP_AT 0                                     // where the helper requests them: 0 = block start, 1 = after B(0) (attention output in), 2 = after P(0)
+#endif
 #define ZN_SK_MAXKEYS 1024                                  // two 512-key blocks: longer contexts go down the per-block path
 #define ZN_SK_DYN_LDS (ZN_SK_CW * ZN_SK_PARK * 8192)        // parked tiles (streaming role) / StepAttnLds (attention role)
 #ifndef ZN_SK_PACE_SHIFT
@@ -354,63 +361,125 @@ __global__ __launch_bounds__(ZN_SK_THREADS) void step_kernel(ChainArgs a) {
   auto op_of = [](int s) constexpr { return s < S1 ? 0 : s < S2 ? 1 : s < S3 ? 2 : s < S4 ? 3 : 4; };
   auto first_of = [](int op) constexpr { return op == 0 ? 0 : op == 1 ? S1 : op == 2 ? S2 : op == 3 ? S3 : S4; };
 
+  // ---- the block's tiles ("loads" l = 0 .. NL-1 in consumption order: op 0's T_OUT tiles, which op 1 reads again, then fc1, fc2, in_proj / heads)
+  // and where each comes from: PARK = streamed through the wave's register buffers into its LDS slots 0 .. P-1 while the attention runs;
+  // HELP = held by a helper wave in ITS registers over the attention and dropped into slots 0 .. NH-1 once op 1 has read them for the
+  // last time (the last NH fc1 tiles); REG = the rotating register buffers, requested NB tiles ahead.
+  constexpr int L_F2 = T_OUT + T_FC1;                         // first load of fc2
+  constexpr int NH = ZN_SK_HELP;
+  static_assert(NH >= 0 && NH <= T_OUT && NH < T_FC1 - (P - T_OUT), "helper tiles take the slots of op 0's tiles");
+  auto src_of = [](int l) constexpr { return l < P ? 1 : (l >= L_F2 - NH && l < L_F2) ? 2 : 0; };           // 0 REG, 1 PARK, 2 HELP
+  auto slot_of = [](int l) constexpr { return l < P ? l : l - (L_F2 - NH); };
+  auto regk = [](int l) constexpr { int k = 0; for (int i = 0; i < l; ++i) k += (i < P ? 1 : (i >= L_F2 - NH && i < L_F2) ? 2 : 0) == 0; return k; };   // REG loads before l
+  auto nth_reg = [](int k) constexpr { int n = 0; for (int i = 0; i < NL; ++i) { if ((i < P ? 1 : (i >= L_F2 - NH && i < L_F2) ? 2 : 0) == 0) { if (n == k) return i; ++n; } } return -1; };
+  constexpr int NREG = NL - P - NH;
+  auto slot_of_load = [](int l) constexpr { return l < S1 ? l : l + T_OUT; };
+  auto load_of_slot = [](int s) constexpr { return s < S1 ? s : s - T_OUT; };
+  struct WT { u32x4 a[NCH], b[NCH]; };
+  // tile of slot s for compute wave w: exists?, weight pointers of rows A and B (lane's first chunk), result index
+  struct LW { const bf16_t *out, *fc1, *fc2, *in; };           // the block's weight matrices, read from the layer table ONCE per block (SGPRs)
+  auto tile_of = [&](const LW Lr, int rows_in, int n_in, int s_in, int s, int w, bool& ok, const bf16_t*& pa, const bf16_t*& pb, int& ridx) {
+    const int op = op_of(s), t = s - first_of(op);
+    if (op == 3) {
+      const int qt = w, j = t;
+      ok = j < n_out;
+      const int u = s_out + (ok ? j : 0);
+      pa = Lr.fc2 + (size_t)(2 * u) * (4 * D) + qt * D + lane * 8;
+      pb = pa + 4 * D;
+      ridx = j * 4 + qt;
+      return;
+    }
+    const int j = w + CW * t;
+    const int n = op <= 1 ? n_out : op == 2 ? n_fc1 : n_in;
+    const int st = op <= 1 ? s_out : op == 2 ? s_fc1 : s_in;
+    ok = j < n;
+    const int u = st + (ok ? j : 0);
+    ridx = j;
+    if (op <= 1) { pa = Lr.out + (size_t)(2 * u) * D + lane * 8; pb = pa + D; }
+    else if (op == 2) { pa = Lr.fc1 + (size_t)u * D + lane * 8; pb = pa + (size_t)F * D; }
+    else { pa = Lr.in + (size_t)(2 * u) * D + lane * 8; pb = (2 * u + 1 < rows_in) ? pa + D : pa; }   // half pair: row B repeats row A, result dropped
+  };
+  auto park_of = [&](int w) { return reinterpret_cast<u32x4*>(zn_dyn_lds) + (size_t)w * (P * 2 * NCH * 64) + lane; };
+
   if (wave >= CW + 2) {
+    // ------------------------------------------------------------------------------------ helper waves
+    const int hw = wave - (CW + 2);                           // serves compute waves 2 hw and 2 hw + 1
+    WT hb[2 * (NH > 0 ? NH : 1)];
 #pragma unroll 1
-    for (int li = 0; li < a.n_layer; ++li)
+    for (int li = 0; li < a.n_layer; ++li) {
+      const LW Lr{a.layers[li].W_out, a.layers[li].W_fc1, a.layers[li].W_fc2, a.layers[li].W_in};
+      auto hload = [&]() {
+        if constexpr (NH > 0) {
+          zn_static_for<0, 2 * NH>([&](auto IC) {
+            constexpr int i = decltype(IC)::value, cwi = i / NH, hh = i % NH;
+            bool ok; const bf16_t *pa, *pb; int ridx;
+            tile_of(Lr, a.nqkv, 0, 0, slot_of_load(L_F2 - NH + hh), 2 * hw + cwi, ok, pa, pb, ridx);     // an fc1 tile: the op-4 arguments are unused
+            if (ok) {
 #pragma unroll
-      for (int b = 0; b < NBAR; ++b) __syncthreads();
+              for (int c2 = 0; c2 < NCH; ++c2) { hb[i].a[c2] = ld_nt16(pa + c2 * 512); hb[i].b[c2] = ld_nt16(pb + c2 * 512); }
+            }
+          });
+        }
+      };
+      if constexpr (ZN_SK_HELP_AT == 0) hload();
+      __syncthreads();                                        // B(0)
+      if constexpr (ZN_SK_HELP_AT == 1) hload();
+      __syncthreads();                                        // A(0)
+      __syncthreads();                                        // P(0)
+      if constexpr (ZN_SK_HELP_AT == 2) hload();
+      __syncthreads();                                        // B(1)
+      __syncthreads();                                        // A(1): op 1 has read slots 0 .. T_OUT-1 for the last time
+      if constexpr (NH > 0) {
+        zn_static_for<0, 2 * NH>([&](auto IC) {
+          constexpr int i = decltype(IC)::value, cwi = i / NH, hh = i % NH;
+          bool ok; const bf16_t *pa, *pb; int ridx;
+          tile_of(Lr, a.nqkv, 0, 0, slot_of_load(L_F2 - NH + hh), 2 * hw + cwi, ok, pa, pb, ridx);
+          if (ok) {
+            u32x4* pk = park_of(2 * hw + cwi);
+#pragma unroll
+            for (int c2 = 0; c2 < NCH; ++c2) { pk[(hh * 2 * NCH + c2) * 64] = hb[i].a[c2]; pk[(hh * 2 * NCH + NCH + c2) * 64] = hb[i].b[c2]; }
+          }
+        });
+      }
+#pragma unroll
+      for (int b = 5; b < NBAR; ++b) __syncthreads();         // P(1) (the tiles are in LDS before any compute wave passes B(2)) ... P(4)
+    }
     return;
   }
 
   if (wave < CW) {
     // ------------------------------------------------------------------------------------ compute waves
-    struct WT { u32x4 a[NCH], b[NCH]; };
     WT bufs[NB];                                           // every index below is a compile-time constant: the buffers live in registers
-    u32x4* park = reinterpret_cast<u32x4*>(zn_dyn_lds) + (size_t)wave * (P * 2 * NCH * 64) + lane;
+    u32x4* park = park_of(wave);
     static_assert(CW == 4, "fc2 splits K over the four compute waves");
+    const bool st_on = a.stamps && sc == 0 && wave == 0 && lane == 0;
 #pragma unroll 1
     for (int li = 0; li < a.n_layer; ++li) {
-      const StackLayer& Lr = a.layers[li];
-      const bf16_t *W_out = Lr.W_out, *W_fc1 = Lr.W_fc1, *W_fc2 = Lr.W_fc2, *W_in = Lr.W_in;
+      const LW Lr{a.layers[li].W_out, a.layers[li].W_fc1, a.layers[li].W_fc2, a.layers[li].W_in};
       const bool last = li + 1 == a.n_layer;
       const int rows_in = last ? a.heads_rows : a.nqkv;
       const int n_in = last ? n_hd : n_qkv, s_in = last ? s_hd : s_qkv;
       const unsigned tag = tag0 + (unsigned)li;
-      // tile of slot s for this wave: exists?, weight pointers of rows A and B (lane's first chunk), result index
-      auto tile = [&](int s, bool& ok, const bf16_t*& pa, const bf16_t*& pb, int& ridx) {
-        const int op = op_of(s), t = s - first_of(op);
-        if (op == 3) {
-          const int qt = wave, j = t;
-          ok = j < n_out;
-          const int u = s_out + (ok ? j : 0);
-          pa = W_fc2 + (size_t)(2 * u) * (4 * D) + qt * D + lane * 8;
-          pb = pa + 4 * D;
-          ridx = j * 4 + qt;
-          return;
-        }
-        const int j = wave + CW * t;
-        const int n = op <= 1 ? n_out : op == 2 ? n_fc1 : n_in;
-        const int st = op <= 1 ? s_out : op == 2 ? s_fc1 : s_in;
-        ok = j < n;
-        const int u = st + (ok ? j : 0);
-        ridx = j;
-        if (op <= 1) { pa = W_out + (size_t)(2 * u) * D + lane * 8; pb = pa + D; }
-        else if (op == 2) { pa = W_fc1 + (size_t)u * D + lane * 8; pb = pa + (size_t)F * D; }
-        else { pa = W_in + (size_t)(2 * u) * D + lane * 8; pb = (2 * u + 1 < rows_in) ? pa + D : pa; }   // half pair: row B repeats row A, result dropped
-      };
-      auto slot_of_load = [](int l) constexpr { return l < S1 ? l : l + T_OUT; };
-      auto load_of_slot = [](int s) constexpr { return s < S1 ? s : s < S2 ? s - T_OUT : s - T_OUT; };
-      auto load_req = [&](auto LC) {
-        constexpr int l = decltype(LC)::value;
-        if constexpr (l < NL) {
+      const bool stamped = st_on && li == a.stamp_layer;
+      auto cstamp = [&](int i) { if (stamped) a.stamps[40 + i] = __builtin_amdgcn_s_memrealtime(); };
+      auto tile = [&](int s, bool& ok, const bf16_t*& pa, const bf16_t*& pb, int& ridx) { tile_of(Lr, rows_in, n_in, s_in, s, wave, ok, pa, pb, ridx); };
+      // load l into register buffer b
+      auto load_into = [&](auto LC, auto BC) {
+        constexpr int l = decltype(LC)::value, b = decltype(BC)::value;
+        if constexpr (l >= 0 && l < NL) {
           bool ok; const bf16_t *pa, *pb; int ridx;
           tile(slot_of_load(l), ok, pa, pb, ridx);
           if (ok) {                                         // wave-uniform
-            WT& w = bufs[l % NB];
+            WT& w = bufs[b];
 #pragma unroll
             for (int c2 = 0; c2 < NCH; ++c2) { w.a[c2] = ld_nt16(pa + c2 * 512); w.b[c2] = ld_nt16(pb + c2 * 512); }
           }
         }
+      };
+      // REG load number k lives in buffer (k + P) % NB: the buffer that the prefetch phase's transit of load k + P - NB ... has just left
+      auto reg_req = [&](auto KC) {
+        constexpr int k = decltype(KC)::value;
+        if constexpr (k >= 0 && k < NREG) load_into(std::integral_constant<int, nth_reg(k)>{}, std::integral_constant<int, (k + P) % NB>{});
       };
       u32x4 xr[NCH][R];
       auto process = [&](int s, const WT& w) {
@@ -431,16 +500,21 @@ __global__ __launch_bounds__(ZN_SK_THREADS) void step_kernel(ChainArgs a) {
           for (int r = 0; r < R; ++r) { s_res[par][ridx][0][r] = accA[r]; s_res[par][ridx][1][r] = accB[r]; }
         }
       };
-      // request raised by the last use of slot s's register buffer (-1: none): parked tiles and op 1's re-use raise nothing
-      auto raised_by = [](int s) constexpr {
-        const int op = s < S1 ? 0 : s < S2 ? 1 : s < S3 ? 2 : s < S4 ? 3 : 4;
-        if (op <= 1) return -1;
-        const int l = s - T_OUT;
-        if (l < P) return -1;
-        return l + NB < NL ? l + NB : -1;
+      // REG request raised by the last use of slot s's register buffer (-1: none)
+      auto raised_by = [&](int s) constexpr {
+        const int l = s < S1 ? s : s - T_OUT;
+        if (s >= S1 && s < S2) return -1;                   // op 1 re-reads op 0's (parked) tiles
+        if ((l < P ? 1 : (l >= L_F2 - NH && l < L_F2) ? 2 : 0) != 0) return -1;
+        int k = 0; for (int i = 0; i < l; ++i) k += (i < P ? 1 : (i >= L_F2 - NH && i < L_F2) ? 2 : 0) == 0;
+        return k + NB < NREG ? k + NB : -1;
       };
-      // ---- prefetch while the attention runs: loads 0 .. P-1 through the register buffers into LDS, loads P .. P+NB-1 stay in flight
-      zn_static_for<0, NB>([&](auto LC) { load_req(LC); });
+      // ---- prefetch while the attention runs: loads 0 .. P-1 through the register buffers into LDS, then the first NB REG loads stay in flight
+      cstamp(0);
+      zn_static_for<0, NB>([&](auto IC) {
+        constexpr int i = decltype(IC)::value;
+        if constexpr (i < P) load_into(std::integral_constant<int, i>{}, std::integral_constant<int, i % NB>{});
+        else reg_req(std::integral_constant<int, i - P>{});
+      });
       zn_static_for<0, P>([&](auto LC) {
         constexpr int l = decltype(LC)::value;
         bool ok; const bf16_t *pa, *pb; int ridx;
@@ -450,8 +524,11 @@ __global__ __launch_bounds__(ZN_SK_THREADS) void step_kernel(ChainArgs a) {
 #pragma unroll
           for (int c2 = 0; c2 < NCH; ++c2) { park[(l * 2 * NCH + c2) * 64] = w.a[c2]; park[(l * 2 * NCH + NCH + c2) * 64] = w.b[c2]; }
         }
-        load_req(std::integral_constant<int, l + NB>{});
+        constexpr int i = l + NB;                           // next item of [transit 0 .. P-1, REG 0 .. NB-1] into the buffer just drained
+        if constexpr (i < P) load_into(std::integral_constant<int, i>{}, std::integral_constant<int, i % NB>{});
+        else reg_req(std::integral_constant<int, i - P>{});
       });
+      cstamp(1);
       zn_static_for<0, NS>([&](auto SC) {
         constexpr int s = decltype(SC)::value;
         constexpr int op = op_of(s);
@@ -461,8 +538,8 @@ __global__ __launch_bounds__(ZN_SK_THREADS) void step_kernel(ChainArgs a) {
             __syncthreads();                                // P(op-1): ... and published; the requests held back for that go out now
             if constexpr (((MASK >> (op - 1)) & 1) != 0) {
               zn_static_for<first_of(op - 1), first_of(op)>([&](auto QC) {
-                constexpr int q = decltype(QC)::value, l = raised_by(q);
-                if constexpr (l >= 0) { if constexpr (op_of(slot_of_load(l >= 0 ? l : 0)) != op - 1) load_req(std::integral_constant<int, (l >= 0 ? l : 0)>{}); }
+                constexpr int q = decltype(QC)::value, k = raised_by(q);
+                if constexpr (k >= 0) { if constexpr (op_of(slot_of_load(nth_reg(k >= 0 ? k : 0))) != op - 1) reg_req(std::integral_constant<int, (k >= 0 ? k : 0)>{}); }
               });
             }
           }
@@ -486,24 +563,28 @@ __global__ __launch_bounds__(ZN_SK_THREADS) void step_kernel(ChainArgs a) {
 #pragma unroll
               for (int r = 0; r < R; ++r) xr[c2][r] = *(const u32x4*)&s_act[r * D + (c2 * 64 + lane) * 8];
           }
+          cstamp(2 + 2 * op);
         }
         constexpr int l = load_of_slot(s);
-        if constexpr (l < P) {                              // parked tile: from LDS
+        if constexpr (src_of(l) != 0) {                     // parked tile (own prefetch or a helper wave's): from LDS
           bool ok; const bf16_t *pa, *pb; int ridx;
           tile(s, ok, pa, pb, ridx);
           if (ok) {
+            constexpr int sl = slot_of(l);
             WT w;
 #pragma unroll
-            for (int c2 = 0; c2 < NCH; ++c2) { w.a[c2] = park[(l * 2 * NCH + c2) * 64]; w.b[c2] = park[(l * 2 * NCH + NCH + c2) * 64]; }
+            for (int c2 = 0; c2 < NCH; ++c2) { w.a[c2] = park[(sl * 2 * NCH + c2) * 64]; w.b[c2] = park[(sl * 2 * NCH + NCH + c2) * 64]; }
             process(s, w);
           }
         } else {
-          process(s, bufs[l % NB]);
+          constexpr int k = regk(l);
+          process(s, bufs[(k + P) % NB]);
           constexpr int rq = raised_by(s);
           if constexpr (rq >= 0) {
-            if constexpr (((MASK >> op) & 1) == 0 || op_of(slot_of_load(rq >= 0 ? rq : 0)) == op) load_req(std::integral_constant<int, (rq >= 0 ? rq : 0)>{});
+            if constexpr (((MASK >> op) & 1) == 0 || op_of(slot_of_load(nth_reg(rq >= 0 ? rq : 0))) == op) reg_req(std::integral_constant<int, (rq >= 0 ? rq : 0)>{});
           }
         }
+        if constexpr (s + 1 == NS || op_of(s + 1 < NS ? s + 1 : s) != op) cstamp(3 + 2 * op);
       });
       __syncthreads();                                      // A(4)
       __syncthreads();                                      // P(4): q | k | v are published; the next block's prefetch may enter the CU's queue
