@@ -33,7 +33,7 @@
 #define ZN_SK_NBUF 3                                        // register tile buffers per compute wave
 #endif
 #ifndef ZN_SK_PARK
-#define ZN_SK_PARK 4                                        // tiles per compute wave parked in LDS during the attention (>= T_OUT)
+#define ZN_SK_PARK 4                                        // tiles per compute wave parked in LDS during the attention (>= T_OUT); 3: 0.8743 vs 0.8694 ms per step
 #endif
 #ifndef ZN_SK_HELP
 #define ZN_SK_HELP 0                                        // tiles per compute wave that a helper wave (6, 7) holds in ITS registers during the attention and
@@ -42,6 +42,9 @@
 #ifndef ZN_SK_HELP_AT
 #define ZN_SK_HELP_AT 0                                     // where the helper requests them: 0 = block start, 1 = after B(0) (attention output in), 2 = after P(0)
 #endif
+#ifndef ZN_SK_EARLY
+#define ZN_SK_EARLY 0                                       // requests for a LATER op's tiles that a wave may raise per op before that op's results are published (the
+#endif                                                      // rest wait for the publish: ZN_CH_DEFER_MASK).  Measured, 400 tokens: 0 0.8694 ms per step, 1 0.8907, 2 0.9398
 #define ZN_SK_MAXKEYS 1024                                  // two 512-key blocks: longer contexts go down the per-block path
 #define ZN_SK_DYN_LDS (ZN_SK_CW * ZN_SK_PARK * 8192)        // parked tiles (streaming role) / StepAttnLds (attention role)
 #ifndef ZN_SK_PACE_SHIFT
@@ -53,7 +56,6 @@ struct StepAttnLds {
   float bm[ZN_SK_MAXKEYS / 512][8][4];                      // per (block, wave, head) maxima
   float acc[32][4][32];                                     // per (wave, 16-lane row) partial P.V
   float l[8][4];
-  __attribute__((aligned(16))) bf16_t k[8][16 * (128 + 8)]; // per wave: 16 key rows, padded
   __attribute__((aligned(16))) bf16_t q[4][128];            // the kv head's 4 query heads
   __attribute__((aligned(16))) bf16_t knew[128], vnew[128]; // newest key / value row of the kv head
   __attribute__((aligned(16))) bf16_t out[4][32];           // result slice
@@ -76,7 +78,7 @@ struct StepPacer {
 // ------------------------------------------------------------------------------------------------ attention role
 ZN_DEVINL void step_attention_role(const ChainArgs& a, StepAttnLds& S, const unsigned tag0, const int c, const int wave, const int lane) {
   constexpr int HD = 128, G = 4, NW = 8, NR = 4, KST = HD / 32, TPW = 4, R = 2;
-  constexpr int KLD = HD + 8, LPK = HD / 8, KPL = 64 / LPK, NLD = 16 / KPL;
+  constexpr int NLD = KST;                                    // K registers per 16-key tile: one B fragment per MFMA step
   typedef __attribute__((ext_vector_type(4))) float f32x4_t;
   const int npairs = a.n_heads_kv * R;
   const int pair = c % npairs, slice = c / npairs, kvh = pair % a.n_heads_kv, ar = pair / a.n_heads_kv;
@@ -84,20 +86,24 @@ ZN_DEVINL void step_attention_role(const ChainArgs& a, StepAttnLds& S, const uns
   const int L = a.lengths[ar] + 1, nb = (L + 511) >> 9;     // keys including this step's; 1 or 2 blocks (host-checked)
   const int hi = L >= 2 ? L - 2 : 0;                         // rows 0 .. L-2 are in the cache from earlier launches; row L-1 comes from LDS
   const size_t kvrow = (size_t)2 * nk;
-  const int kn = lane & 15, kg = lane >> 4, kq = lane / LPK, kd = lane % LPK;
+  const int kn = lane & 15, kg = lane >> 4;
   const int vsub = lane & 3, vkey = lane >> 2, row = lane >> 4;
   const bool stamped = a.stamps && c == 0 && wave == 0 && lane == 0;
   u32x4 kkA[TPW][NLD], kkB[TPW][NLD], vA[NR], vB[NR];
   // Buffer loads with a 32-bit byte offset per request, recomputed at every issue from a value the optimiser cannot see through
   // (`opq` = 0): hoisted out of the block loop, the 40 loop-invariant addresses stayed live beside the 160 K / V registers and spilled.
   const int rowbytes = (int)kvrow * 2;
+  // K is requested straight in the MFMA B-fragment layout (lane = (key kn, k-group kg): 16 B of dims 32 st + 8 kg .. + 8 of key row
+  // tt + kn): 16 rows x 64 B per wave-load, a shape that runs at ~30 GB/s per CU — which is what kept the fused LAUNCH on whole rows
+  // + an LDS transpose, its K requests being on the critical path.  Here they are a block (~25 us) ahead of their use, so the
+  // scores need no LDS staging at all: same operands in the same MFMA slots, bit-identical scores.
   auto issue_k = [&](const bf16_t* kv, u32x4 (&kk)[TPW][NLD], int tb, int opq) {
     const __amdgpu_buffer_rsrc_t rs = zn_rsrc(kv);
-    const int base = ar * a.max_len * rowbytes + (kvh * HD + kd * 8) * 2, r0 = opq + wave * 16 + kq;
+    const int base = ar * a.max_len * rowbytes + (kvh * HD + 8 * kg) * 2, r0 = opq + wave * 16 + kn;
 #pragma unroll
     for (int tl = 0; tl < TPW; ++tl)
 #pragma unroll
-      for (int i = 0; i < NLD; ++i) kk[tl][i] = __builtin_amdgcn_raw_buffer_load_b128(rs, base + min(r0 + tb + tl * NW * 16 + KPL * i, hi) * rowbytes, 0, 0);
+      for (int st = 0; st < KST; ++st) kk[tl][st] = __builtin_amdgcn_raw_buffer_load_b128(rs, base + min(r0 + tb + tl * NW * 16, hi) * rowbytes + 64 * st, 0, 0);
   };
   auto issue_v = [&](const bf16_t* kv, u32x4 (&vv)[NR], int tb, int opq) {
     const __amdgpu_buffer_rsrc_t rs = zn_rsrc(kv);
@@ -112,7 +118,6 @@ ZN_DEVINL void step_attention_role(const ChainArgs& a, StepAttnLds& S, const uns
     issue_v(kv0, vA, 0, 0);
     if (nb > 1) issue_v(kv0, vB, 512, 0);
   }
-  bf16_t* kw = &S.k[wave][0];
   StepPacer pace{0ull, 0u};
 #pragma unroll 1
   for (int li = 0; li < a.n_layer; ++li) {
@@ -155,7 +160,9 @@ ZN_DEVINL void step_attention_role(const ChainArgs& a, StepAttnLds& S, const uns
         if (kn < G) v = *(const u32x4*)&S.q[kn][32 * st + 8 * kg];
         qa[st] = __builtin_bit_cast(zn_bf16x8, v);
       }
-      const u32x4 knew_piece = *(const u32x4*)&S.knew[kd * 8];
+      u32x4 knew_frag[KST];                                  // the newest key row is not in the cache for this launch's readers: from LDS
+#pragma unroll
+      for (int st = 0; st < KST; ++st) knew_frag[st] = *(const u32x4*)&S.knew[32 * st + 8 * kg];
       auto block_scores = [&](u32x4 (&kk)[TPW][NLD], int j) {
         float mx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
         const int tb = j * 512, tend = min(L, tb + 512);
@@ -163,15 +170,11 @@ ZN_DEVINL void step_attention_role(const ChainArgs& a, StepAttnLds& S, const uns
         for (int tl = 0; tl < TPW; ++tl) {
           const int tt = tb + (tl * NW + wave) * 16;
           if (tt < tend) {                                    // wave-uniform
-#pragma unroll
-            for (int i = 0; i < NLD; ++i) {                   // the newest row is not in the cache for this launch's readers: from LDS
-              const u32x4 piece = (tt + KPL * i + kq >= L - 1) ? knew_piece : kk[tl][i];
-              *(u32x4*)(kw + (KPL * i + kq) * KLD + kd * 8) = piece;
-            }
+            const bool newest = tt + kn >= L - 1;
             f32x4_t cc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int st = 0; st < KST; ++st) {
-              const u32x4 bfrag = *(const u32x4*)(kw + kn * KLD + 32 * st + 8 * kg);
+              const u32x4 bfrag = newest ? knew_frag[st] : kk[tl][st];
               cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa[st], __builtin_bit_cast(zn_bf16x8, bfrag), cc, 0, 0, 0);
             }
             const int t = tt + kn;
@@ -322,6 +325,45 @@ ZN_DEVINL void step_attention_role(const ChainArgs& a, StepAttnLds& S, const uns
 }
 
 // ------------------------------------------------------------------------------------------------ the launch
+// The static tile schedule of a streaming workgroup's compute wave, as compile-time arithmetic.  Slots s = 0 .. NS-1 in processing
+// order (op 0's T_OUT tiles, op 1 re-reading them, fc1, fc2, in_proj / heads); "loads" l = 0 .. NL-1 = the distinct tiles; each load
+// comes from PARK (streamed through the register buffers into LDS slots 0 .. P-1 while the attention runs), from HELP (a helper
+// wave's registers -> LDS slots 0 .. NH-1 after op 1: the last NH fc1 tiles) or from REG (the NB rotating register buffers).
+template <int T_OUT, int T_FC1, int T_FC2, int T_IN, int NB, int P, int NH, int MASK, int EARLY>
+struct StepSched {
+  static constexpr int S1 = T_OUT, S2 = 2 * T_OUT, S3 = S2 + T_FC1, S4 = S3 + T_FC2, NS = S4 + T_IN;
+  static constexpr int NL = NS - T_OUT, L_F2 = T_OUT + T_FC1, NREG = NL - P - NH;
+  static constexpr int op_of(int s) { return s < S1 ? 0 : s < S2 ? 1 : s < S3 ? 2 : s < S4 ? 3 : 4; }
+  static constexpr int first_of(int op) { return op == 0 ? 0 : op == 1 ? S1 : op == 2 ? S2 : op == 3 ? S3 : S4; }
+  static constexpr int slot_of_load(int l) { return l < S1 ? l : l + T_OUT; }
+  static constexpr int load_of_slot(int s) { return s < S1 ? s : s - T_OUT; }
+  static constexpr int src_of(int l) { return l < P ? 1 : (l >= L_F2 - NH && l < L_F2) ? 2 : 0; }                 // 0 REG, 1 PARK, 2 HELP
+  static constexpr int slot_of(int l) { return l < P ? l : l - (L_F2 - NH); }                                     // LDS slot of a PARK / HELP load
+  static constexpr int regk(int l) { int k = 0; for (int i = 0; i < l; ++i) k += src_of(i) == 0; return k; }      // REG loads before l
+  static constexpr int nth_reg(int k) { int n = 0; for (int i = 0; i < NL; ++i) { if (src_of(i) == 0) { if (n == k) return i; ++n; } } return -1; }
+  // REG request (its number) raised by the last use of slot s's register buffer, -1: none
+  static constexpr int raised_by(int s) {
+    const int l = load_of_slot(s);
+    if (op_of(s) == 1 || src_of(l) != 0) return -1;         // op 1 re-reads op 0's (parked) tiles
+    const int k = regk(l);
+    return k + NB < NREG ? k + NB : -1;
+  }
+  static constexpr int target_op(int k) { return op_of(slot_of_load(nth_reg(k))); }
+  // requests for ANOTHER op's tiles raised by the slots of s's op before s
+  static constexpr int cross_idx(int s) {
+    const int op = op_of(s);
+    int n = 0;
+    for (int q = first_of(op); q < s; ++q) { const int k = raised_by(q); if (k >= 0 && target_op(k) != op) ++n; }
+    return n;
+  }
+  // does slot s raise its request at once (true) or hold it until its op's results are published?
+  static constexpr bool raise_now(int s) {
+    const int k = raised_by(s), op = op_of(s);
+    return k >= 0 && (((MASK >> op) & 1) == 0 || target_op(k) == op || cross_idx(s) < EARLY);
+  }
+  static constexpr bool raise_late(int s) { return raised_by(s) >= 0 && !raise_now(s); }
+};
+
 // T_* = tiles per compute wave per op (upper bounds: the matrices do not divide evenly over 224 workgroups; a wave skips the tiles
 // its workgroup does not have).  d_model = 512 * NCH, d_ff = 4 * d_model (host-checked, as are the bounds).
 template <int NCH, int T_OUT, int T_FC1, int T_FC2, int T_IN>
@@ -358,23 +400,19 @@ __global__ __launch_bounds__(ZN_SK_THREADS) void step_kernel(ChainArgs a) {
   split((a.heads_rows + 1) / 2, n_hd, s_hd);
   constexpr int NBAR = 14;                                    // workgroup barriers per block (every wave of a streaming workgroup runs them all)
 
-  auto op_of = [](int s) constexpr { return s < S1 ? 0 : s < S2 ? 1 : s < S3 ? 2 : s < S4 ? 3 : 4; };
-  auto first_of = [](int op) constexpr { return op == 0 ? 0 : op == 1 ? S1 : op == 2 ? S2 : op == 3 ? S3 : S4; };
+  using SC = StepSched<T_OUT, T_FC1, T_FC2, T_IN, NB, P, ZN_SK_HELP, MASK, ZN_SK_EARLY>;
+  auto op_of = [](int s) constexpr { return SC::op_of(s); };
+  auto first_of = [](int op) constexpr { return SC::first_of(op); };
 
   // ---- the block's tiles ("loads" l = 0 .. NL-1 in consumption order: op 0's T_OUT tiles, which op 1 reads again, then fc1, fc2, in_proj / heads)
   // and where each comes from: PARK = streamed through the wave's register buffers into its LDS slots 0 .. P-1 while the attention runs;
   // HELP = held by a helper wave in ITS registers over the attention and dropped into slots 0 .. NH-1 once op 1 has read them for the
   // last time (the last NH fc1 tiles); REG = the rotating register buffers, requested NB tiles ahead.
-  constexpr int L_F2 = T_OUT + T_FC1;                         // first load of fc2
+  constexpr int L_F2 = SC::L_F2;                              // first load of fc2
   constexpr int NH = ZN_SK_HELP;
   static_assert(NH >= 0 && NH <= T_OUT && NH < T_FC1 - (P - T_OUT), "helper tiles take the slots of op 0's tiles");
-  auto src_of = [](int l) constexpr { return l < P ? 1 : (l >= L_F2 - NH && l < L_F2) ? 2 : 0; };           // 0 REG, 1 PARK, 2 HELP
-  auto slot_of = [](int l) constexpr { return l < P ? l : l - (L_F2 - NH); };
-  auto regk = [](int l) constexpr { int k = 0; for (int i = 0; i < l; ++i) k += (i < P ? 1 : (i >= L_F2 - NH && i < L_F2) ? 2 : 0) == 0; return k; };   // REG loads before l
-  auto nth_reg = [](int k) constexpr { int n = 0; for (int i = 0; i < NL; ++i) { if ((i < P ? 1 : (i >= L_F2 - NH && i < L_F2) ? 2 : 0) == 0) { if (n == k) return i; ++n; } } return -1; };
-  constexpr int NREG = NL - P - NH;
-  auto slot_of_load = [](int l) constexpr { return l < S1 ? l : l + T_OUT; };
-  auto load_of_slot = [](int s) constexpr { return s < S1 ? s : s - T_OUT; };
+  constexpr int NREG = SC::NREG;
+  auto slot_of_load = [](int l) constexpr { return SC::slot_of_load(l); };
   struct WT { u32x4 a[NCH], b[NCH]; };
   // tile of slot s for compute wave w: exists?, weight pointers of rows A and B (lane's first chunk), result index
   struct LW { const bf16_t *out, *fc1, *fc2, *in; };           // the block's weight matrices, read from the layer table ONCE per block (SGPRs)
@@ -479,7 +517,7 @@ __global__ __launch_bounds__(ZN_SK_THREADS) void step_kernel(ChainArgs a) {
       // REG load number k lives in buffer (k + P) % NB: the buffer that the prefetch phase's transit of load k + P - NB ... has just left
       auto reg_req = [&](auto KC) {
         constexpr int k = decltype(KC)::value;
-        if constexpr (k >= 0 && k < NREG) load_into(std::integral_constant<int, nth_reg(k)>{}, std::integral_constant<int, (k + P) % NB>{});
+        if constexpr (k >= 0 && k < NREG) load_into(std::integral_constant<int, SC::nth_reg(k >= 0 && k < NREG ? k : 0)>{}, std::integral_constant<int, ((k >= 0 ? k : 0) + P) % NB>{});
       };
       u32x4 xr[NCH][R];
       auto process = [&](int s, const WT& w) {
@@ -499,14 +537,6 @@ __global__ __launch_bounds__(ZN_SK_THREADS) void step_kernel(ChainArgs a) {
 #pragma unroll
           for (int r = 0; r < R; ++r) { s_res[par][ridx][0][r] = accA[r]; s_res[par][ridx][1][r] = accB[r]; }
         }
-      };
-      // REG request raised by the last use of slot s's register buffer (-1: none)
-      auto raised_by = [&](int s) constexpr {
-        const int l = s < S1 ? s : s - T_OUT;
-        if (s >= S1 && s < S2) return -1;                   // op 1 re-reads op 0's (parked) tiles
-        if ((l < P ? 1 : (l >= L_F2 - NH && l < L_F2) ? 2 : 0) != 0) return -1;
-        int k = 0; for (int i = 0; i < l; ++i) k += (i < P ? 1 : (i >= L_F2 - NH && i < L_F2) ? 2 : 0) == 0;
-        return k + NB < NREG ? k + NB : -1;
       };
       // ---- prefetch while the attention runs: loads 0 .. P-1 through the register buffers into LDS, then the first NB REG loads stay in flight
       cstamp(0);
@@ -536,12 +566,10 @@ __global__ __launch_bounds__(ZN_SK_THREADS) void step_kernel(ChainArgs a) {
           if constexpr (op > 0) {
             __syncthreads();                                // A(op-1): this workgroup's results of the previous op are in LDS
             __syncthreads();                                // P(op-1): ... and published; the requests held back for that go out now
-            if constexpr (((MASK >> (op - 1)) & 1) != 0) {
-              zn_static_for<first_of(op - 1), first_of(op)>([&](auto QC) {
-                constexpr int q = decltype(QC)::value, k = raised_by(q);
-                if constexpr (k >= 0) { if constexpr (op_of(slot_of_load(nth_reg(k >= 0 ? k : 0))) != op - 1) reg_req(std::integral_constant<int, (k >= 0 ? k : 0)>{}); }
-              });
-            }
+            zn_static_for<SC::first_of(op - 1), SC::first_of(op)>([&](auto QC) {
+              constexpr int q = decltype(QC)::value;
+              if constexpr (SC::raise_late(q)) reg_req(std::integral_constant<int, SC::raised_by(q)>{});
+            });
           }
           if constexpr (op == 3) {
             // fc2's input m [2][4 d]: this wave's K quarter straight from the granules (no LDS, no barrier)
@@ -565,24 +593,21 @@ __global__ __launch_bounds__(ZN_SK_THREADS) void step_kernel(ChainArgs a) {
           }
           cstamp(2 + 2 * op);
         }
-        constexpr int l = load_of_slot(s);
-        if constexpr (src_of(l) != 0) {                     // parked tile (own prefetch or a helper wave's): from LDS
+        constexpr int l = SC::load_of_slot(s);
+        if constexpr (SC::src_of(l) != 0) {                 // parked tile (own prefetch or a helper wave's): from LDS
           bool ok; const bf16_t *pa, *pb; int ridx;
           tile(s, ok, pa, pb, ridx);
           if (ok) {
-            constexpr int sl = slot_of(l);
+            constexpr int sl = SC::slot_of(l);
             WT w;
 #pragma unroll
             for (int c2 = 0; c2 < NCH; ++c2) { w.a[c2] = park[(sl * 2 * NCH + c2) * 64]; w.b[c2] = park[(sl * 2 * NCH + NCH + c2) * 64]; }
             process(s, w);
           }
         } else {
-          constexpr int k = regk(l);
+          constexpr int k = SC::regk(l);
           process(s, bufs[(k + P) % NB]);
-          constexpr int rq = raised_by(s);
-          if constexpr (rq >= 0) {
-            if constexpr (((MASK >> op) & 1) == 0 || op_of(slot_of_load(nth_reg(rq >= 0 ? rq : 0))) == op) reg_req(std::integral_constant<int, (rq >= 0 ? rq : 0)>{});
-          }
+          if constexpr (SC::raise_now(s)) reg_req(std::integral_constant<int, SC::raised_by(s)>{});
         }
         if constexpr (s + 1 == NS || op_of(s + 1 < NS ? s + 1 : s) != op) cstamp(3 + 2 * op);
       });
