@@ -146,8 +146,10 @@ int zn_graph_active(zn_handle h);
  * model whose shapes it serves), 0 if every op is a launch of its own.  Both paths give bit-identical results. */
 int zn_decode_path(zn_handle h);
 /* Which kernels served the decode step enqueued last: 0 = one launch per op, 1 = one attention launch + one persistent chain
- * launch per block, 2 = the whole-step persistent kernel (every block of the step in one launch; contexts up to 1024 keys).
- * All three give bit-identical results (the per-block path with its fused attention launch: zn_debug_tune(5, ...)). */
+ * launch per block, 2 / 3 = a whole-step persistent kernel (every block of the step in one launch; contexts up to 1024 keys):
+ * 2 = two workgroup roles (attention / streaming, the default), 3 = three roles (attention / projection / bulk: zn_debug_tune(15, 4),
+ * an experiment kept for the record - bit-identical, slower).
+ * All give bit-identical results (the per-block path with its fused attention launch: zn_debug_tune(5, ...)). */
 int zn_decode_path_detail(zn_handle h);
 /* Ends the generation begun by zn_gen_begin: releases the device's persistent-kernel tenancy (below) so that another handle's next
  * generation may take it.  The handle's state stays readable (zn_decode_path, zn_get_step_outputs); further steps need a new

@@ -15,7 +15,7 @@ eng.call("zn_debug_eos_bias", float("-inf"))
 eng.call("zn_debug_tune", 5, 1024)
 cond = synth.conditioning(1234, "cond", 2, int(os.environ.get("ZN_LC", "24")), 2048).to("cuda:0")
 res = {}
-for name, t15 in (("chain", 2), ("stack", 1), ("stack2", 1)):
+for name, t15 in (("chain", 2), ("stack", 1), ("stack2", 1), ("threerole", 4)):
     eng.call("zn_debug_tune", 15, t15)
     tr = {"logits": []}
     out = model.generate(cond, max_new_tokens=n, sampling_params={"temperature": 0.0}, _trace=tr)
@@ -30,3 +30,4 @@ for k in range(min(len(a), len(b))):
         break
 print("codes equal:", torch.equal(res["chain"][0], res["stack"][0]))
 print("stack runs equal:", all(torch.equal(x, y) for x, y in zip(res["stack"][1], res["stack2"][1])))
+print("three-role kernel equal to the chain path:", torch.equal(res["chain"][0], res["threerole"][0]) and all(torch.equal(x, y) for x, y in zip(res["chain"][1], res["threerole"][1])))

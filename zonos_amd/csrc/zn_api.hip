@@ -4,6 +4,7 @@
 #include "zn_decode_kernels.h"
 #include "zn_chain_kernel.h"
 #include "zn_step_kernel.h"
+#include "zn_step3_kernel.h"
 #include "zn_prefill_kernels.h"
 #include "zn_cond_kernels.h"
 #include "zn_mamba_kernels.h"
@@ -41,7 +42,7 @@ struct zn_handle_s {
   unsigned long long *ch_gy1 = nullptr, *ch_gx1 = nullptr, *ch_gx2 = nullptr, *ch_gm = nullptr;
   unsigned long long *ch_gqkv = nullptr, *ch_ga = nullptr;   // whole-step kernel: q | k | v of the next block, attention output
   StackLayer* stack_layers = nullptr;        // device table [n_layer], rebuilt by zn_gen_begin (it holds the KV cache pointers)
-  bool use_stack = false, stack_ok = false, stack_checked = false;                    // the steps being enqueued run the whole-step kernel
+  bool use_stack = false, stack_ok = false, stack_checked = false, stack3_ok = false;   // stack3: the three-role whole-step kernel (zn_step3_kernel.h)                    // the steps being enqueued run the whole-step kernel
   unsigned* ch_epoch = nullptr;
   unsigned* ch_diag = nullptr;               // [8] words: the first hand-off wait that timed out describes itself (sweep_granules)
   unsigned diag_host[8] = {};
@@ -660,9 +661,30 @@ static bool stack_shapes_ok(zn_handle h) {
   if (hipFuncGetAttributes(&fa, (const void*)step_kernel<ZN_SK_T>) != hipSuccess) { (void)hipGetLastError(); return false; }
   return per_cu >= 1 && n_cus >= ZN_CH_GRID && fa.localSizeBytes == 0;
 }
+// The three-role whole-step kernel (zn_step3_kernel.h: attention / projection / bulk workgroups): opt-in, zn_debug_tune(15, 4); bit-identical, measured slower.
+#define ZN_S3_T 4, 13, 7, 8
+static bool stack3_shapes_ok(zn_handle h) {
+  const zn_config& c = h->cfg;
+  if (!h->stack_ok) return false;                            // same model family, same attention role
+  const int natt = 2 * c.n_heads_kv * (h->hd / 32), nbw = ZN_CH_GRID - natt - ZN_S3_NPROJ;
+  const int nqkv = (c.n_heads + 2 * c.n_heads_kv) * h->hd;
+  if (nbw < 64 || c.n_layer < 2) return false;
+  if ((c.d_model / 2) != ZN_S3_NPROJ * 8 * ZN_S3_TO || (nqkv / 2) != ZN_S3_NPROJ * 8 * ZN_S3_TI) return false;   // the projection waves' register-resident slices
+  auto most = [&](int units) { return (units + nbw - 1) / nbw; };
+  const int p_fc1 = 2 * most(c.d_ff / 2), p_fc2 = most(c.d_model / 2), p_hd = most((c.n_codebooks * c.vocab_head + 1) / 2);
+  if (p_fc1 > ZN_SK_CW * 13 || p_fc2 > 7 || p_hd > ZN_SK_CW * 8) return false;                                    // the static schedule <4, 13, 7, 8>
+  if (p_fc1 > 64 || p_fc2 * 2 > 64 || p_hd * 2 > 64) return false;
+  int per_cu = 0;
+  if (hipFuncSetAttribute((const void*)step3_kernel<ZN_S3_T>, hipFuncAttributeMaxDynamicSharedMemorySize, ZN_S3_DYN_LDS) != hipSuccess) { (void)hipGetLastError(); return false; }
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, step3_kernel<ZN_S3_T>, ZN_SK_THREADS, ZN_S3_DYN_LDS) != hipSuccess) { (void)hipGetLastError(); return false; }
+  hipFuncAttributes fa{};
+  if (hipFuncGetAttributes(&fa, (const void*)step3_kernel<ZN_S3_T>) != hipSuccess) { (void)hipGetLastError(); return false; }
+  return per_cu >= 1 && fa.localSizeBytes == 0;
+}
 static bool stack_active(zn_handle h, int rows, int keys_upper_bound) {
   return chain_active(h, rows) && h->tune[15] != 2 && keys_upper_bound <= ZN_SK_MAXKEYS && h->stack_ok;
 }
+static bool stack3_selected(zn_handle h) { return h->stack3_ok && h->tune[15] == 4; }   // zn_debug_tune(15, 4): the three-role kernel (measured slower: zn_step3_kernel.h)
 static int launch_stack(zn_handle h, hipStream_t s) {
   const zn_config& c = h->cfg;
   ChainArgs a{};
@@ -675,7 +697,8 @@ static int launch_stack(zn_handle h, hipStream_t s) {
   a.rope_positions = c.rope_positions;
   a.layers = h->stack_layers; a.n_layer = c.n_layer; a.q0 = h->q; a.scale = (float)(1.0 / std::sqrt((double)h->hd));
   a.heads_rows = c.n_codebooks * c.vocab_head; a.heads_out = h->logits_raw; a.trace = h->dbg_trace;
-  hipLaunchKernelGGL((step_kernel<ZN_SK_T>), dim3(ZN_CH_GRID), dim3(ZN_SK_THREADS), ZN_SK_DYN_LDS, s, a);
+  if (stack3_selected(h)) hipLaunchKernelGGL((step3_kernel<ZN_S3_T>), dim3(ZN_CH_GRID), dim3(ZN_SK_THREADS), ZN_S3_DYN_LDS, s, a);
+  else hipLaunchKernelGGL((step_kernel<ZN_SK_T>), dim3(ZN_CH_GRID), dim3(ZN_SK_THREADS), ZN_SK_DYN_LDS, s, a);
   return ZN_OK;
 }
 // device table of the whole-step kernel (KV cache pointers of this generation)
@@ -953,7 +976,7 @@ extern "C" int zn_gen_begin(zn_handle h, int32_t batch, const void* const* kv_la
   // batch 1 on a model the persistent kernels serve: claim the device for them, or run this generation on the launches path
   h->persist_ok = !(h->cfg.arch == 0 && h->ch_variant != 0 && batch == 1) || zn_tenant_try_claim(h->device, h) != 0;
   if (h->cfg.arch == 0 && h->ch_variant == 1) {
-    if (!h->stack_checked) { h->stack_ok = stack_shapes_ok(h); h->stack_checked = true; }
+    if (!h->stack_checked) { h->stack_ok = stack_shapes_ok(h); h->stack3_ok = stack3_shapes_ok(h); h->stack_checked = true; }
     if (h->stack_ok) { int rc = build_stack_table(h); if (rc) return rc; }
   }
   GenState st{};
@@ -1325,7 +1348,7 @@ extern "C" int zn_gen_end(zn_handle h) {
 extern "C" int zn_decode_path(zn_handle h) { return (h && h->gen_active && h->cfg.arch == 0 && chain_active(h, h->rows)) ? 1 : 0; }
 extern "C" int zn_decode_path_detail(zn_handle h) {
   if (!h || !h->gen_active || h->cfg.arch != 0 || !chain_active(h, h->rows)) return 0;
-  return h->use_stack ? 2 : 1;
+  return h->use_stack ? (stack3_selected(h) ? 3 : 2) : 1;
 }
 extern "C" int zn_graph_active(zn_handle h) {
   if (!h) return 0;
@@ -1447,7 +1470,7 @@ extern "C" int zn_bench_kernel(zn_handle h, int32_t which, int32_t rows, int32_t
   const int ctx = ctx_arg > 0 ? ctx_arg : 450;
   if (which == 6) {
     if (!chain_active(h, rows)) ZN_FAIL(h, ZN_ERR_UNSUPPORTED, "zn_bench_kernel: the whole-step kernel serves batch 1 (2 rows) of the transformer only");
-    if (!h->stack_checked) { h->stack_ok = stack_shapes_ok(h); h->stack_checked = true; }
+    if (!h->stack_checked) { h->stack_ok = stack_shapes_ok(h); h->stack3_ok = stack3_shapes_ok(h); h->stack_checked = true; }
     if (!h->stack_ok || ctx + 1 > ZN_SK_MAXKEYS) ZN_FAIL(h, ZN_ERR_UNSUPPORTED, "zn_bench_kernel: the whole-step kernel does not serve this model / context");
     const int cap = ctx + 8;
     std::vector<int> lens(rows, ctx);

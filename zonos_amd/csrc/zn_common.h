@@ -30,6 +30,11 @@ __device__ __forceinline__ float dot8(const u32x4& w, const u32x4& x, float c) {
 // streamed-once weights: non-temporal 16-B load (MI355X_MICROARCH.md "nt-weights")
 __device__ __forceinline__ u32x4 ld_nt16(const void* p) { return __builtin_nontemporal_load((const u32x4*)p); }
 __device__ __forceinline__ u32x4 ld16(const void* p) { return *(const u32x4*)p; }
+// The same through a GLOBAL-address-space pointer, for weights whose address was read from a device table: loaded through a
+// generic pointer they become flat_load instructions, which count on lgkmcnt as well as vmcnt - every wait for an LDS read then
+// also waits for every weight tile still in flight (found in the whole-step kernels' ISA: 201 flat loads).
+__device__ __forceinline__ u32x4 ld_nt16g(const void* p) { return __builtin_nontemporal_load((const __attribute__((address_space(1))) u32x4*)p); }
+__device__ __forceinline__ u32x4 ld16g(const void* p) { return *(const __attribute__((address_space(1))) u32x4*)p; }
 
 // ---- cross-lane reductions on the VALU (DPP within a 16-lane row, v_permlane16/32_swap across rows): no LDS
 // round trips (ds_bpermute chains made the first version of these kernels latency-bound).

@@ -369,7 +369,7 @@ struct StepSched {
 template <int NCH, int T_OUT, int T_FC1, int T_FC2, int T_IN>
 __global__ __launch_bounds__(ZN_SK_THREADS) void step_kernel(ChainArgs a) {
   constexpr int R = 2, D = NCH * 512, CW = ZN_SK_CW;
-  constexpr int S1 = T_OUT, S2 = 2 * T_OUT, S3 = S2 + T_FC1, S4 = S3 + T_FC2, NS = S4 + T_IN;     // slot ranges per op
+  constexpr int NS = 2 * T_OUT + T_FC1 + T_FC2 + T_IN;         // slots of a block (StepSched)
   constexpr int NOPS = 5;
   constexpr int MASK = ZN_CH_DEFER_MASK;
   constexpr int NB = ZN_SK_NBUF, P = ZN_SK_PARK;
@@ -454,7 +454,7 @@ __global__ __launch_bounds__(ZN_SK_THREADS) void step_kernel(ChainArgs a) {
             tile_of(Lr, a.nqkv, 0, 0, slot_of_load(L_F2 - NH + hh), 2 * hw + cwi, ok, pa, pb, ridx);     // an fc1 tile: the op-4 arguments are unused
             if (ok) {
 #pragma unroll
-              for (int c2 = 0; c2 < NCH; ++c2) { hb[i].a[c2] = ld_nt16(pa + c2 * 512); hb[i].b[c2] = ld_nt16(pb + c2 * 512); }
+              for (int c2 = 0; c2 < NCH; ++c2) { hb[i].a[c2] = ld_nt16g(pa + c2 * 512); hb[i].b[c2] = ld_nt16g(pb + c2 * 512); }
             }
           });
         }
@@ -510,7 +510,7 @@ __global__ __launch_bounds__(ZN_SK_THREADS) void step_kernel(ChainArgs a) {
           if (ok) {                                         // wave-uniform
             WT& w = bufs[b];
 #pragma unroll
-            for (int c2 = 0; c2 < NCH; ++c2) { w.a[c2] = ld_nt16(pa + c2 * 512); w.b[c2] = ld_nt16(pb + c2 * 512); }
+            for (int c2 = 0; c2 < NCH; ++c2) { w.a[c2] = ld_nt16g(pa + c2 * 512); w.b[c2] = ld_nt16g(pb + c2 * 512); }
           }
         }
       };
@@ -658,9 +658,9 @@ __global__ __launch_bounds__(ZN_SK_THREADS) void step_kernel(ChainArgs a) {
     auto stamp = [&]() { if (stamped) a.stamps[nst] = __builtin_amdgcn_s_memrealtime(); ++nst; };
     stamp();                                               // 0: block starts
 #pragma unroll
-    for (int c2 = 0; c2 < NCH; ++c2) { l2w[c2] = ld16(Lr.ln2_w + (c2 * 64 + lane) * 8); l2b[c2] = ld16(Lr.ln2_b + (c2 * 64 + lane) * 8); }
+    for (int c2 = 0; c2 < NCH; ++c2) { l2w[c2] = ld16g(Lr.ln2_w + (c2 * 64 + lane) * 8); l2b[c2] = ld16g(Lr.ln2_b + (c2 * 64 + lane) * 8); }
 #pragma unroll
-    for (int c2 = 0; c2 < NCH; ++c2) { lnw[c2] = ld16(Lr.lnn_w + (c2 * 64 + lane) * 8); lnbb[c2] = ld16(Lr.lnn_b + (c2 * 64 + lane) * 8); }
+    for (int c2 = 0; c2 < NCH; ++c2) { lnw[c2] = ld16g(Lr.lnn_w + (c2 * 64 + lane) * 8); lnbb[c2] = ld16g(Lr.lnn_b + (c2 * 64 + lane) * 8); }
     // ---- the attention output of all heads -> s_act
     pace.sleep();
     stamp();                                               // 1: polling starts
