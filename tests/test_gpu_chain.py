@@ -170,3 +170,51 @@ def test_second_generation_on_the_device_takes_the_launches_path():
     assert torch.equal(out1, alone)
     again = m2.generate(cond, max_new_tokens=12, sampling_params=GREEDY).cpu()
     assert e2.lib.zn_decode_path(e2.h) == 1 and torch.equal(again, alone)
+
+
+def test_handoff_tags_restart_before_they_can_wrap():
+    """The hand-off tags are 32-bit and advance by n_layer per decode step (about 41 hours of continuous batch-1 decoding).  Between two
+    generations, long before a wrap, zn_gen_begin restarts the epoch at 1 over zeroed granule buffers; zn_debug_tune(14, 7) makes the next
+    zn_gen_begin take that branch: the generation after it must be unaffected (same codes, same logits, no stale tag accepted)."""
+    cfg, seed = synth.FULL_CFG, 1234
+    model, _ = build_model(cfg, seed, "cuda:0")
+    eng = model.engine(1)
+    cond = synth.conditioning(seed, "cond", 2, 24, cfg["d_model"])
+    a, la, _ = _run(model, cond, 40)
+    assert eng.lib.zn_decode_path_detail(eng.h) == 2
+    eng.call("zn_debug_tune", 14, 7)
+    b, lb, _ = _run(model, cond, 40)
+    assert torch.equal(a, b) and torch.equal(la.view(torch.int32), lb.view(torch.int32))
+    c, lc, _ = _run(model, cond, 40)                       # and the epoch counts on from 1 afterwards
+    assert torch.equal(a, c) and torch.equal(la.view(torch.int32), lc.view(torch.int32))
+
+
+def test_a_reported_handoff_timeout_is_survived(capfd):
+    """A bounded hand-off wait that gives up voids the generation, makes the handle fall back to the launches path and - when the caller
+    has not seen any frame of it yet - `Zonos.generate` repeats the generation there.  zn_debug_tune(14, 9) sets the sticky timeout word
+    for the next generation (every wait gives up at once): the call must still return the right codes, say what happened, and leave the
+    handle on the launches path until zn_debug_tune(8, 1)."""
+    cfg, seed = synth.FULL_CFG, 1234
+    model, _ = build_model(cfg, seed, "cuda:0")
+    eng = model.engine(1)
+    cond = synth.conditioning(seed, "cond", 2, 24, cfg["d_model"]).to("cuda:0")
+    eng.call("zn_debug_eos_bias", float("-inf"))
+    try:
+        ref = model.generate(cond, max_new_tokens=40, sampling_params=GREEDY).cpu()
+        assert eng.lib.zn_decode_path_detail(eng.h) == 2
+        eng.call("zn_debug_tune", 14, 9)
+        out = model.generate(cond, max_new_tokens=40, sampling_params=GREEDY).cpu()
+        err = capfd.readouterr().err
+        assert "hand-off wait" in err and "repeating the generation" in err
+        assert torch.equal(out, ref)
+        assert eng.lib.zn_decode_path(eng.h) == 0, "after a reported timeout the handle runs the launches path"
+        eng.call("zn_debug_tune", 14, 9)                        # with a callback the caller has seen frames: the error is raised, not hidden
+        eng.call("zn_debug_tune", 8, 1)
+        with pytest.raises(Exception, match="hand-off wait"):
+            model.generate(cond, max_new_tokens=40, sampling_params=GREEDY, callback=lambda f, s_, m: True)
+        eng.call("zn_debug_tune", 8, 1)
+        again = model.generate(cond, max_new_tokens=40, sampling_params=GREEDY).cpu()
+        assert torch.equal(again, ref) and eng.lib.zn_decode_path_detail(eng.h) == 2
+    finally:
+        eng.call("zn_debug_tune", 8, 1)
+        eng.call("zn_debug_eos_bias", 0.0)

@@ -44,6 +44,7 @@ struct zn_handle_s {
   StackLayer* stack_layers = nullptr;        // device table [n_layer], rebuilt by zn_gen_begin (it holds the KV cache pointers)
   bool use_stack = false, stack_ok = false, stack_checked = false, stack3_ok = false;   // stack3: the three-role whole-step kernel (zn_step3_kernel.h)                    // the steps being enqueued run the whole-step kernel
   unsigned* ch_epoch = nullptr;
+  unsigned long long epoch_bound = 1;        // host-side upper bound of the device epoch (tags advance by one per block of every decode step enqueued)
   unsigned* ch_diag = nullptr;               // [8] words: the first hand-off wait that timed out describes itself (sweep_granules)
   unsigned diag_host[8] = {};
   bf16_t* ch_x2 = nullptr;
@@ -368,7 +369,7 @@ static bool gemm16k_fits(zn_handle h, int epi, int N, int K) {
   if (epi == EPI_SILU || h->tune[7] <= 1 || h->tune[11] == 2) return false;
   const int per = ZN_G16K_NKW * ZN_G16K_KCH, nch = K / per;
   if (K % per || (nch != 2 && nch != 4)) return false;
-  return (N + 15) / 16 < 1024;                                        // many rows: the 64-row workgroups fill the chip without a split
+  return (N + 15) / 16 < (h->tune[13] > 0 ? h->tune[13] : 1024);     // many rows: the 64-row workgroups fill the chip without a split (tune[13]: the tile count from which they take over)
 }
 template <int PRO, int EPI>
 static void run_gemm16k(const GemvArgs& g, hipStream_t s) {
@@ -753,6 +754,7 @@ static int decode_blocks(zn_handle h, const int* ext, int ext_scalar, hipStream_
     return ZN_OK;
   }
   if ((rc = layer_in_proj(h, 0, x0 ? const_cast<bf16_t*>(x0) : h->x, (bf16_t*)h->kv_layers[0], h->max_len, h->lengths, h->rows, s))) return rc;
+  h->epoch_bound += c.n_layer;                             // one tag per chain launch (counted again by zn_decode_steps: the bound stays an upper bound)
   for (int li = 0; li < c.n_layer; ++li) {
     trace_q(li);
     if ((rc = run_attention(h, h->q, (bf16_t*)h->kv_layers[li], h->max_len, h->lengths, ext, ext_scalar, h->o1, h->rows, s,
@@ -973,6 +975,19 @@ extern "C" int zn_gen_begin(zn_handle h, int32_t batch, const void* const* kv_la
   h->cfg_scale = cfg_scale; h->sp = *sp;
   h->kv_layers.assign(kv_layers_dev, kv_layers_dev + h->cfg.n_layer);
   h->lengths = lengths_dev; h->codes = delayed_codes_dev;
+  // The hand-off tags are 32-bit and advance by n_layer per decode step (~41 hours of continuous batch-1 decoding): long before they
+  // can wrap, between two generations, the epoch restarts at 1 over zeroed granule buffers (tag 0 is never a launch's epoch).
+  if (h->tune[14] == 7) { h->epoch_bound = 0x70000001ull; h->tune[14] = 0; }   // test hook (zn_debug_tune(14, 7)): behave as if the tags were about to wrap
+  if (h->epoch_bound > 0x70000000ull) {
+    const size_t R = h->max_rows, nqkv = (size_t)(h->cfg.n_heads + 2 * h->cfg.n_heads_kv) * h->hd;
+    for (unsigned long long* g : {h->ch_gy1, h->ch_gx1, h->ch_gx2, h->ch_ga}) HIPCHK(h, hipMemsetAsync(g, 0, R * (h->cfg.d_model / 2) * 8, s));
+    HIPCHK(h, hipMemsetAsync(h->ch_gqkv, 0, R * (nqkv / 2 + 1) * 8, s));
+    HIPCHK(h, hipMemsetAsync(h->ch_gm, 0, R * (h->cfg.d_ff / 2 + 1) * 8, s));
+    const unsigned one = 1;
+    HIPCHK(h, hipMemcpyAsync(h->ch_epoch, &one, sizeof one, hipMemcpyHostToDevice, s));
+    HIPCHK(h, hipStreamSynchronize(s));
+    h->epoch_bound = 1;
+  }
   // batch 1 on a model the persistent kernels serve: claim the device for them, or run this generation on the launches path
   h->persist_ok = !(h->cfg.arch == 0 && h->ch_variant != 0 && batch == 1) || zn_tenant_try_claim(h->device, h) != 0;
   if (h->cfg.arch == 0 && h->ch_variant == 1) {
@@ -981,6 +996,7 @@ extern "C" int zn_gen_begin(zn_handle h, int32_t batch, const void* const* kv_la
   }
   GenState st{};
   st.offset = offset0; st.step = 0; st.all_done = 0; st.force_eos_step = h->force_eos_step; st.eos_bias = h->eos_bias;
+  if (h->tune[14] == 9) { st.pad[0] = 1; h->tune[14] = 0; }   // test hook (zn_debug_tune(14, 9)): this generation's hand-off waits find the timeout word set
   HIPCHK(h, hipMemcpyAsync(h->st, &st, sizeof st, hipMemcpyHostToDevice, s));
   std::vector<int> rem(batch, t_total - offset0), stop(batch, 0);   // model.py:439-441
   HIPCHK(h, hipMemcpyAsync(h->remaining, rem.data(), batch * sizeof(int), hipMemcpyHostToDevice, s));
@@ -1332,7 +1348,7 @@ extern "C" int zn_decode_steps(zn_handle h, int32_t n, zn_stream stream) {
     }
     if (h->graph_exec[k]) HIPCHK(h, hipGraphLaunch(h->graph_exec[k], s));
     else for (int j = 0; j < run; ++j) { int rc = enqueue_step(h, s); if (rc) return rc; }
-    i += run; h->len_hi += run;
+    i += run; h->len_hi += run; h->epoch_bound += (unsigned long long)run * (h->cfg.n_layer + 1);
   }
   HIPCHK(h, hipGetLastError());
   return ZN_OK;
@@ -1539,6 +1555,7 @@ extern "C" int zn_bench_kernel(zn_handle h, int32_t which, int32_t rows, int32_t
     HIPCHK(h, hipMemcpy(&tmo, &h->st->pad[0], sizeof(int), hipMemcpyDeviceToHost));
     if (tmo != 0) return handoff_timeout(h, tmo);
   }
+  if (which == 5 || which == 6) h->epoch_bound += (unsigned long long)(iters + 8) * (c.n_layer + 1);
   int launches = iters;
   if (which == 5) { launches = 0; for (int i = 0; i < iters; ++i) launches += (i % c.n_layer != c.n_layer - 1); }
   *ms_per_launch = ms / launches;

@@ -33,7 +33,8 @@
 #define ZN_CH_NBUF 3                                       // weight tiles requested ahead per compute wave (register buffers)
 #endif
 #define ZN_CH_THREADS ((ZN_CH_CWAVES + 2) * 64)              // + one communication wave per activation row
-#define ZN_CH_TIMEOUT_TICKS 2000000ull                     // 20 ms of s_memrealtime (100 MHz)
+#define ZN_CH_TIMEOUT_TICKS 2000000ull                     // 20 ms of s_memrealtime (100 MHz) ...
+#define ZN_CH_TIMEOUT_PASSES 4096u                         // ... AND this many sweep passes (~1 us each when the wave runs): see sweep_granules
 
 struct ChainArgs {
   const bf16_t *W_out, *W_fc1, *W_fc2, *W_in;              // W_in = next block's in_proj (NULL: the chain ends after fc2)
@@ -86,6 +87,12 @@ ZN_DEVINL void st_granule(unsigned long long* g, unsigned tag, unsigned value) {
 }
 // One wave sweeps the 4 * N granules it needs (two per 16-byte sc1 load: .x/.z values, .y/.w tags; byte offsets off[]) until every
 // tag equals `tag`, re-reading all of them every pass; bounded.  data[i] = the eight bf16 of off[i].
+// The bound is wall time AND work: a wait gives up only after 20 ms in which it has also made ZN_CH_TIMEOUT_PASSES passes.  The first
+// timeout this diagnostic ever recorded (round 3, profiles/r03_handoff_timeout_record.txt) showed a wave that had made 14 passes in 20 ms
+// - a pass takes about a microsecond - i.e. the wave itself had not been running for almost all of that time (the queue preempted or
+// the device stalled; s_memrealtime keeps counting), and on resumption every wait on the chip found its 20 ms "expired" although no
+// hand-off was lost.  A wall-clock bound alone turns such a pause into a failed generation; counting passes as well does not, and a
+// hand-off that really never arrives is still reported after 20 ms of genuine spinning.
 // A wait that gives up describes itself: the first wave to time out (tmo 0 -> 1) leaves, in diag[0..7], the caller's code
 // (stage << 8 | block), workgroup, wave, the tag it waited for, the byte offset and the tag of its first stale granule, the lane that
 // held it and the passes made; zn_all_stopped prints them.  Later waits see tmo != 0 and return at once (the results are void anyway).
@@ -105,7 +112,7 @@ ZN_DEVINL bool sweep_granules(__amdgpu_buffer_rsrc_t rs, const int (&off)[N], un
     }
     const unsigned long long bad = __builtin_amdgcn_ballot_w64(!ok);
     if (bad == 0ull) { if (passes_out) *passes_out = np; return true; }
-    if (__builtin_amdgcn_s_memrealtime() - t0 > ZN_CH_TIMEOUT_TICKS || __hip_atomic_load(tmo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+    if ((np >= ZN_CH_TIMEOUT_PASSES && __builtin_amdgcn_s_memrealtime() - t0 > ZN_CH_TIMEOUT_TICKS) || __hip_atomic_load(tmo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
       if (lane == (int)__builtin_ctzll(bad) && atomicAdd(tmo, 1) == 0 && who.diag) {
         unsigned badoff = 0xffffffffu, badtag = 0;            // the first stale granule of this lane, read once more
 #pragma unroll

@@ -8,6 +8,7 @@ hipGraph replay per step inside libzonos_hip.so; the host only mirrors the refer
 from __future__ import annotations
 
 import ctypes as C
+import sys
 import json
 from typing import Callable
 
@@ -178,9 +179,21 @@ class Zonos(nn.Module):
         B = batch_size
         eng = self.engine(B)
         # the engine's handle holds this generation's state: concurrent generate() calls on one model queue here
+        if seed is None:
+            seed = int(torch.randint(0, 2 ** 62, (1,)).item())
         with eng.lock, torch.cuda.device(dev):
-            return self._generate_locked(eng, prefix_conditioning, audio_prefix_codes, max_new_tokens, cfg_scale, B, sampling_params, callback,
-                                         seed, _trace)
+            try:
+                return self._generate_locked(eng, prefix_conditioning, audio_prefix_codes, max_new_tokens, cfg_scale, B, sampling_params, callback,
+                                             seed, _trace)
+            except _lib.ZonosHipError as e:
+                # A bounded in-kernel hand-off wait gave up (include/zonos_hip.h, INTEGRATION.md "Single tenant per device"): the results
+                # are void and the library has switched this handle to the launches path, which has no in-launch hand-offs.  Nothing has
+                # been returned yet, so the generation is simply run again - unless the caller has already seen frames of it.
+                if "hand-off wait" not in str(e) or callback is not None or _trace is not None:
+                    raise
+                print(f"[zonos_amd] {e}\n[zonos_amd] repeating the generation on the launches path", file=sys.stderr, flush=True)
+                return self._generate_locked(eng, prefix_conditioning, audio_prefix_codes, max_new_tokens, cfg_scale, B, sampling_params, callback,
+                                             seed, _trace)
 
     def _generate_locked(self, eng, prefix_conditioning, audio_prefix_codes, max_new_tokens, cfg_scale, batch_size, sampling_params, callback, seed,
                          _trace):
@@ -200,8 +213,6 @@ class Zonos(nn.Module):
         t_total = delayed.shape[2]
         offset = P + 1
         st = eng.stream()
-        if seed is None:
-            seed = int(torch.randint(0, 2 ** 62, (1,)).item())
         sp = _sampling_struct(sampling_params, seed)
         kv_ptrs = (C.c_void_p * self.config.backbone.n_layer)(*[ip.key_value_memory_dict[i][0].data_ptr() for i in range(self.config.backbone.n_layer)])
         eng.call("zn_gen_begin", B, kv_ptrs, ip.max_seqlen, ip.lengths_per_sample.data_ptr(), delayed.data_ptr(), t_total, offset,
