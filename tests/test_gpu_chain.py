@@ -218,3 +218,36 @@ def test_a_reported_handoff_timeout_is_survived(capfd):
     finally:
         eng.call("zn_debug_tune", 8, 1)
         eng.call("zn_debug_eos_bias", 0.0)
+
+
+def test_two_concurrent_requests_on_one_model():
+    """The reference serves two requests per model at a time (utilities/app_constants.py:18).  Two threads call generate() on ONE model
+    at once: the second finds the model's engine busy and runs on a second handle over the same weights (launches path: the first holds
+    the device's persistent-kernel tenancy); both get the codes a solo run gives."""
+    import threading
+    cfg = synth.CHAIN_CFG
+    model, _ = build_model(cfg, 55, "cuda:0")
+    conds = [synth.conditioning(55 + i, "cond", 2, 9, cfg["d_model"]).to("cuda:0") for i in range(2)]
+    solo = [model.generate(c, max_new_tokens=120, sampling_params=GREEDY).cpu() for c in conds]
+    assert model._spare is None
+    outs, errs = [None, None], []
+    gate = threading.Barrier(2)
+
+    def work(i):
+        try:
+            torch.cuda.set_device(0)
+            gate.wait()
+            outs[i] = model.generate(conds[i], max_new_tokens=120, sampling_params=GREEDY).cpu()
+        except Exception as e:                                  # surfaced below
+            errs.append(e)
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errs, errs
+    assert model._spare is not None, "the second request did not get a handle of its own"
+    for i in range(2):
+        n = min(outs[i].shape[-1], solo[i].shape[-1])
+        assert n >= 100 and torch.equal(outs[i][..., :8], solo[i][..., :8])    # d 512: chain and launches paths cut fc2's K differently
+        assert (outs[i][..., :n] == solo[i][..., :n]).float().mean() > 0.9

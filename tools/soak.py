@@ -1,0 +1,38 @@
+"""Soak of the default batch-1 decode path (whole-step kernel): N full-length generations (10 s each: prefill + 868 decode steps = 26 x 6
+in-kernel hand-offs per step), every one compared with the first (the kernels are deterministic) - codes must be identical, no hand-off
+wait may give up, the handle must still be on the whole-step kernel at the end.
+    python tools/soak.py [generations]"""
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from zonos_amd import synth  # noqa: E402
+from zonos_amd.testing import build_model  # noqa: E402
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 50
+model, _ = build_model(synth.FULL_CFG, 1234, "cuda:0")
+eng = model.engine(1)
+eng.call("zn_debug_eos_bias", float("-inf"))
+cond = synth.conditioning(1234, "cond", 2, 24, 2048).to("cuda:0")
+ref = None
+t0 = time.perf_counter()
+worst = 0.0
+for i in range(n):
+    torch.cuda.synchronize()
+    ta = time.perf_counter()
+    out = model.generate(cond, max_new_tokens=861, sampling_params={"temperature": 0.0})
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - ta
+    worst = max(worst, dt)
+    path = eng.lib.zn_decode_path_detail(eng.h)
+    if ref is None:
+        ref = out.clone()
+    same = torch.equal(out, ref)
+    if not same or path != 2 or i % 10 == 0:
+        print(f"generation {i}: {dt * 1e3:.1f} ms, path {path}, identical to the first: {same}", flush=True)
+    assert same and path == 2, "soak failed"
+hand_offs = n * 869 * 26 * 6
+print(f"{n} generations ({hand_offs / 1e6:.1f} M in-kernel hand-offs) in {time.perf_counter() - t0:.1f} s, slowest {worst * 1e3:.1f} ms: all identical, no wait gave up")

@@ -9,6 +9,7 @@ from __future__ import annotations
 
 import ctypes as C
 import sys
+import threading
 import json
 from typing import Callable
 
@@ -55,6 +56,8 @@ class Zonos(nn.Module):
         self.embeddings = nn.ModuleList([nn.Embedding(vocab_size, dim) for _ in range(self.autoencoder.num_codebooks)])
         self.fused_heads = nn.Linear(dim, self.autoencoder.num_codebooks * 1025, bias=False)
         self._engine: HipEngine | None = None
+        self._spare: HipEngine | None = None          # second handle over the same weights (a concurrent generate() call)
+        self._spare_guard = threading.Lock()
 
     # ------------------------------------------------------------------ loading
     @property
@@ -111,25 +114,58 @@ class Zonos(nn.Module):
 
     def _apply(self, fn, *a, **k):
         self._engine = None       # device/dtype moves invalidate bound pointers
+        self._spare = None
         if getattr(self.backbone, "_engine", None) is not None:
             self.backbone._engine = None
         return super()._apply(fn, *a, **k)
 
+    def _new_engine(self, batch_size: int) -> HipEngine:
+        return HipEngine(self.backbone, [m.weight for m in self.embeddings], self.fused_heads.weight,
+                         max_rows=2 * batch_size, double_out_proj=getattr(self.backbone, "ref_double_out_proj", True),
+                         n_codebooks=self.autoencoder.num_codebooks, vocab_head=1025, vocab_embed=self.embeddings[0].weight.shape[0],
+                         eos_id=self.eos_token_id, mask_id=self.masked_token_id)
+
     def engine(self, batch_size: int = 1) -> HipEngine:
         e = self._engine
         if e is None or e.max_rows < 2 * batch_size or e.device != self.device:
-            self._engine = e = HipEngine(self.backbone, [m.weight for m in self.embeddings], self.fused_heads.weight,
-                                         max_rows=2 * batch_size, double_out_proj=getattr(self.backbone, "ref_double_out_proj", True),
-                                         n_codebooks=self.autoencoder.num_codebooks, vocab_head=1025, vocab_embed=self.embeddings[0].weight.shape[0],
-                                         eos_id=self.eos_token_id, mask_id=self.masked_token_id)
+            self._engine = e = self._new_engine(batch_size)
+            self._spare = None
         return e
+
+    def _acquire_engine(self, batch_size: int) -> HipEngine:
+        """The engine a generate() call runs on, with its lock held.  The reference serves two requests per model at a time
+        (utilities/app_constants.py:18); one library handle carries one generation, so a second handle over the SAME weight tensors
+        (a few MB of workspace) takes the second request instead of making it wait for the first.  The device's persistent-kernel
+        tenancy (include/zonos_hip.h) stays with whichever generation began first; the other runs the launches path."""
+        def take(e, blocking):
+            # (the engine lock is re-entrant for the calls a generation makes on its own thread; `generating` keeps a generate()
+            # nested in a callback from re-entering the handle that is mid-generation)
+            if not e.lock.acquire(blocking=blocking):
+                return False
+            if getattr(e, "generating", False):
+                e.lock.release()
+                return False
+            e.generating = True
+            return True
+        eng = self.engine(batch_size)
+        if take(eng, False):
+            return eng
+        with self._spare_guard:
+            sp = getattr(self, "_spare", None)
+            if sp is None or sp.max_rows < 2 * batch_size or sp.device != self.device:
+                self._spare = sp = self._new_engine(batch_size)
+        if take(sp, False):
+            return sp
+        if not take(eng, True):                             # both busy: queue on the first
+            raise _lib.ZonosHipError("generate() re-entered from a callback while both of the model's engines are generating")
+        return eng
 
     # ------------------------------------------------------------------ embed / heads
     @torch.inference_mode()
-    def embed_codes(self, codes: torch.Tensor) -> torch.Tensor:
+    def embed_codes(self, codes: torch.Tensor, _eng: HipEngine | None = None) -> torch.Tensor:
         """codec_utils.py:15-37: codes [B, n_q, T] -> bf16 [B, T, d]."""
         B, nq, T = codes.shape
-        eng = self.engine(1)
+        eng = _eng if _eng is not None else self.engine(1)
         flat = codes.permute(0, 2, 1).reshape(B * T, nq).to(device=self.device, dtype=torch.int32).contiguous()
         out = torch.empty(B * T, self.config.backbone.d_model, dtype=torch.bfloat16, device=self.device)
         eng.call("zn_op_embed", flat.data_ptr(), out.data_ptr(), B * T, eng.stream())
@@ -177,11 +213,18 @@ class Zonos(nn.Module):
         if dev.type != "cuda":
             raise _lib.ZonosHipError("zonos_amd runs on MI355X only: move the model to a cuda device (no CPU fallback)")
         B = batch_size
-        eng = self.engine(B)
-        # the engine's handle holds this generation's state: concurrent generate() calls on one model queue here
         if seed is None:
             seed = int(torch.randint(0, 2 ** 62, (1,)).item())
-        with eng.lock, torch.cuda.device(dev):
+        # an engine's handle holds this generation's state: a third concurrent generate() call on one model queues here
+        eng = self._acquire_engine(B)
+        try:
+            return self._generate_on(eng, dev, prefix_conditioning, audio_prefix_codes, max_new_tokens, cfg_scale, B, sampling_params, callback, seed, _trace)
+        finally:
+            eng.generating = False
+            eng.lock.release()
+
+    def _generate_on(self, eng, dev, prefix_conditioning, audio_prefix_codes, max_new_tokens, cfg_scale, B, sampling_params, callback, seed, _trace):
+        with torch.cuda.device(dev):
             try:
                 return self._generate_locked(eng, prefix_conditioning, audio_prefix_codes, max_new_tokens, cfg_scale, B, sampling_params, callback,
                                              seed, _trace)
@@ -238,7 +281,7 @@ class Zonos(nn.Module):
         """Prefill, first frame and the hot loop (model.py:421-509); returns the final column offset."""
         dev = self.device
         # prefill (generation_utils.py:236-244): [cond ‖ uncond] conditioning + embed(delayed[..., :P+1]) for both halves
-        emb = self.embed_codes(delayed[..., :offset])
+        emb = self.embed_codes(delayed[..., :offset], _eng=eng)
         hidden = torch.cat([prefix_conditioning.to(device=dev, dtype=torch.bfloat16), emb.repeat(2, 1, 1)], dim=1).contiguous()
         S = hidden.shape[1]
         eng.call("zn_prefill", hidden.data_ptr(), S, st)
