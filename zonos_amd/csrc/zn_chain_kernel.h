@@ -33,6 +33,12 @@
 #define ZN_CH_NBUF 3                                       // weight tiles requested ahead per compute wave (register buffers)
 #endif
 #define ZN_CH_THREADS ((ZN_CH_CWAVES + 2) * 64)              // + one communication wave per activation row
+#ifndef ZN_CH_SWEEP_DELAY
+#define ZN_CH_SWEEP_DELAY 40                               // s_sleep units (64 cycles) between an op's publish and the first sweep pass for its output (zn_step_kernel.h: ZN_SK_SWEEP_DELAY)
+#endif
+#ifndef ZN_SWEEP_BACKOFF
+#define ZN_SWEEP_BACKOFF 0                                 // s_sleep units (64 cycles) between a failed sweep pass and the next
+#endif
 #define ZN_CH_TIMEOUT_TICKS 2000000ull                     // 20 ms of s_memrealtime (100 MHz) ...
 #define ZN_CH_TIMEOUT_PASSES 4096u                         // ... AND this many sweep passes (~1 us each when the wave runs): see sweep_granules
 
@@ -112,6 +118,7 @@ ZN_DEVINL bool sweep_granules(__amdgpu_buffer_rsrc_t rs, const int (&off)[N], un
     }
     const unsigned long long bad = __builtin_amdgcn_ballot_w64(!ok);
     if (bad == 0ull) { if (passes_out) *passes_out = np; return true; }
+    if constexpr (ZN_SWEEP_BACKOFF > 0) __builtin_amdgcn_s_sleep(ZN_SWEEP_BACKOFF);      // a failed pass: let the publishers' stores through before asking again
     if ((np >= ZN_CH_TIMEOUT_PASSES && __builtin_amdgcn_s_memrealtime() - t0 > ZN_CH_TIMEOUT_TICKS) || __hip_atomic_load(tmo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
       if (lane == (int)__builtin_ctzll(bad) && atomicAdd(tmo, 1) == 0 && who.diag) {
         unsigned badoff = 0xffffffffu, badtag = 0;            // the first stale granule of this lane, read once more
@@ -388,6 +395,7 @@ __global__ __launch_bounds__(ZN_CH_THREADS) void chain_kernel(ChainArgs a) {
       if constexpr (op != 2) {                             // (fc2's input is swept by the compute waves)
         // (requesting the first pass ahead of the compute waves' held-back requests was measured slower, 1.089 vs 1.023 ms per step: it
         // comes back before the slowest publishers' stores are visible, and the second pass then queues behind those requests)
+        if constexpr (ZN_CH_SWEEP_DELAY > 0) __builtin_amdgcn_s_sleep(ZN_CH_SWEEP_DELAY);
         sweep_granules<NCH>(zn_rsrc(op == 0 ? a.g_y1 : op == 1 ? a.g_x1 : a.g_x2), goff, tag, g, a.tmo, lane,
                             SweepWho{((op == 0 ? 1u : op == 1 ? 2u : 4u) << 8) | (unsigned)a.stamp_layer, a.diag},
                             (a.stamps && epi && c == 0 && lane == 0) ? (unsigned*)(a.stamps + 24 + op) : nullptr);

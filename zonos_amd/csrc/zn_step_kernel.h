@@ -46,6 +46,12 @@
 #ifndef ZN_SK_EARLY
 #define ZN_SK_EARLY 0                                       // requests for a LATER op's tiles that a wave may raise per op before that op's results are published (the
 #endif                                                      // rest wait for the publish: ZN_CH_DEFER_MASK).  Measured, 400 tokens: 0 0.8694 ms per step, 1 0.8907, 2 0.9398
+#ifndef ZN_SK_MSWEEP_DELAY
+#define ZN_SK_MSWEEP_DELAY 0                                // the same for fc2's input, swept by the compute waves
+#endif
+#ifndef ZN_SK_SWEEP_DELAY
+#define ZN_SK_SWEEP_DELAY 40                                // s_sleep units (64 cycles) between an op's publish and the first sweep pass for its output
+#endif                                                      // (two sweep passes in flight per wave, a new one every half round trip: 0.891 vs 0.869 ms per step - more polling loads the fabric)
 #define ZN_SK_MAXKEYS 1024                                  // two 512-key blocks: longer contexts go down the per-block path
 #define ZN_SK_DYN_LDS (ZN_SK_CW * ZN_SK_PARK * 8192)        // parked tiles (streaming role) / StepAttnLds (attention role)
 #ifndef ZN_SK_PACE_SHIFT
@@ -143,7 +149,7 @@ ZN_DEVINL void step_attention_role(const ChainArgs& a, StepAttnLds& S, const uns
         int off1[1] = {first ? qoff : koff};
         u32x4 d1[1];
         pace.sleep();
-        sweep_granules<1>(zn_rsrc(a.g_qkv), off1, tag - 1u, d1, a.tmo, lane, SweepWho{(5u << 8) | (unsigned)li, a.diag});
+        sweep_granules<1>(zn_rsrc(a.g_qkv), off1, tag - 1u, d1, a.tmo, lane, SweepWho{(5u << 8) | (unsigned)li, a.diag});   // (one pass at a time: 253 VGPRs here)
         pace.done();
         if (first) *(u32x4*)&S.q[lane >> 4][(lane & 15) * 8] = d1[0];
         else if (lane < 16) *(u32x4*)&S.knew[lane * 8] = d1[0];
@@ -351,6 +357,7 @@ __global__ __launch_bounds__(ZN_SK_THREADS) void step_kernel(ChainArgs a) {
   // ------------------------------------------------------------------------------------------------ streaming role
   __shared__ __attribute__((aligned(16))) bf16_t s_act[R * D];              // the current op's input vector (ops 0, 1, 2, 4)
   __shared__ float s_res[2][64][2][R];                                      // per-unit results of even / odd ops (fc2: [unit * 4 + quarter])
+  __shared__ __attribute__((aligned(16))) bf16_t s_ln[4 * D];               // the block's LayerNorm parameters (norm2 w, b; next norm w, b): staged by the helper waves
   const int sc = c - natt, NSW = (int)gridDim.x - natt;
   auto split = [&](int U, int& n, int& start) { const int base = U / NSW, extra = U % NSW; n = base + (sc < extra ? 1 : 0); start = sc * base + min(sc, extra); };
   int n_out, s_out, ng1, sg1;
@@ -421,6 +428,16 @@ __global__ __launch_bounds__(ZN_SK_THREADS) void step_kernel(ChainArgs a) {
           });
         }
       };
+      {   // the block's LayerNorm parameters -> LDS (the communication waves' registers are for sweep passes in flight); the previous
+          // block's were last read before its B(4)
+        const bf16_t* p0 = hw == 0 ? a.layers[li].ln2_w : a.layers[li].lnn_w;
+        const bf16_t* p1 = hw == 0 ? a.layers[li].ln2_b : a.layers[li].lnn_b;
+#pragma unroll
+        for (int c2 = 0; c2 < NCH; ++c2) {
+          *(u32x4*)&s_ln[(2 * hw) * D + (c2 * 64 + lane) * 8] = ld16g(p0 + (c2 * 64 + lane) * 8);
+          *(u32x4*)&s_ln[(2 * hw + 1) * D + (c2 * 64 + lane) * 8] = ld16g(p1 + (c2 * 64 + lane) * 8);
+        }
+      }
       if constexpr (ZN_SK_HELP_AT == 0) hload();
       __syncthreads();                                        // B(0)
       if constexpr (ZN_SK_HELP_AT == 1) hload();
@@ -541,6 +558,7 @@ __global__ __launch_bounds__(ZN_SK_THREADS) void step_kernel(ChainArgs a) {
             for (int c2 = 0; c2 < NCH; ++c2)
 #pragma unroll
               for (int r = 0; r < R; ++r) off[c2 * R + r] = (r * (2 * D) + wave * (D / 2) + (c2 * 64 + lane) * 4) * 8;
+            if constexpr (ZN_SK_MSWEEP_DELAY > 0) __builtin_amdgcn_s_sleep(ZN_SK_MSWEEP_DELAY);
             sweep_granules<NCH * R>(zn_rsrc(a.g_m), off, tag, dat, a.tmo, lane, SweepWho{(3u << 8) | (unsigned)li, a.diag});
 #pragma unroll
             for (int c2 = 0; c2 < NCH; ++c2)
@@ -584,7 +602,6 @@ __global__ __launch_bounds__(ZN_SK_THREADS) void step_kernel(ChainArgs a) {
   const int myr = wave - CW;
   const bool epi = myr == 0;
   u32x4 g[NCH];
-  u32x4 l2w[NCH], l2b[NCH], lnw[NCH], lnbb[NCH];
   const int ij = lane >> 1, ir = lane & 1;
   const bool it_out = epi && ij < n_out;
   const int u_out = s_out + (it_out ? ij : 0);
@@ -619,10 +636,9 @@ __global__ __launch_bounds__(ZN_SK_THREADS) void step_kernel(ChainArgs a) {
     int nst = 0;
     auto stamp = [&]() { if (stamped) a.stamps[nst] = __builtin_amdgcn_s_memrealtime(); ++nst; };
     stamp();                                               // 0: block starts
-#pragma unroll
-    for (int c2 = 0; c2 < NCH; ++c2) { l2w[c2] = ld16g(Lr.ln2_w + (c2 * 64 + lane) * 8); l2b[c2] = ld16g(Lr.ln2_b + (c2 * 64 + lane) * 8); }
-#pragma unroll
-    for (int c2 = 0; c2 < NCH; ++c2) { lnw[c2] = ld16g(Lr.lnn_w + (c2 * 64 + lane) * 8); lnbb[c2] = ld16g(Lr.lnn_b + (c2 * 64 + lane) * 8); }
+    int opq = 0;                                           // 0 the optimiser cannot see through: the granule addresses below are formed where they are used
+    asm volatile("" : "+v"(opq));                          // (hoisted out of the block loop they sat beside the sweep passes in flight and spilled)
+    const int irq = ir + opq, uoq = u_out + opq, uqq = u_qkv + opq;
     // ---- the attention output of all heads -> s_act
     pace.sleep();
     stamp();                                               // 1: polling starts
@@ -639,11 +655,11 @@ __global__ __launch_bounds__(ZN_SK_THREADS) void step_kernel(ChainArgs a) {
       stamp();
       // ---- epilogue of this workgroup's units, published as granules
       if constexpr (op == 0) {                             // EPI_STORE
-        if (it_out) st_granule(a.g_y1 + (size_t)ir * (D / 2) + u_out, tag, pack2(s_res[par][ij][0][ir], s_res[par][ij][1][ir]));
+        if (it_out) st_granule(a.g_y1 + (size_t)irq * (D / 2) + uoq, tag, pack2(s_res[par][ij][0][ir], s_res[par][ij][1][ir]));
       } else if constexpr (op == 1) {                      // EPI_RESID
         if (it_out) {
           x1own = pack2(lo_f(resid) + bfround(s_res[par][ij][0][ir]), hi_f(resid) + bfround(s_res[par][ij][1][ir]));
-          st_granule(a.g_x1 + (size_t)ir * (D / 2) + u_out, tag, x1own);
+          st_granule(a.g_x1 + (size_t)irq * (D / 2) + uoq, tag, x1own);
         }
       } else if constexpr (op == 2) {                      // EPI_SILU: each communication wave its own row; lane = m element, neighbours share a granule
         const bool on = lane < n_fc1;
@@ -652,23 +668,23 @@ __global__ __launch_bounds__(ZN_SK_THREADS) void step_kernel(ChainArgs a) {
         const float sg = bfround(gt / (1.0f + expf(-gt)));
         const unsigned mine = (unsigned)f2bf(y * sg);
         const unsigned nbv = (unsigned)__shfl_down((int)mine, 1);
-        if (on && (lane & 1) == 0) st_granule(a.g_m + (size_t)myr * (F / 2) + ((s_fc1 + lane) >> 1), tag, mine | (nbv << 16));
+        if (on && (lane & 1) == 0) st_granule(a.g_m + (size_t)(myr + opq) * (F / 2) + ((s_fc1 + lane) >> 1), tag, mine | (nbv << 16));
       } else if constexpr (op == 3) {                      // EPI_RESID over the four K quarters, in gemv_kernel's order
         if (it_out) {
           const float vA = ((s_res[par][ij * 4 + 0][0][ir] + s_res[par][ij * 4 + 1][0][ir]) + s_res[par][ij * 4 + 2][0][ir]) + s_res[par][ij * 4 + 3][0][ir];
           const float vB = ((s_res[par][ij * 4 + 0][1][ir] + s_res[par][ij * 4 + 1][1][ir]) + s_res[par][ij * 4 + 2][1][ir]) + s_res[par][ij * 4 + 3][1][ir];
           const unsigned o = pack2(lo_f(x1own) + bfround(vA), hi_f(x1own) + bfround(vB));
-          st_granule(a.g_x2 + (size_t)ir * (D / 2) + u_out, tag, o);
-          if (last) *(unsigned*)(a.xout + (size_t)ir * D + 2 * u_out) = o;
-          if (a.trace) *(unsigned*)(a.trace + ((size_t)(8 * li) * R + ir) * D + 2 * u_out) = o;
+          st_granule(a.g_x2 + (size_t)irq * (D / 2) + uoq, tag, o);
+          if (last) *(unsigned*)(a.xout + (size_t)irq * D + 2 * uoq) = o;
+          if (a.trace) *(unsigned*)(a.trace + ((size_t)(8 * li) * R + irq) * D + 2 * uoq) = o;
           resid = o;                                       // the residual stream entering the next block
         }
       } else {
         if (last) {                                        // EPI_F32 (gemv_epilogue): bf16-valued fp32 logits
           if (epi && ij < n_hd) {
             const int u = s_hd + ij;
-            a.heads_out[(size_t)ir * a.heads_rows + 2 * u] = bfround(s_res[par][ij][0][ir]);
-            if (2 * u + 1 < a.heads_rows) a.heads_out[(size_t)ir * a.heads_rows + 2 * u + 1] = bfround(s_res[par][ij][1][ir]);
+            a.heads_out[(size_t)irq * a.heads_rows + 2 * u] = bfround(s_res[par][ij][0][ir]);
+            if (2 * u + 1 < a.heads_rows) a.heads_out[(size_t)irq * a.heads_rows + 2 * u + 1] = bfround(s_res[par][ij][1][ir]);
           }
         } else if (it_qkv) {                               // EPI_ROPE_KV (gemv_epilogue) of the next block, q | k | v also as granules
           const int rowA = 2 * u_qkv;
@@ -679,10 +695,10 @@ __global__ __launch_bounds__(ZN_SK_THREADS) void step_kernel(ChainArgs a) {
             zn_rope_pair(x0, x1, cs, sn, re, im);
             packed = pack2(re, im);
           } else packed = pack2(x0, x1);
-          st_granule(a.g_qkv + (size_t)ir * (a.nqkv / 2) + u_qkv, tag, packed);
+          st_granule(a.g_qkv + (size_t)irq * (a.nqkv / 2) + uqq, tag, packed);
           if (rowA >= nq && pos < a.max_len) {
             const int which = rowA < nq + nk ? 0 : 1, colk = rowA - nq - which * nk;
-            *(unsigned*)(Lr.kv_next + (((size_t)ir * a.max_len + pos) * 2 + which) * nk + colk) = packed;
+            *(unsigned*)(Lr.kv_next + (((size_t)irq * a.max_len + pos) * 2 + which) * nk + colk) = packed;
           }
         }
       }
@@ -690,10 +706,19 @@ __global__ __launch_bounds__(ZN_SK_THREADS) void step_kernel(ChainArgs a) {
       stamp();
       if constexpr (op + 1 < NOPS) {
         if constexpr (op != 2) {                           // (fc2's input is swept by the compute waves)
+          if constexpr (ZN_SK_SWEEP_DELAY > 0) __builtin_amdgcn_s_sleep(ZN_SK_SWEEP_DELAY);
           sweep_granules<NCH>(zn_rsrc(op == 0 ? a.g_y1 : op == 1 ? a.g_x1 : a.g_x2), goff, tag, g, a.tmo, lane,
                               SweepWho{((op == 0 ? 1u : op == 1 ? 2u : 4u) << 8) | (unsigned)li, a.diag});
           stamp();
-          if constexpr (op == 1 || op == 3) chain_layernorm_row<NCH>(g, op == 1 ? l2w : lnw, op == 1 ? l2b : lnbb, a.eps);
+          if constexpr (op == 1 || op == 3) {
+            u32x4 lw[NCH], lb[NCH];
+#pragma unroll
+            for (int c2 = 0; c2 < NCH; ++c2) {
+              lw[c2] = *(const u32x4*)&s_ln[(op == 1 ? 0 : 2) * D + (c2 * 64 + lane) * 8];
+              lb[c2] = *(const u32x4*)&s_ln[(op == 1 ? 1 : 3) * D + (c2 * 64 + lane) * 8];
+            }
+            chain_layernorm_row<NCH>(g, lw, lb, a.eps);
+          }
 #pragma unroll
           for (int c2 = 0; c2 < NCH; ++c2) *(u32x4*)&s_act[myr * D + (c2 * 64 + lane) * 8] = g[c2];
           __syncthreads();                                 // B(op + 1)
