@@ -47,13 +47,17 @@
 #define ZN_SK_EARLY 0                                       // requests for a LATER op's tiles that a wave may raise per op before that op's results are published (the
 #endif                                                      // rest wait for the publish: ZN_CH_DEFER_MASK).  Measured, 400 tokens: 0 0.8694 ms per step, 1 0.8907, 2 0.9398
 #ifndef ZN_SK_MSWEEP_DELAY
-#define ZN_SK_MSWEEP_DELAY 0                                // the same for fc2's input, swept by the compute waves
+#define ZN_SK_MSWEEP_DELAY 0                                // the same for fc2's input, swept by the compute waves behind fc2's held-back tile requests (24 / 48: 0.837 vs 0.8335;
+                                                            // that sweep's first pass issued AHEAD of those requests, 1 us after the publish: 0.868 vs 0.829)
 #endif
 #ifndef ZN_SK_SWEEP_DELAY
 #define ZN_SK_SWEEP_DELAY 40                                // s_sleep units (64 cycles) between an op's publish and the first sweep pass for its output
 #endif                                                      // (two sweep passes in flight per wave, a new one every half round trip: 0.891 vs 0.869 ms per step - more polling loads the fabric)
 #define ZN_SK_MAXKEYS 1024                                  // two 512-key blocks: longer contexts go down the per-block path
 #define ZN_SK_DYN_LDS (ZN_SK_CW * ZN_SK_PARK * 8192)        // parked tiles (streaming role) / StepAttnLds (attention role)
+#ifndef ZN_SK_PACE_MARGIN
+#define ZN_SK_PACE_MARGIN 0                                 // > 0: sleep until this many 10 ns ticks before the previous wait's length instead of a fraction of it
+#endif
 #ifndef ZN_SK_PACE_SHIFT
 #define ZN_SK_PACE_SHIFT 2                                  // a waiting wave sleeps through the first (1 - 2^-SHIFT) of the wait it measured one block earlier
 #endif
@@ -76,7 +80,7 @@ struct StepPacer {
   unsigned long long t_ref; unsigned prev;
   ZN_DEVINL void start() { t_ref = __builtin_amdgcn_s_memrealtime(); }
   ZN_DEVINL void sleep() const {
-    const unsigned long long until = t_ref + (prev - (prev >> ZN_SK_PACE_SHIFT));
+    const unsigned long long until = t_ref + (ZN_SK_PACE_MARGIN > 0 ? (prev > ZN_SK_PACE_MARGIN ? prev - ZN_SK_PACE_MARGIN : 0u) : (prev - (prev >> ZN_SK_PACE_SHIFT)));
     while (__builtin_amdgcn_s_memrealtime() < until) __builtin_amdgcn_s_sleep(8);
   }
   ZN_DEVINL void done() { prev = (unsigned)(__builtin_amdgcn_s_memrealtime() - t_ref); }
