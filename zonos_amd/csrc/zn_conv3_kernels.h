@@ -1,0 +1,238 @@
+// DAC decoder convolutions on the bf16 matrix cores with fp32-grade operands (zn_dac.hip's decode path).
+//
+// An fp32 value v is carried as three bf16 terms h + m + l (h = bf16(v), m = bf16(v - h), l = bf16(v - h - m): 24 significand
+// bits, the differences are exact in fp32), and a product a * b as the six partial products whose magnitude is >= 2^-16 |a b|
+// (hh, hm, mh, mm, hl, lh; the three dropped ones are <= 2^-24 |a b|, the size of an fp32 rounding), each exact in the matrix
+// core and accumulated in fp32.  v_mfma_f32_32x32x16_bf16 is 16 x the rate of v_mfma_f32_32x32x2_f32, so six of them do the
+// work of eight fp32 MFMAs in 3/8 of the issue time - and the Snake activation, which zn_conv_kernels.h applies to its
+// input rows once per output-channel tile (6 - 12 times per element), moves to the PRODUCER's epilogue: a layer stores the
+// next layer's input, activated and split, once.
+//
+// Layouts.  Activations "S3": [B][T][C/16][3][16] bf16 - per time step and 16-channel chunk the three terms of the chunk, 96
+// contiguous bytes (what a workgroup stages per row and K chunk).  Weights "W3": [phase][Cin/16][tap][CoutPad][3][16].  The
+// residual stream a unit adds back at its end (DacResidualUnit, modeling_dac.py:175-209) stays fp32 [B][T][C].
+// Workgroup: 256 threads, RB x 128 output times x 64 output channels; wave = RB x 32 rows x 64 channels; K advances 16 input
+// channels per stage: the rows a tile needs (with the dilation halo) and all taps of the stage's weights sit in LDS (96-byte
+// rows, the two 16-byte halves of a term swapped on rows with bit 3 set: conflict-free ds_read_b128 fragments without padding;
+// 71 KB at RB = 2, so two workgroups share a CU and one stages while the other multiplies).
+#pragma once
+#include "zn_conv_kernels.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 c3_bf16x8;
+
+#define C3_KC 16
+#define C3_TN 64
+#define C3_ROW 96                      // LDS / S3 bytes per (row, 16-channel chunk): 3 terms x 16 bf16
+#define C3_MAXTAPS 7
+#define C3_HALO 54                     // 6 * dilation 9
+
+struct Conv3Args {
+  const bf16_t* in; int Tin, Cin;          // S3 [B][Tin][Cin/16][3][16]: already activated (or the raw latent)
+  const bf16_t* w;                         // W3 [phase][Cin/16][tap][CoutPad][3][16]
+  const float* bias;                       // [Cout]
+  const float* alpha;                      // Snake alpha of the NEXT layer (over this layer's output channels), or NULL: out3 holds the plain output
+  const float* skip;                       // fp32 residual [B][Tout][Cout], or NULL
+  float* out32;                            // fp32 output [B][Tout][Cout] (before the next Snake), or NULL; may alias skip
+  bf16_t* out3;                            // S3 output (after the next Snake), or NULL
+  int Tout, Cout, CoutPad;
+  int M;                                   // GEMM rows per phase
+  int taps, off0, offstep;                 // input row of GEMM row m, tap k: m + off0 + k*offstep
+  int ostride, ooff, phases;               // output time of row m in phase p: m*ostride + ooff + p
+};
+
+ZN_DEVINL void c3_split(float v, bf16_t& h, bf16_t& m, bf16_t& l) {
+  h = f2bf(v);
+  const float r1 = v - bf2f(h);            // exact
+  m = f2bf(r1);
+  l = f2bf(r1 - bf2f(m));                  // exact difference, one rounding
+}
+ZN_DEVINL int c3_swz(int row, int term, int half) { return row * C3_ROW + term * 32 + ((half ^ ((row >> 3) & 1)) << 4); }
+
+template <int RB>
+__global__ __launch_bounds__(256, 2) void dac_conv3_kernel(Conv3Args a) {
+  constexpr int TM = RB * 128, NT = C3_TN / 32, MAXROWS = TM + C3_HALO;
+  extern __shared__ __attribute__((aligned(16))) unsigned char c3_smem[];
+  unsigned char* s_in = c3_smem;                            // [MAXROWS][96]
+  unsigned char* s_w = c3_smem + MAXROWS * C3_ROW;          // [taps][64][96]
+  const int m0 = blockIdx.x * TM, n0 = blockIdx.y * C3_TN;
+  const int b = blockIdx.z / a.phases, phase = blockIdx.z % a.phases;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int offlast = a.off0 + (a.taps - 1) * a.offstep;
+  const int offmin = a.off0 < offlast ? a.off0 : offlast, offmax = a.off0 < offlast ? offlast : a.off0;
+  const int nrows = TM + offmax - offmin;
+  const int nck = a.Cin / C3_KC;
+  const bf16_t* inb = a.in + (size_t)b * a.Tin * a.Cin * 3;
+  const bf16_t* wp = a.w + (size_t)phase * nck * a.taps * a.CoutPad * 48;
+  f32x16 acc[RB][NT];
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[rb][nt][e] = 0.f;
+
+  // staging slots (16-byte pieces: 6 per row): the next stage's requests go out before this stage's MFMAs and land in LDS after them.
+  // Buffer loads: one 32-bit offset per piece (rows outside [0, Tin) fall outside the batch element's range and read as zeros: the
+  // convolution's zero padding), the K stage advances through the scalar offset.
+  constexpr int IN_P = (MAXROWS * 6 + 255) / 256, W_P = (C3_MAXTAPS * C3_TN * 6 + 255) / 256;
+  u32x4 rin[IN_P], rw[W_P];
+  int vin[IN_P], vw[W_P];
+  const int n_in = nrows * 6, n_w = a.taps * C3_TN * 6;
+  const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)inb, 0, (int)((size_t)a.Tin * nck * C3_ROW), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)wp, 0, (int)((size_t)nck * a.taps * a.CoutPad * C3_ROW), 0x00020000);
+#pragma unroll
+  for (int j = 0; j < IN_P; ++j) {
+    const int i = tid + j * 256, row = i / 6, q = i - row * 6;
+    vin[j] = i < n_in ? (m0 + offmin + row) * (nck * C3_ROW) + q * 16 : (int)0x80000000;
+  }
+#pragma unroll
+  for (int j = 0; j < W_P; ++j) {
+    const int i = tid + j * 256, rowi = i / 6, q = i - rowi * 6;         // rowi = tap * 64 + n
+    const int tap = rowi / C3_TN, n = rowi - tap * C3_TN;
+    vw[j] = i < n_w ? (tap * a.CoutPad + n0 + n) * C3_ROW + q * 16 : (int)0x80000000;
+  }
+  auto fetch = [&](int ck) {
+#pragma unroll
+    for (int j = 0; j < IN_P; ++j) rin[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, vin[j], ck * C3_ROW, 0);
+#pragma unroll
+    for (int j = 0; j < W_P; ++j) rw[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, vw[j], ck * a.taps * a.CoutPad * C3_ROW, 0);
+  };
+  fetch(0);
+  const int fr = lane & 31, fh = lane >> 5;                  // fragment row / column, K half
+  for (int ck = 0; ck < nck; ++ck) {
+    __syncthreads();                                     // the previous stage's fragment reads are done
+#pragma unroll
+    for (int j = 0; j < IN_P; ++j) {
+      const int i = tid + j * 256, row = i / 6, q = i - row * 6;
+      if (i < n_in) *(u32x4*)(s_in + c3_swz(row, q >> 1, q & 1)) = rin[j];
+    }
+#pragma unroll
+    for (int j = 0; j < W_P; ++j) {
+      const int i = tid + j * 256, rowi = i / 6, q = i - rowi * 6;
+      if (i < n_w) *(u32x4*)(s_w + (rowi / C3_TN) * (C3_TN * C3_ROW) + c3_swz(rowi % C3_TN, q >> 1, q & 1)) = rw[j];
+    }
+    __syncthreads();
+    if (ck + 1 < nck) fetch(ck + 1);
+    for (int tap = 0; tap < a.taps; ++tap) {
+      const int r0 = wave * (32 * RB) + fr + a.off0 + tap * a.offstep - offmin;
+      c3_bf16x8 A[RB][3], Bf[NT][3];
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) A[rb][p] = *(const c3_bf16x8*)(s_in + c3_swz(r0 + rb * 32, p, fh));
+      const unsigned char* wt = s_w + tap * (C3_TN * C3_ROW);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) Bf[nt][p] = *(const c3_bf16x8*)(wt + c3_swz(nt * 32 + fr, p, fh));
+      // the six partial products, smallest first; consecutive MFMAs go to different accumulators
+      constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};
+#pragma unroll
+      for (int t6 = 0; t6 < 6; ++t6)
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+            acc[rb][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[rb][PA[t6]], Bf[nt][PB[t6]], acc[rb][nt], 0, 0, 0);
+    }
+  }
+  // ---- epilogue.  C layout: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).  bias, residual, fp32 store from the
+  // registers; the S3 image of 128 rows x 64 channels (next Snake applied, split) goes through LDS so that it leaves in
+  // 16-byte pieces, 384 contiguous bytes per row.
+  unsigned char* s_o = c3_smem;                              // [128][4 chunks][96]
+  const int nchunk_out = a.Cout / C3_KC;
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb) {
+    __syncthreads();
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int cl = nt * 32 + fr, co = n0 + cl;
+      const bool c_ok = co < a.Cout;
+      const float bv = (a.bias && c_ok) ? a.bias[co] : 0.f;
+      const float al = (a.alpha && c_ok) ? a.alpha[co] : 0.f;
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const int rowi = (reg & 3) + 8 * (reg >> 2) + 4 * fh;
+        const int m = m0 + wave * (32 * RB) + rb * 32 + rowi;
+        const int to = m * a.ostride + a.ooff + phase;
+        float v = acc[rb][nt][reg] + bv;
+        if (c_ok && m < a.M && to >= 0 && to < a.Tout) {
+          const size_t o = ((size_t)b * a.Tout + to) * a.Cout + co;
+          if (a.skip) v = a.skip[o] + v;
+          if (a.out32) a.out32[o] = v;
+        }
+        if (a.out3) {
+          if (a.alpha) v = snake_f(v, al);
+          bf16_t h, mm, l;
+          c3_split(v, h, mm, l);
+          bf16_t* d = (bf16_t*)(s_o + (wave * 32 + rowi) * (4 * C3_ROW) + (cl >> 4) * C3_ROW) + (cl & 15);
+          d[0] = h; d[16] = mm; d[32] = l;
+        }
+      }
+    }
+    if (!a.out3) continue;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 12; ++j) {
+      const int piece = tid + j * 256, irow = piece / 24, q = piece - irow * 24;     // 128 rows x 24 pieces
+      const int m = m0 + (irow >> 5) * (32 * RB) + rb * 32 + (irow & 31);
+      const int to = m * a.ostride + a.ooff + phase;
+      const int chunk = (n0 >> 4) + q / 6;
+      if (m < a.M && to >= 0 && to < a.Tout && chunk < nchunk_out)
+        *(u32x4*)(a.out3 + (((size_t)b * a.Tout + to) * nchunk_out + chunk) * 48 + (q % 6) * 8) = *(const u32x4*)(s_o + irow * (4 * C3_ROW) + q * 16);
+    }
+  }
+}
+
+// fp32 [n] -> S3 split of a channels-last tensor [rows][C] (the latent the decoder starts from)
+__global__ __launch_bounds__(256) void dac_split3_kernel(const float* x, bf16_t* o, size_t n, int C) {
+  for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const size_t row = i / C; const int c = (int)(i - row * C);
+    bf16_t h, m, l;
+    c3_split(x[i], h, m, l);
+    bf16_t* d = o + (row * (C / C3_KC) + (c >> 4)) * 48 + (c & 15);
+    d[0] = h; d[16] = m; d[32] = l;
+  }
+}
+// conv weight [Cout][Cin][K] -> W3 [Cin/16][K][CoutPad][3][16]
+__global__ void dac_w3conv_kernel(const float* w, bf16_t* o, int Cout, int Cin, int K, int CoutPad) {
+  const size_t n = (size_t)K * Cin * CoutPad;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const int ci = i % Cin, co = (i / Cin) % CoutPad, k = i / ((size_t)Cin * CoutPad);
+    bf16_t h, m, l;
+    c3_split(co < Cout ? w[((size_t)co * Cin + ci) * K + k] : 0.f, h, m, l);
+    bf16_t* d = o + ((((size_t)(ci >> 4)) * K + k) * CoutPad + co) * 48 + (ci & 15);
+    d[0] = h; d[16] = m; d[32] = l;
+  }
+}
+// conv-transpose weight [Cin][Cout][2s] -> W3 [phase p][Cin/16][tap j][CoutPad][3][16], tap 0 <-> k = p (input q), tap 1 <-> k = p + s (input q-1)
+__global__ void dac_w3convt_kernel(const float* w, bf16_t* o, int Cin, int Cout, int s, int CoutPad) {
+  const size_t n = (size_t)s * 2 * Cin * CoutPad;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const int ci = i % Cin, co = (i / Cin) % CoutPad, j = (i / ((size_t)Cin * CoutPad)) % 2, p = i / ((size_t)Cin * CoutPad * 2);
+    bf16_t h, m, l;
+    c3_split(co < Cout ? w[((size_t)ci * Cout + co) * (2 * s) + p + j * s] : 0.f, h, m, l);
+    bf16_t* d = o + (((((size_t)p * (Cin >> 4)) + (ci >> 4)) * 2 + j) * CoutPad + co) * 48 + (ci & 15);
+    d[0] = h; d[16] = m; d[32] = l;
+  }
+}
+
+static inline size_t zn_conv3_lds(int rb) { return (size_t)(rb * 128 + C3_HALO) * C3_ROW + (size_t)C3_MAXTAPS * C3_TN * C3_ROW; }
+static inline hipError_t zn_conv3_set_attrs() {
+  hipError_t e = hipFuncSetAttribute((const void*)dac_conv3_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)zn_conv3_lds(1));
+  if (e != hipSuccess) return e;
+  return hipFuncSetAttribute((const void*)dac_conv3_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)zn_conv3_lds(2));
+}
+static inline int zn_conv3_pad(int c) { return (c + C3_TN - 1) / C3_TN * C3_TN; }
+// 256-row tiles once they fill the chip's 512 workgroup slots, 128-row tiles for the short early layers
+static inline void zn_conv3_launch(const Conv3Args& a, int B, hipStream_t s) {
+  const int ntile = a.CoutPad / C3_TN;
+  const long wg2 = (long)((a.M + 255) / 256) * ntile * B * a.phases;
+  if (wg2 >= 512) {
+    dim3 grid((a.M + 255) / 256, ntile, B * a.phases);
+    hipLaunchKernelGGL((dac_conv3_kernel<2>), grid, dim3(256), zn_conv3_lds(2), s, a);
+  } else {
+    dim3 grid((a.M + 127) / 128, ntile, B * a.phases);
+    hipLaunchKernelGGL((dac_conv3_kernel<1>), grid, dim3(256), zn_conv3_lds(1), s, a);
+  }
+}

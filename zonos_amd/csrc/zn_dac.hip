@@ -18,6 +18,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 #include <map>
@@ -25,6 +26,7 @@
 #include <vector>
 
 #include "zn_conv_kernels.h"
+#include "zn_conv3_kernels.h"
 
 static thread_local std::string g_dac_err;
 
@@ -217,7 +219,7 @@ __global__ __launch_bounds__(256) void dac_rvq_kernel(RvqArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------ host
-struct ConvLayer { float *w = nullptr; const float *bias = nullptr, *alpha = nullptr; int Cin = 0, Cout = 0, CoutPad = 0, K = 0, dil = 1, stride = 0; };
+struct ConvLayer { float *w = nullptr; bf16_t* w3 = nullptr; const float *bias = nullptr, *alpha = nullptr; int Cin = 0, Cout = 0, CoutPad = 0, K = 0, dil = 1, stride = 0; };
 struct zn_dac_s {
   zn_dac_config cfg;
   float* table = nullptr;
@@ -227,6 +229,11 @@ struct zn_dac_s {
   int fin_C = 0;
   float* buf[3] = {nullptr, nullptr, nullptr};
   size_t buf_elems = 0;
+  // decode on the bf16 matrix cores with three-term operands (zn_conv3_kernels.h): the default.  ZONOS_DAC_CONV=fp32 in the environment of
+  // zn_dac_create keeps the decoder on the fp32 matrix cores (zn_conv_kernels.h; development: A/B of the two paths)
+  bool split3 = true;
+  bf16_t* s3[2] = {nullptr, nullptr};
+  size_t s3_elems = 0;
   // encoder (optional: present when the state dict carries encoder.* and quantizer in_proj tensors)
   bool has_encoder = false;
   const float *enc_w1 = nullptr, *enc_b1 = nullptr;
@@ -246,6 +253,7 @@ extern "C" int zn_dac_destroy(zn_dac d) {
   if (!d) return ZN_OK;
   for (float* p : d->owned) (void)hipFree(p);
   for (float* p : d->buf) if (p) (void)hipFree(p);
+  for (bf16_t* p : d->s3) if (p) (void)hipFree(p);
   delete d;
   return ZN_OK;
 }
@@ -253,7 +261,7 @@ extern "C" int zn_dac_destroy(zn_dac d) {
 static int pad32(int c) { return zn_conv_pad(c); }
 
 static int make_conv(zn_dac d, const std::map<std::string, const zn_dac_tensor*>& t, const std::string& wname, const std::string& bname,
-                     const char* aname, int Cin, int Cout, int K, int dil, ConvLayer& L) {
+                     const char* aname, int Cin, int Cout, int K, int dil, ConvLayer& L, bool dec3 = false) {
   auto w = t.find(wname), b = t.find(bname);
   if (w == t.end() || b == t.end()) DFAIL(d, ZN_ERR_ARG, "missing tensor %s / %s", wname.c_str(), bname.c_str());
   if (w->second->numel != (int64_t)Cout * Cin * K || b->second->numel != Cout) DFAIL(d, ZN_ERR_ARG, "shape mismatch for %s", wname.c_str());
@@ -267,6 +275,12 @@ static int make_conv(zn_dac d, const std::map<std::string, const zn_dac_tensor*>
   DHIP(d, hipMalloc(&L.w, (size_t)K * Cin * L.CoutPad * sizeof(float)));
   d->owned.push_back(L.w);
   hipLaunchKernelGGL(dac_wconv_kernel, dim3(512), dim3(256), 0, 0, w->second->data_dev, L.w, Cout, Cin, K, L.CoutPad);
+  if (dec3) {
+    const int cp = zn_conv3_pad(Cout);
+    DHIP(d, hipMalloc(&L.w3, (size_t)K * Cin * cp * 3 * sizeof(bf16_t)));
+    d->owned.push_back((float*)L.w3);
+    hipLaunchKernelGGL(dac_w3conv_kernel, dim3(512), dim3(256), 0, 0, w->second->data_dev, L.w3, Cout, Cin, K, cp);
+  }
   return ZN_OK;
 }
 
@@ -279,6 +293,7 @@ extern "C" int zn_dac_create(const zn_dac_config* cfg, const zn_dac_tensor* tens
   for (int i = 0; i < n; ++i) if (tensors[i].name && tensors[i].data_dev) t[tensors[i].name] = &tensors[i];
   zn_dac d = new zn_dac_s();
   d->cfg = *cfg;
+  { const char* e = getenv("ZONOS_DAC_CONV"); d->split3 = !(e && !strcmp(e, "fp32")); }
   int rc = ZN_OK;
   auto fail = [&](int code) { g_dac_err = d->err; zn_dac_destroy(d); return code; };
   // codebook tables
@@ -296,7 +311,7 @@ extern "C" int zn_dac_create(const zn_dac_config* cfg, const zn_dac_tensor* tens
                        d->table + (size_t)i * tsz, cfg->codebook_size, cfg->codebook_dim, cfg->hidden_size);
   }
   int c = cfg->decoder_hidden_size;
-  if ((rc = make_conv(d, t, "decoder.conv1.weight", "decoder.conv1.bias", nullptr, cfg->hidden_size, c, 7, 1, d->conv1))) return fail(rc);
+  if ((rc = make_conv(d, t, "decoder.conv1.weight", "decoder.conv1.bias", nullptr, cfg->hidden_size, c, 7, 1, d->conv1, d->split3))) return fail(rc);
   for (int bi = 0; bi < cfg->n_ratios; ++bi) {
     const std::string p = "decoder.block." + std::to_string(bi) + ".";
     const int s = cfg->ratios[bi], co = c / 2;
@@ -311,12 +326,18 @@ extern "C" int zn_dac_create(const zn_dac_config* cfg, const zn_dac_tensor* tens
     if (hipMalloc(&T.w, (size_t)s * 2 * c * T.CoutPad * sizeof(float)) != hipSuccess) { d->err = "hipMalloc failed"; return fail(ZN_ERR_HIP); }
     d->owned.push_back(T.w);
     hipLaunchKernelGGL(dac_wconvt_kernel, dim3(512), dim3(256), 0, 0, w->second->data_dev, T.w, c, co, s, T.CoutPad);
+    if (d->split3) {
+      const int cp = zn_conv3_pad(co);
+      if (hipMalloc(&T.w3, (size_t)s * 2 * c * cp * 3 * sizeof(bf16_t)) != hipSuccess) { d->err = "hipMalloc failed"; return fail(ZN_ERR_HIP); }
+      d->owned.push_back((float*)T.w3);
+      hipLaunchKernelGGL(dac_w3convt_kernel, dim3(512), dim3(256), 0, 0, w->second->data_dev, T.w3, c, co, s, cp);
+    }
     const int dils[3] = {1, 3, 9};
     for (int u = 0; u < 3; ++u) {
       const std::string r = p + "res_unit" + std::to_string(u + 1) + ".";
       const std::string a1 = r + "snake1.alpha", a2 = r + "snake2.alpha";
-      if ((rc = make_conv(d, t, r + "conv1.weight", r + "conv1.bias", a1.c_str(), co, co, 7, dils[u], B.c1[u]))) return fail(rc);
-      if ((rc = make_conv(d, t, r + "conv2.weight", r + "conv2.bias", a2.c_str(), co, co, 1, 1, B.c2[u]))) return fail(rc);
+      if ((rc = make_conv(d, t, r + "conv1.weight", r + "conv1.bias", a1.c_str(), co, co, 7, dils[u], B.c1[u], d->split3))) return fail(rc);
+      if ((rc = make_conv(d, t, r + "conv2.weight", r + "conv2.bias", a2.c_str(), co, co, 1, 1, B.c2[u], d->split3))) return fail(rc);
     }
     c = co;
   }
@@ -384,6 +405,7 @@ extern "C" int zn_dac_create(const zn_dac_config* cfg, const zn_dac_tensor* tens
     d->has_encoder = true;
   }
   if (hipDeviceSynchronize() != hipSuccess || hipGetLastError() != hipSuccess) { d->err = "weight re-layout kernels failed"; return fail(ZN_ERR_HIP); }
+  { hipError_t e = zn_conv3_set_attrs(); if (e != hipSuccess) { d->err = std::string("hipFuncSetAttribute: ") + hipGetErrorString(e); return fail(ZN_ERR_HIP); } }
   { hipError_t e = zn_conv_set_attrs(); if (e != hipSuccess) { d->err = std::string("hipFuncSetAttribute: ") + hipGetErrorString(e); return fail(ZN_ERR_HIP); } }
   (void)hipFuncSetAttribute((const void*)dac_final_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   *out = d;
@@ -404,6 +426,22 @@ static int launch_conv(zn_dac d, const ConvLayer& L, const float* in, int Tin, c
   return launch_conv_args(a, L.CoutPad, B, s);
 }
 
+// Three-term path: `in3` is the layer's input as the producer left it (activated, split); alpha_next = the Snake the consumer of this layer's
+// output applies (NULL: none / the consumer reads out32).
+static void launch_conv3(const ConvLayer& L, const bf16_t* in3, int Tin, const float* skip, float* out32, bf16_t* out3, const float* alpha_next,
+                         int Tout, int B, bool transpose, hipStream_t s) {
+  Conv3Args a{};
+  a.in = in3; a.Tin = Tin; a.Cin = L.Cin; a.w = L.w3; a.bias = L.bias; a.alpha = alpha_next; a.skip = skip; a.out32 = out32; a.out3 = out3;
+  a.Tout = Tout; a.Cout = L.Cout; a.CoutPad = zn_conv3_pad(L.Cout);
+  if (!transpose) {
+    a.M = Tin; a.taps = L.K; a.off0 = -((L.K - 1) * L.dil) / 2; a.offstep = L.dil; a.ostride = 1; a.ooff = 0; a.phases = 1;
+  } else {
+    const int st = L.stride, padT = (st + 1) / 2;
+    a.M = Tin + 1; a.taps = 2; a.off0 = 0; a.offstep = -1; a.ostride = st; a.ooff = -padT; a.phases = st;
+  }
+  zn_conv3_launch(a, B, s);
+}
+
 extern "C" int zn_dac_decode(zn_dac d, const int32_t* codes, int32_t B, int32_t T, float* wav, zn_stream stream) {
   if (!d) return ZN_ERR_ARG;
   if (!codes || !wav || B < 1 || T < 1) DFAIL(d, ZN_ERR_ARG, "zn_dac_decode: bad argument");
@@ -421,6 +459,38 @@ extern "C" int zn_dac_decode(zn_dac d, const int32_t* codes, int32_t B, int32_t 
   }
   float *x = d->buf[0], *y = d->buf[1], *z = d->buf[2];
   hipLaunchKernelGGL(dac_codes_kernel, dim3(T, B), dim3(256), 0, s, codes, d->table, x, c.n_codebooks, T, c.hidden_size, c.codebook_size);
+  if (d->split3) {
+    if (need > d->s3_elems) {
+      DHIP(d, hipStreamSynchronize(s));
+      for (auto& p : d->s3) { if (p) (void)hipFree(p); p = nullptr; }
+      for (auto& p : d->s3) DHIP(d, hipMalloc(&p, need * 3 * sizeof(bf16_t)));
+      d->s3_elems = need;
+    }
+    // x: the fp32 residual stream (a unit's conv2 adds to it in place); p / q: the activated, split input of the next convolution
+    bf16_t *p = d->s3[0], *q = d->s3[1];
+    { const size_t n = (size_t)B * T * c.hidden_size;
+      hipLaunchKernelGGL(dac_split3_kernel, dim3((unsigned)std::min<size_t>((n + 255) / 256, 4096)), dim3(256), 0, s, x, p, n, c.hidden_size); }
+    launch_conv3(d->conv1, p, T, nullptr, nullptr, q, d->blocks[0].convt.alpha, T, B, false, s);     // decoder.conv1 -> block 0's snake1
+    std::swap(p, q);
+    int t = T;
+    for (int bi = 0; bi < c.n_ratios; ++bi) {
+      auto& Bk = d->blocks[bi];
+      const int to = t * c.ratios[bi];
+      launch_conv3(Bk.convt, p, t, nullptr, x, q, Bk.c1[0].alpha, to, B, true, s);                   // conv_t1 -> x, unit 1's snake1
+      std::swap(p, q);
+      t = to;
+      for (int u = 0; u < 3; ++u) {                                                                    // x += conv2(snake2(conv1(snake1(x))))
+        const bool last_unit = u == 2, last_block = bi + 1 == c.n_ratios;
+        const float* an = !last_unit ? Bk.c1[u + 1].alpha : (!last_block ? d->blocks[bi + 1].convt.alpha : nullptr);
+        launch_conv3(Bk.c1[u], p, t, nullptr, nullptr, q, Bk.c2[u].alpha, t, B, false, s);
+        launch_conv3(Bk.c2[u], q, t, x, x, (last_unit && last_block) ? nullptr : p, an, t, B, false, s);
+      }
+    }
+    const size_t lds = (size_t)((DAC_FIN_T + 6) * (d->fin_C + 1) + 7 * d->fin_C) * sizeof(float);
+    hipLaunchKernelGGL(dac_final_kernel, dim3((t + DAC_FIN_T - 1) / DAC_FIN_T, B), dim3(DAC_FIN_T), lds, s, x, d->fin_alpha, d->fin_w, d->fin_b, wav, t, d->fin_C);
+    DHIP(d, hipGetLastError());
+    return ZN_OK;
+  }
   launch_conv(d, d->conv1, x, T, nullptr, y, T, B, false, s);          // decoder.conv1
   std::swap(x, y);
   int t = T;
