@@ -4,6 +4,7 @@ DESIGN.md quote.
     python tools/pmc_summary.py stepkernel <fetch_dir> <write_dir> [out.json] # dominant kernel (tools/pmc_kernel.py 6) -> profiles/pmc_step_kernel.json
     python tools/pmc_summary.py kernel <fetch_dir> <write_dir> [out.json]     # the per-block chain launch (tools/pmc_kernel.py 5) -> profiles/pmc_chain.json
     python tools/pmc_summary.py step <fetch_dir> <write_dir> <decode_steps> [out.json]   # whole decode steps (tools/pmc_step.py)
+    python tools/pmc_summary.py dacmfma <dir> [out.json]   # matrix-core utilisation of the DAC kernels (one pass: --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE)
 
 Counter units are KB; FETCH_SIZE is doubled (gfx950 reports half the bytes of wide coalesced reads, MI355X_MICROARCH.md, HBM).
 The kernel summary records the kernel's name and a hash of the kernel sources it was measured on: bench.py refuses it once
@@ -56,6 +57,28 @@ def kernel_summary(fetch_dir, write_dir, out, which=5):
     print(json.dumps(rec))
 
 
+def dac_mfma_summary(d, out):
+    """SQ_VALU_MFMA_BUSY_CYCLES is summed over the 1024 SIMDs, GRBM_GUI_ACTIVE over the 8 XCDs: utilisation = busy / (gui / 8 * 1024)."""
+    busy, gui, ns = collections.defaultdict(float), collections.defaultdict(float), collections.defaultdict(float)
+    cnt = collections.Counter()
+    for n, v, t0, t1 in read_counter(d, "SQ_VALU_MFMA_BUSY_CYCLES"):
+        if "dac_" in n:
+            busy[n] += v; ns[n] += t1 - t0; cnt[n] += 1
+    for n, v, *_ in read_counter(d, "GRBM_GUI_ACTIVE"):
+        if "dac_" in n:
+            gui[n] += v
+    rec = {"command": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -- python3 tools/dacprof.py 10 1 2   (4 decodes of 10 s)",
+           "interpretation": "SQ_VALU_MFMA_BUSY_CYCLES is summed over the 1024 SIMDs, GRBM_GUI_ACTIVE over the 8 XCDs; MFMA pipe utilisation = busy / (gui / 8 * 1024); "
+                             "the three-term kernels issue 6 bf16 MFMAs (32 cycles each) where the fp32 kernels issued 8 fp32 MFMAs (64 cycles each)",
+           "date": time.strftime("%Y-%m-%d"), "kernels": {}}
+    for n in sorted(busy):
+        if gui[n] > 0 and busy[n] > 0:
+            rec["kernels"][n.split("(")[0]] = {"launches": cnt[n], "total_ms": round(ns[n] / 1e6, 3), "SQ_VALU_MFMA_BUSY_CYCLES": busy[n], "GRBM_GUI_ACTIVE": gui[n],
+                                               "mfma_utilisation": round(busy[n] / (gui[n] / 8 * 1024), 4)}
+    json.dump(rec, open(out, "w"), indent=1)
+    print(json.dumps(rec, indent=1))
+
+
 def step_summary(fetch_dir, write_dir, steps, out):
     fetch, write = collections.defaultdict(list), collections.defaultdict(list)
     for n, v, *_ in read_counter(fetch_dir, "FETCH_SIZE"):
@@ -82,6 +105,9 @@ def step_summary(fetch_dir, write_dir, steps, out):
         print(f"  {v['launches']:6d} x {v['hbm_read_bytes_per_launch'] / 1e6:9.3f} MB read {v['hbm_write_bytes_per_launch'] / 1e6:8.3f} MB written  {n[:100]}")
 
 
+if __name__ == "__main__" and len(sys.argv) > 2 and sys.argv[1] == "dacmfma":
+    dac_mfma_summary(sys.argv[2], sys.argv[3] if len(sys.argv) > 3 else os.path.join(ROOT, "profiles", "r03_pmc_dac_mfma.json"))
+    sys.exit(0)
 if __name__ == "__main__":
     if sys.argv[1] == "kernel":
         kernel_summary(sys.argv[2], sys.argv[3], sys.argv[4] if len(sys.argv) > 4 else os.path.join(ROOT, "profiles", "pmc_chain.json"))

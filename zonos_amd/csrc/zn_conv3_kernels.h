@@ -23,8 +23,13 @@ typedef __attribute__((ext_vector_type(8))) __bf16 c3_bf16x8;
 #define C3_KC 16
 #define C3_TN 64
 #define C3_ROW 96                      // LDS / S3 bytes per (row, 16-channel chunk): 3 terms x 16 bf16
-#define C3_MAXTAPS 7
-#define C3_HALO 54                     // 6 * dilation 9
+#define C3_IMG (128 * 2 * C3_ROW)      // epilogue image: 128 rows x 32 channels
+#ifndef C3_NFAST
+#define C3_NFAST 1                     // 1: output-channel tiles vary fastest in the dispatch order (workgroups of one time tile run together)
+#endif
+#ifndef C3_K1_RB
+#define C3_K1_RB 1                     // row blocks per wave of the 1-tap (pointwise) layers
+#endif
 
 struct Conv3Args {
   const bf16_t* in; int Tin, Cin;          // S3 [B][Tin][Cin/16][3][16]: already activated (or the raw latent)
@@ -48,13 +53,36 @@ ZN_DEVINL void c3_split(float v, bf16_t& h, bf16_t& m, bf16_t& l) {
 }
 ZN_DEVINL int c3_swz(int row, int term, int half) { return row * C3_ROW + term * 32 + ((half ^ ((row >> 3) & 1)) << 4); }
 
-template <int RB>
+// sin(a)^2 for Snake (modeling_dac.py:98) in 13 instructions: a = k pi + r (pi in two fp32 terms, fused), sin(r) = r g(r^2) on
+// [-pi/2, pi/2] (degree-5 fit in r^2); the sign of sin drops out of the square.  Against sin^2 in fp64 over |a| <= 50: max error
+// 2.9e-7, rms 4.7e-8 (sinf of the device library squared: 1.3e-7, 2.9e-8).  |a| > 2^16 (never seen; the reduction would lose bits)
+// takes the library's sinf.
+ZN_DEVINL float c3_sin2(float a) {
+  if (!(fabsf(a) <= 65536.0f)) { const float s = sinf(a); return s * s; }
+  const float k = rintf(a * 0.318309886183790672f);
+  float r = fmaf(k, -3.1415927410125732f, a);
+  r = fmaf(k, 8.742277657347586e-08f, r);
+  const float u = r * r;
+  float g = -2.3866771670e-08f;
+  g = fmaf(g, u, 2.7524013149e-06f);
+  g = fmaf(g, u, -1.9840836467e-04f);
+  g = fmaf(g, u, 8.3333309740e-03f);
+  g = fmaf(g, u, -1.6666667163e-01f);
+  g = fmaf(g, u, 1.0f);
+  const float sn = r * g;
+  return sn * sn;
+}
+
+// RB: 32-row blocks per wave (workgroup = RB * 128 output times); MAXT: taps the launch may have (7: the dilated 7-tap layers, halo
+// of up to 54 rows; 2: the two taps of a transposed convolution's phase; 1: the pointwise layers - small staging, several workgroups
+// per CU hide one another's per-stage latency).
+template <int RB, int MAXT>
 __global__ __launch_bounds__(256, 2) void dac_conv3_kernel(Conv3Args a) {
-  constexpr int TM = RB * 128, NT = C3_TN / 32, MAXROWS = TM + C3_HALO;
+  constexpr int TM = RB * 128, NT = C3_TN / 32, HALO = MAXT == 7 ? 54 : (MAXT == 2 ? 1 : 0), MAXROWS = TM + HALO;
   extern __shared__ __attribute__((aligned(16))) unsigned char c3_smem[];
   unsigned char* s_in = c3_smem;                            // [MAXROWS][96]
   unsigned char* s_w = c3_smem + MAXROWS * C3_ROW;          // [taps][64][96]
-  const int m0 = blockIdx.x * TM, n0 = blockIdx.y * C3_TN;
+  const int m0 = (C3_NFAST ? blockIdx.y : blockIdx.x) * TM, n0 = (C3_NFAST ? blockIdx.x : blockIdx.y) * C3_TN;
   const int b = blockIdx.z / a.phases, phase = blockIdx.z % a.phases;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int offlast = a.off0 + (a.taps - 1) * a.offstep;
@@ -74,7 +102,7 @@ __global__ __launch_bounds__(256, 2) void dac_conv3_kernel(Conv3Args a) {
   // staging slots (16-byte pieces: 6 per row): the next stage's requests go out before this stage's MFMAs and land in LDS after them.
   // Buffer loads: one 32-bit offset per piece (rows outside [0, Tin) fall outside the batch element's range and read as zeros: the
   // convolution's zero padding), the K stage advances through the scalar offset.
-  constexpr int IN_P = (MAXROWS * 6 + 255) / 256, W_P = (C3_MAXTAPS * C3_TN * 6 + 255) / 256;
+  constexpr int IN_P = (MAXROWS * 6 + 255) / 256, W_P = (MAXT * C3_TN * 6 + 255) / 256;
   u32x4 rin[IN_P], rw[W_P];
   int vin[IN_P], vw[W_P];
   const int n_in = nrows * 6, n_w = a.taps * C3_TN * 6;
@@ -113,7 +141,8 @@ __global__ __launch_bounds__(256, 2) void dac_conv3_kernel(Conv3Args a) {
     }
     __syncthreads();
     if (ck + 1 < nck) fetch(ck + 1);
-    for (int tap = 0; tap < a.taps; ++tap) {
+#pragma unroll 1
+    for (int tap = 0; tap < (MAXT == 1 ? 1 : a.taps); ++tap) {
       const int r0 = wave * (32 * RB) + fr + a.off0 + tap * a.offstep - offmin;
       c3_bf16x8 A[RB][3], Bf[NT][3];
 #pragma unroll
@@ -137,49 +166,54 @@ __global__ __launch_bounds__(256, 2) void dac_conv3_kernel(Conv3Args a) {
     }
   }
   // ---- epilogue.  C layout: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).  bias, residual, fp32 store from the
-  // registers; the S3 image of 128 rows x 64 channels (next Snake applied, split) goes through LDS so that it leaves in
-  // 16-byte pieces, 384 contiguous bytes per row.
-  unsigned char* s_o = c3_smem;                              // [128][4 chunks][96]
+  // registers; the S3 image of 128 rows x 32 channels (next Snake applied, split) goes through LDS so that it leaves in
+  // 16-byte pieces, 192 contiguous bytes per row.
+  unsigned char* s_o = c3_smem;                              // [128][2 chunks][96]
   const int nchunk_out = a.Cout / C3_KC;
 #pragma unroll
   for (int rb = 0; rb < RB; ++rb) {
-    __syncthreads();
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
-      const int cl = nt * 32 + fr, co = n0 + cl;
+      __syncthreads();                                       // the fragment reads / the previous image's copy are done
+      const int co = n0 + nt * 32 + fr;
       const bool c_ok = co < a.Cout;
       const float bv = (a.bias && c_ok) ? a.bias[co] : 0.f;
-      const float al = (a.alpha && c_ok) ? a.alpha[co] : 0.f;
+      const float al = (a.alpha && c_ok) ? a.alpha[co] : 1.f;
+      const float ial = 1.0f / (al + 1e-9f);
+      float v[16];
 #pragma unroll
       for (int reg = 0; reg < 16; ++reg) {
         const int rowi = (reg & 3) + 8 * (reg >> 2) + 4 * fh;
         const int m = m0 + wave * (32 * RB) + rb * 32 + rowi;
         const int to = m * a.ostride + a.ooff + phase;
-        float v = acc[rb][nt][reg] + bv;
+        v[reg] = acc[rb][nt][reg] + bv;
         if (c_ok && m < a.M && to >= 0 && to < a.Tout) {
           const size_t o = ((size_t)b * a.Tout + to) * a.Cout + co;
-          if (a.skip) v = a.skip[o] + v;
-          if (a.out32) a.out32[o] = v;
-        }
-        if (a.out3) {
-          if (a.alpha) v = snake_f(v, al);
-          bf16_t h, mm, l;
-          c3_split(v, h, mm, l);
-          bf16_t* d = (bf16_t*)(s_o + (wave * 32 + rowi) * (4 * C3_ROW) + (cl >> 4) * C3_ROW) + (cl & 15);
-          d[0] = h; d[16] = mm; d[32] = l;
+          if (a.skip) v[reg] = a.skip[o] + v[reg];
+          if (a.out32) a.out32[o] = v[reg];
         }
       }
-    }
-    if (!a.out3) continue;
-    __syncthreads();
+      if (!a.out3) continue;
 #pragma unroll
-    for (int j = 0; j < 12; ++j) {
-      const int piece = tid + j * 256, irow = piece / 24, q = piece - irow * 24;     // 128 rows x 24 pieces
-      const int m = m0 + (irow >> 5) * (32 * RB) + rb * 32 + (irow & 31);
-      const int to = m * a.ostride + a.ooff + phase;
-      const int chunk = (n0 >> 4) + q / 6;
-      if (m < a.M && to >= 0 && to < a.Tout && chunk < nchunk_out)
-        *(u32x4*)(a.out3 + (((size_t)b * a.Tout + to) * nchunk_out + chunk) * 48 + (q % 6) * 8) = *(const u32x4*)(s_o + irow * (4 * C3_ROW) + q * 16);
+      for (int reg = 0; reg < 16; ++reg) {
+        const int rowi = (reg & 3) + 8 * (reg >> 2) + 4 * fh;
+        float x = v[reg];
+        if (a.alpha) x = x + ial * c3_sin2(al * x);
+        bf16_t h, mm, l;
+        c3_split(x, h, mm, l);
+        bf16_t* d = (bf16_t*)(s_o + (wave * 32 + rowi) * (2 * C3_ROW) + (fr >> 4) * C3_ROW) + (fr & 15);
+        d[0] = h; d[16] = mm; d[32] = l;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
+        const int piece = tid + j * 256, irow = piece / 12, q = piece - irow * 12;     // 128 rows x 12 pieces
+        const int m = m0 + (irow >> 5) * (32 * RB) + rb * 32 + (irow & 31);
+        const int to = m * a.ostride + a.ooff + phase;
+        const int chunk = (n0 >> 4) + nt * 2 + q / 6;
+        if (m < a.M && to >= 0 && to < a.Tout && chunk < nchunk_out)
+          *(u32x4*)(a.out3 + (((size_t)b * a.Tout + to) * nchunk_out + chunk) * 48 + (q % 6) * 8) = *(const u32x4*)(s_o + irow * (2 * C3_ROW) + q * 16);
+      }
     }
   }
 }
@@ -217,22 +251,30 @@ __global__ void dac_w3convt_kernel(const float* w, bf16_t* o, int Cin, int Cout,
   }
 }
 
-static inline size_t zn_conv3_lds(int rb) { return (size_t)(rb * 128 + C3_HALO) * C3_ROW + (size_t)C3_MAXTAPS * C3_TN * C3_ROW; }
+template <int RB, int MAXT> static inline size_t zn_conv3_lds() {
+  const size_t stage = (size_t)(RB * 128 + (MAXT == 7 ? 54 : (MAXT == 2 ? 1 : 0))) * C3_ROW + (size_t)MAXT * C3_TN * C3_ROW;
+  return stage > C3_IMG ? stage : C3_IMG;
+}
+template <int RB, int MAXT> static inline hipError_t zn_conv3_attr() {
+  return hipFuncSetAttribute((const void*)dac_conv3_kernel<RB, MAXT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)zn_conv3_lds<RB, MAXT>());
+}
 static inline hipError_t zn_conv3_set_attrs() {
-  hipError_t e = hipFuncSetAttribute((const void*)dac_conv3_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)zn_conv3_lds(1));
-  if (e != hipSuccess) return e;
-  return hipFuncSetAttribute((const void*)dac_conv3_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)zn_conv3_lds(2));
+  hipError_t e;
+  if ((e = zn_conv3_attr<1, 7>()) != hipSuccess || (e = zn_conv3_attr<2, 7>()) != hipSuccess || (e = zn_conv3_attr<1, 2>()) != hipSuccess ||
+      (e = zn_conv3_attr<2, 2>()) != hipSuccess || (e = zn_conv3_attr<C3_K1_RB, 1>()) != hipSuccess) return e;
+  return hipSuccess;
 }
 static inline int zn_conv3_pad(int c) { return (c + C3_TN - 1) / C3_TN * C3_TN; }
+template <int RB, int MAXT> static inline void zn_conv3_go(const Conv3Args& a, int B, hipStream_t s) {
+  const int ntile = a.CoutPad / C3_TN, mt = (a.M + RB * 128 - 1) / (RB * 128);
+  const dim3 grid = C3_NFAST ? dim3(ntile, mt, B * a.phases) : dim3(mt, ntile, B * a.phases);
+  const size_t lds = zn_conv3_lds<RB, MAXT>();
+  hipLaunchKernelGGL((dac_conv3_kernel<RB, MAXT>), grid, dim3(256), lds, s, a);
+}
 // 256-row tiles once they fill the chip's 512 workgroup slots, 128-row tiles for the short early layers
 static inline void zn_conv3_launch(const Conv3Args& a, int B, hipStream_t s) {
-  const int ntile = a.CoutPad / C3_TN;
-  const long wg2 = (long)((a.M + 255) / 256) * ntile * B * a.phases;
-  if (wg2 >= 512) {
-    dim3 grid((a.M + 255) / 256, ntile, B * a.phases);
-    hipLaunchKernelGGL((dac_conv3_kernel<2>), grid, dim3(256), zn_conv3_lds(2), s, a);
-  } else {
-    dim3 grid((a.M + 127) / 128, ntile, B * a.phases);
-    hipLaunchKernelGGL((dac_conv3_kernel<1>), grid, dim3(256), zn_conv3_lds(1), s, a);
-  }
+  if (a.taps == 1) return zn_conv3_go<C3_K1_RB, 1>(a, B, s);
+  const bool big = (long)((a.M + 255) / 256) * (a.CoutPad / C3_TN) * B * a.phases >= 512;
+  if (a.taps == 2) { if (big) zn_conv3_go<2, 2>(a, B, s); else zn_conv3_go<1, 2>(a, B, s); return; }
+  if (big) zn_conv3_go<2, 7>(a, B, s); else zn_conv3_go<1, 7>(a, B, s);
 }

@@ -68,30 +68,55 @@ __global__ void dac_wconvt_kernel(const float* w, float* o, int Cin, int Cout, i
     o[i] = co < Cout ? w[((size_t)ci * Cout + co) * (2 * s) + p + j * s] : 0.f;
   }
 }
-// last layer: Snake -> Conv1d(C -> 1, k = 7, pad 3) -> tanh  (modeling_dac.py:438-441)
+// last layer: Snake -> Conv1d(C -> 1, k = 7, pad 3) -> tanh  (modeling_dac.py:438-441) on the VALU.  128 output times per workgroup; the
+// 134 input rows are requested in one batch of 16-byte loads, activated on the way into LDS (row stride C + 1: conflict-free column
+// walks); two threads per output time take the even and the odd channels (7 x C/2 fused multiply-adds each, in tap-then-channel order)
+// and meet through one DPP add.
 #define DAC_FIN_T 128
-__global__ __launch_bounds__(DAC_FIN_T) void dac_final_kernel(const float* in, const float* alpha, const float* w /*[1][C][7]*/, const float* bias,
-                                                             float* out, int T, int C) {
+#define DAC_FIN_MAXP 16
+__global__ __launch_bounds__(256) void dac_final_kernel(const float* in, const float* alpha, const float* w /*[1][C][7]*/, const float* bias,
+                                                        float* out, int T, int C) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* s_x = smem;                         // [DAC_FIN_T + 6][C + 1]
   float* s_w = smem + (DAC_FIN_T + 6) * (C + 1);   // [7][C]
-  const int t0 = blockIdx.x * DAC_FIN_T, b = blockIdx.y;
+  const int t0 = blockIdx.x * DAC_FIN_T, b = blockIdx.y, tid = threadIdx.x;
   const float* inb = in + (size_t)b * T * C;
-  for (int i = threadIdx.x; i < (DAC_FIN_T + 6) * C; i += DAC_FIN_T) {
-    const int row = i / C, c = i % C, t = t0 - 3 + row;
-    s_x[row * (C + 1) + c] = (t >= 0 && t < T) ? snake_f(inb[(size_t)t * C + c], alpha[c]) : 0.f;
+  const int c4n = C / 4, npiece = (DAC_FIN_T + 6) * c4n;
+  f32x4 r[DAC_FIN_MAXP];
+#pragma unroll
+  for (int j = 0; j < DAC_FIN_MAXP; ++j) {
+    const int i = tid + j * 256, row = i / c4n, c4 = i - row * c4n;
+    int t = t0 - 3 + row;
+    t = t < 0 ? 0 : (t >= T ? T - 1 : t);
+    if (i < npiece) r[j] = *(const f32x4*)(inb + (size_t)t * C + c4 * 4);
   }
-  for (int i = threadIdx.x; i < 7 * C; i += DAC_FIN_T) { const int k = i / C, c = i % C; s_w[i] = w[(size_t)c * 7 + k]; }
+  for (int i = tid; i < 7 * C; i += 256) { const int k = i / C, c = i - k * C; s_w[i] = w[(size_t)c * 7 + k]; }
+  float* s_al = s_w + 7 * C;                 // [C] alpha, [C] 1 / (alpha + 1e-9)
+  for (int c = tid; c < C; c += 256) { const float al = alpha[c]; s_al[c] = al; s_al[C + c] = 1.0f / (al + 1e-9f); }
   __syncthreads();
-  const int t = t0 + threadIdx.x;
-  if (t >= T) return;
+#pragma unroll
+  for (int j = 0; j < DAC_FIN_MAXP; ++j) {
+    const int i = tid + j * 256, row = i / c4n, c4 = i - row * c4n;
+    if (i < npiece) {
+      const int t = t0 - 3 + row;
+      const float* al = s_al + c4 * 4;       // (the LDS offsets of s_w / s_al are not 16-byte aligned: scalar reads)
+      const float x[4] = {r[j].x, r[j].y, r[j].z, r[j].w};
+      float* d = s_x + row * (C + 1) + c4 * 4;
+#pragma unroll
+      for (int e = 0; e < 4; ++e)            // Snake (modeling_dac.py:98) with the decoder kernels' sin^2 (zn_conv3_kernels.h); zero padding outside [0, T)
+        d[e] = (t >= 0 && t < T) ? x[e] + al[C + e] * c3_sin2(al[e] * x[e]) : 0.f;
+    }
+  }
+  __syncthreads();
+  const int tl = tid >> 1, hf = tid & 1, t = t0 + tl;
   float acc = 0.f;
   for (int k = 0; k < 7; ++k) {
-    const float* xr = s_x + (threadIdx.x + k) * (C + 1);
-    const float* wr = s_w + k * C;
-    for (int c = 0; c < C; ++c) acc = fmaf(xr[c], wr[c], acc);
+    const float* xr = s_x + (tl + k) * (C + 1) + hf;
+    const float* wr = s_w + k * C + hf;
+    for (int c = 0; c < C; c += 2) acc = fmaf(xr[c], wr[c], acc);
   }
-  out[(size_t)b * T + t] = tanhf(acc + bias[0]);
+  acc += dpp_mov<ZN_DPP_XOR1>(acc);
+  if (hf == 0 && t < T) out[(size_t)b * T + t] = tanhf(acc + bias[0]);
 }
 
 // ------------------------------------------------------------------------------------------------ encoder pieces
@@ -344,6 +369,7 @@ extern "C" int zn_dac_create(const zn_dac_config* cfg, const zn_dac_tensor* tens
   auto fa = t.find("decoder.snake1.alpha"), fw = t.find("decoder.conv2.weight"), fb = t.find("decoder.conv2.bias");
   if (fa == t.end() || fw == t.end() || fb == t.end() || fw->second->numel != (int64_t)c * 7) { d->err = "missing/mis-shaped final conv tensors"; return fail(ZN_ERR_ARG); }
   d->fin_alpha = fa->second->data_dev; d->fin_w = fw->second->data_dev; d->fin_b = fb->second->data_dev; d->fin_C = c;
+  if (c % 4 || (DAC_FIN_T + 6) * (c / 4) > DAC_FIN_MAXP * 256) { d->err = "final conv: channel count " + std::to_string(c) + " not supported (multiple of 4, <= 120)"; return fail(ZN_ERR_UNSUPPORTED); }
   // ---- encoder + residual VQ (DacEncoder, modeling_dac.py:444-473; DacResidualVectorQuantizer :283-345)
   if (t.count("encoder.conv1.weight") && t.count("quantizer.quantizers.0.in_proj.weight") && cfg->encoder_hidden_size > 0) {
     const int eh = cfg->encoder_hidden_size;
@@ -486,8 +512,8 @@ extern "C" int zn_dac_decode(zn_dac d, const int32_t* codes, int32_t B, int32_t 
         launch_conv3(Bk.c2[u], q, t, x, x, (last_unit && last_block) ? nullptr : p, an, t, B, false, s);
       }
     }
-    const size_t lds = (size_t)((DAC_FIN_T + 6) * (d->fin_C + 1) + 7 * d->fin_C) * sizeof(float);
-    hipLaunchKernelGGL(dac_final_kernel, dim3((t + DAC_FIN_T - 1) / DAC_FIN_T, B), dim3(DAC_FIN_T), lds, s, x, d->fin_alpha, d->fin_w, d->fin_b, wav, t, d->fin_C);
+    const size_t lds = (size_t)((DAC_FIN_T + 6) * (d->fin_C + 1) + 9 * d->fin_C) * sizeof(float);
+    hipLaunchKernelGGL(dac_final_kernel, dim3((t + DAC_FIN_T - 1) / DAC_FIN_T, B), dim3(256), lds, s, x, d->fin_alpha, d->fin_w, d->fin_b, wav, t, d->fin_C);
     DHIP(d, hipGetLastError());
     return ZN_OK;
   }
@@ -506,8 +532,8 @@ extern "C" int zn_dac_decode(zn_dac d, const int32_t* codes, int32_t B, int32_t 
       std::swap(x, z);
     }
   }
-  const size_t lds = (size_t)((DAC_FIN_T + 6) * (d->fin_C + 1) + 7 * d->fin_C) * sizeof(float);
-  hipLaunchKernelGGL(dac_final_kernel, dim3((t + DAC_FIN_T - 1) / DAC_FIN_T, B), dim3(DAC_FIN_T), lds, s, x, d->fin_alpha, d->fin_w, d->fin_b, wav, t, d->fin_C);
+  const size_t lds = (size_t)((DAC_FIN_T + 6) * (d->fin_C + 1) + 9 * d->fin_C) * sizeof(float);
+  hipLaunchKernelGGL(dac_final_kernel, dim3((t + DAC_FIN_T - 1) / DAC_FIN_T, B), dim3(256), lds, s, x, d->fin_alpha, d->fin_w, d->fin_b, wav, t, d->fin_C);
   DHIP(d, hipGetLastError());
   return ZN_OK;
 }
