@@ -251,3 +251,35 @@ def test_two_concurrent_requests_on_one_model():
         n = min(outs[i].shape[-1], solo[i].shape[-1])
         assert n >= 100 and torch.equal(outs[i][..., :8], solo[i][..., :8])    # d 512: chain and launches paths cut fc2's K differently
         assert (outs[i][..., :n] == solo[i][..., :n]).float().mean() > 0.9
+
+
+def test_single_workgroup_sampler_matches_the_ticketed_sampler():
+    """Batch 1: sample1_kernel (one workgroup: a wave per codebook, bookkeeping and the next embedding behind a barrier) against
+    sample_kernel + its ticketed tail (zn_debug_tune(16, 2)): same codes and same logits over greedy decoding, temperature + min_p
+    sampling with a repetition window, and a run that ends through the EOS bookkeeping (forced EOS: masks, remaining counters)."""
+    cfg, seed = synth.FULL_CFG, 1234
+    model, _ = build_model(cfg, seed, "cuda:0")
+    eng = model.engine(1)
+    cond = synth.conditioning(seed, "cond", 2, 24, cfg["d_model"]).to("cuda:0")
+    cases = [({"temperature": 0.0}, None), ({"temperature": 1.0, "min_p": 0.1}, None),
+             ({"temperature": 0.7, "min_p": 0.0, "repetition_penalty": 2.0, "repetition_penalty_window": 5}, None), ({"temperature": 0.0}, 21)]
+    try:
+        for sp, force in cases:
+            outs = []
+            for t16 in (2, 1):
+                eng.call("zn_debug_tune", 16, t16)
+                eng.call("zn_debug_eos_bias", float("-inf") if force is None else 0.0)
+                eng.call("zn_debug_force_eos", -1 if force is None else force)
+                tr = {"logits": []}
+                o = model.generate(cond, max_new_tokens=64, sampling_params=sp, seed=77, _trace=tr)
+                outs.append((o.cpu(), torch.stack(tr["logits"]).cpu()))
+                o2 = model.generate(cond, max_new_tokens=64, sampling_params=sp, seed=77)       # 8-step graphs
+                assert torch.equal(o2.cpu(), outs[-1][0]), (sp, t16)
+            assert torch.equal(outs[0][0], outs[1][0]), sp
+            assert torch.equal(outs[0][1].view(torch.int32), outs[1][1].view(torch.int32)), sp
+            if force is not None:
+                assert outs[0][0].shape[-1] < 64, "the forced EOS did not end the generation"
+    finally:
+        eng.call("zn_debug_tune", 16, 1)
+        eng.call("zn_debug_force_eos", -1)
+        eng.call("zn_debug_eos_bias", 0.0)

@@ -88,7 +88,7 @@ struct zn_handle_s {
   int *lengths = nullptr, *codes = nullptr;
   int force_eos_step = -1;
   float eos_bias = 0.f;
-  int tune[16] = {256, 512, 512, 1024, 512, 704, 2, 2, 0, 0, 0, 0, 0, 0, 0, 0};   // target workgroups: in_proj, out_proj, fc1, fc2, heads; [5] longest context of the fused attention launch; [6] > 1: multi-step graphs; [7] > 1: LDS-staged small-M projections; [8] = 2: no persistent chain kernel (five launches per block instead); [9]: KV capacity above which the P.V pass splits per block (0 = 1408); [10] = 2: VALU prefill attention; [11] = 2: no in-workgroup-split small-M kernel
+  int tune[20] = {256, 512, 512, 1024, 512, 704, 2, 2, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // target workgroups: in_proj, out_proj, fc1, fc2, heads; [5] longest context of the fused attention launch; [6] > 1: multi-step graphs; [7] > 1: LDS-staged small-M projections; [8] = 2: no persistent chain kernel (five launches per block instead); [9]: KV capacity above which the P.V pass splits per block (0 = 1408); [10] = 2: VALU prefill attention; [11] = 2: no in-workgroup-split small-M kernel
   const int* tok_override = nullptr;
   int tok_override_calls = 0;
   hipStream_t cap_stream = nullptr;
@@ -949,6 +949,10 @@ static int enqueue_step(zn_handle h, hipStream_t s) {
   f.mask_id = c.mask_id; f.tokens = h->tok_raw; f.remaining = h->remaining; f.stopping = h->stopping; f.lengths = h->lengths;
   f.rows = h->rows; f.first = 0; f.override = h->tok_override; f.override_calls = h->tok_override_calls;
   if (fused) { a.ticket = h->tail_ticket; a.em = make_embed_args(h); }
+  // batch 1: sampling, bookkeeping and the next embedding in one workgroup (sample1_kernel; tune[16] = 2 keeps the ticketed kernel)
+  const bool one_wg = fused && h->batch == 1 && h->tune[16] != 2 && c.vocab_head <= 64 * ZN_S1_IT && c.n_codebooks <= 16 && !(h->sp.top_p > 0.f) &&
+                      h->sp.top_k <= 0 && !(h->sp.linear > 0.f) && (!a.use_penalty || h->sp.repetition_penalty_window <= 16) && h->rows <= 1024;
+  if (one_wg) { hipLaunchKernelGGL(sample1_kernel, dim3(1), dim3(1024), 0, s, a); return ZN_OK; }
   hipLaunchKernelGGL(sample_kernel, dim3(c.n_codebooks, h->batch), dim3(256), 0, s, a);
   if (!fused) hipLaunchKernelGGL(frame_update_kernel, dim3(1), dim3(256), 0, s, f);
   return ZN_OK;
@@ -1436,7 +1440,7 @@ extern "C" int zn_debug_token_override(zn_handle h, const int32_t* tokens_dev, i
   return ZN_OK;
 }
 extern "C" int zn_debug_tune(zn_handle h, int32_t key, int32_t value) {
-  if (!h || key < 0 || key >= 16 || value < 1) return ZN_ERR_ARG;
+  if (!h || key < 0 || key >= 20 || value < 1) return ZN_ERR_ARG;
   h->tune[key] = value; free_graph(h); h->emb_valid = false;
   return ZN_OK;
 }

@@ -1793,4 +1793,183 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
   }
 }
 
+// Batch 1, loop steps: the whole tail of a decode step in ONE workgroup - one wave per codebook samples from registers (17 logits per
+// lane), then the bookkeeping and the next step's embedding follow behind a barrier instead of behind sample_kernel's token store,
+// arrival ticket and re-read (three memory round trips on the step's launch-bound tail), and the bookkeeping's inputs are requested
+// together with the penalty window.  Arithmetic and tie rules are sample_kernel's: its block reductions (per-thread partial in
+// element order, wave_sum per wave, waves added in order) are reproduced with the four "virtual waves" j mod 4 of the 64-lane slots, so
+// both kernels return the same token and the same probabilities.  Not here (zn_api.hip keeps sample_kernel for them): top-p / top-k
+// (sorting), the unified sampler, penalty windows > 16, vocabularies > 1088, batches.
+#define ZN_S1_IT 17
+template <typename F> ZN_DEVINL float s1_sum(const float (&x)[ZN_S1_IT], int lane, int V, F keep) {
+  float part[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int j = 0; j < ZN_S1_IT; ++j) if (lane + 64 * j < V) part[j & 3] += keep(x[j]);
+  float t = 0.f;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) t += wave_sum(part[w]);
+  return t;
+}
+ZN_DEVINL void s1_argmax(float& v, int& i) {          // first-max-wins over the wave; every lane gets the result
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(v, o);
+    const int oi = __shfl_xor(i, o);
+    if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
+  }
+}
+__global__ __launch_bounds__(1024) void sample1_kernel(SampleArgs a) {
+  const int tid = threadIdx.x, lane = tid & 63, cb = tid >> 6;
+  const int V = a.V, nq = a.n_q;
+  __shared__ int s_tok[ZN_FRAME_MAXQ];
+  __shared__ int s_code[ZN_FRAME_MAXQ];
+  const FrameArgs& fr = a.fr;
+  const int o = a.st->offset, stp = a.st->step;
+  const float st_bias = a.st->eos_bias;
+  const bool st_force = a.st->force_eos_step == stp;
+  // ---- requests: this wave's logits; the penalty window; the bookkeeping's cell, counters and override token (lanes 0..15 of wave 0)
+  float cc[ZN_S1_IT], uu[ZN_S1_IT];
+  const bool on = cb < nq;
+  const int cbq = on ? cb : nq - 1;
+  const float* rc = a.raw + (size_t)cbq * V;
+  const float* ru = a.raw + (size_t)((a.mix ? 1 : 0) * nq + cbq) * V;
+#pragma unroll
+  for (int j = 0; j < ZN_S1_IT; ++j) {
+    const int i = min(lane + 64 * j, V - 1);
+    cc[j] = rc[i];
+    uu[j] = ru[i];
+  }
+  constexpr int HW = 16;
+  int nw = 0, hist_tok = -1;
+  if (a.use_penalty && a.codes) {
+    const int avail = o + 1 < a.ctx ? o + 1 : a.ctx;   // columns [max(0,o+1-ctx), o]
+    nw = avail < a.pen_window ? avail : a.pen_window;
+    if (lane < nw) hist_tok = a.codes[(size_t)cbq * a.t_total + (o + 1 - nw) + lane];
+  }
+  const int fcb = tid & (ZN_FRAME_MAXQ - 1), fcbc = min(fcb, nq - 1);
+  const int col = o + 1;
+  const bool in_range = fcb < nq && col < fr.t_total;
+  int* cell = fr.codes + (size_t)fcbc * fr.t_total + min(col, fr.t_total - 1);
+  const int call = stp + 1;
+  const bool ovr = fr.override && call < fr.override_calls;
+  int cur = 0, rem = 0, stop = 0, otok = 0, otok0 = 0;
+  if (tid < ZN_FRAME_MAXQ) {
+    cur = *cell; rem = fr.remaining[0]; stop = fr.stopping[0];
+    if (ovr) { otok = fr.override[(size_t)call * nq + fcbc]; otok0 = fr.override[(size_t)call * nq]; }
+  }
+  int tok = 0;
+  if (on) {
+    // ---- logits: CFG mix (model.py:231-232), logit bias (model.py:433-437,476)
+    float l[ZN_S1_IT];
+#pragma unroll
+    for (int j = 0; j < ZN_S1_IT; ++j) {
+      const int i = lane + 64 * j;
+      float x = a.mix ? __fadd_rn(uu[j], __fmul_rn(__fsub_rn(cc[j], uu[j]), a.cfg_scale)) : cc[j];
+      if (a.apply_bias && i == a.eos_id) {
+        if (cb == 0) {
+          x = __fadd_rn(x, -0.6931471824645996f);
+          x += st_bias;
+          if (st_force) x = 1.0e4f;
+        } else x = -INFINITY;
+      }
+      if (a.logits_out && i < V) a.logits_out[(size_t)cb * V + i] = x;
+      l[j] = x;
+    }
+    // ---- repetition penalty (sampling.py:159-163): factor = penalty^(#occurrences in the window), once per distinct token
+    for (int w = 0; w < nw; ++w) {
+      int g = __shfl(hist_tok, w);
+      if (g < 0) continue;
+      g = g > V - 1 ? V - 1 : g;
+      bool seen = false;
+      float f = 1.f;
+      for (int w2 = 0; w2 < nw; ++w2) {
+        int g2 = __shfl(hist_tok, w2);
+        g2 = g2 > V - 1 ? V - 1 : g2;
+        if (g2 == g) { if (w2 < w) seen = true; else f = __fmul_rn(f, a.penalty); }
+      }
+      if (seen) continue;
+#pragma unroll
+      for (int j = 0; j < ZN_S1_IT; ++j)
+        if (lane + 64 * j == g) l[j] = (l[j] <= 0.f) ? __fmul_rn(l[j], f) : __fdiv_rn(l[j], f);
+    }
+    if (!(a.temperature > 0.f)) {
+      float bv = -INFINITY; int bi = 0x7fffffff;
+#pragma unroll
+      for (int j = 0; j < ZN_S1_IT; ++j) { const int i = lane + 64 * j; if (i < V && l[j] > bv) { bv = l[j]; bi = i; } }
+      s1_argmax(bv, bi);
+      tok = bi == 0x7fffffff ? 0 : bi;
+    } else {
+      // ---- softmax(logits / T) (sampling.py:217), min_p (sampling.py:123-127), Gumbel-max (sampling.py:28-30)
+      float mx = -INFINITY;
+#pragma unroll
+      for (int j = 0; j < ZN_S1_IT; ++j) { l[j] = l[j] / a.temperature; if (lane + 64 * j < V) mx = fmaxf(mx, l[j]); }
+      mx = wave_max(mx);
+#pragma unroll
+      for (int j = 0; j < ZN_S1_IT; ++j) l[j] = expf(l[j] - mx);
+      const float ssum = s1_sum(l, lane, V, [](float e) { return e; });
+#pragma unroll
+      for (int j = 0; j < ZN_S1_IT; ++j) l[j] = l[j] / ssum;
+      if (a.min_p > 0.f) {
+        float m3 = 0.f;
+#pragma unroll
+        for (int j = 0; j < ZN_S1_IT; ++j) if (lane + 64 * j < V) m3 = fmaxf(m3, l[j]);
+        m3 = wave_max(m3);
+        const float thr = a.min_p * m3;
+#pragma unroll
+        for (int j = 0; j < ZN_S1_IT; ++j) if (l[j] < thr) l[j] = 0.f;
+        const float s5 = s1_sum(l, lane, V, [](float e) { return e; });
+#pragma unroll
+        for (int j = 0; j < ZN_S1_IT; ++j) l[j] = l[j] / s5;
+      }
+      if (a.probs_out) {
+#pragma unroll
+        for (int j = 0; j < ZN_S1_IT; ++j) { const int i = lane + 64 * j; if (i < V) a.probs_out[(size_t)cb * V + i] = l[j]; }
+      }
+      const unsigned long long h0 = zn_mix64(a.seed ^ zn_mix64(a.draw + (unsigned long long)stp));
+      float bv = -1.f; int bi = 0x7fffffff;
+#pragma unroll
+      for (int j = 0; j < ZN_S1_IT; ++j) {
+        const int i = lane + 64 * j;
+        if (i < V) {
+          const unsigned long long h = zn_mix64(h0 + 0x9E3779B97F4A7C15ull * (unsigned long long)((size_t)cb * V + i + 1));
+          const float u01 = ((float)(h >> 40) + 0.5f) * (1.0f / 16777216.0f);
+          const float v = l[j] / (-logf(u01));
+          if (v > bv || (v == bv && i < bi)) { bv = v; bi = i; }
+        }
+      }
+      s1_argmax(bv, bi);
+      tok = bi == 0x7fffffff ? 0 : bi;
+    }
+    if (lane == 0) { s_tok[cb] = tok; a.tokens[cb] = tok; }
+  }
+  __syncthreads();
+  // ---- bookkeeping of the step (frame_update_body; model.py:483-497 + tensor_ops.py:155-211) for the one utterance
+  if (tid < ZN_FRAME_MAXQ) {
+    const int tk = ovr ? otok : s_tok[fcbc], tk0 = ovr ? otok0 : s_tok[0];
+    if (tk0 == fr.eos_id) { rem = rem < nq ? rem : nq; stop = 1; }
+    int eos_idx = nq - rem; if (eos_idx > nq - 1) eos_idx = nq - 1;
+    int t = tk;
+    if (stop && fcb < eos_idx) t = fr.mask_id; else if (stop && fcb == eos_idx) t = fr.eos_id;
+    if (in_range && cur == -1) *cell = t;
+    s_code[fcb] = (in_range && cur == -1) ? t : cur;
+    rem -= 1;
+    if (fcb == 0) {
+      fr.remaining[0] = rem; fr.stopping[0] = stop;
+      a.st->offset = o + 1; a.st->step = stp + 1; a.st->all_done = rem > 0 ? 0 : 1;
+    }
+  }
+  if (tid < fr.rows) fr.lengths[tid] += 1;                  // tensor_ops.py:85-86
+  __syncthreads();
+  // ---- the next step's embedding
+  if (tid < 256) {
+    int code[ZN_EMBED_MAXQ];
+#pragma unroll
+    for (int i = 0; i < ZN_EMBED_MAXQ; ++i) {
+      const int c = s_code[min(i, a.em.n_q - 1)];
+      code[i] = c < 0 ? 0 : (c >= a.em.vocab_embed ? a.em.vocab_embed - 1 : c);
+    }
+    embed_row(a.em, 0, code);
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ bookkeeping
