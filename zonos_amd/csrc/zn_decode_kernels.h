@@ -1839,8 +1839,7 @@ __global__ __launch_bounds__(1024) void sample1_kernel(SampleArgs a) {
     cc[j] = rc[i];
     uu[j] = ru[i];
   }
-  constexpr int HW = 16;
-  int nw = 0, hist_tok = -1;
+  int nw = 0, hist_tok = -1;                               // (windows of at most 16 tokens: zn_api.hip)
   if (a.use_penalty && a.codes) {
     const int avail = o + 1 < a.ctx ? o + 1 : a.ctx;   // columns [max(0,o+1-ctx), o]
     nw = avail < a.pen_window ? avail : a.pen_window;
