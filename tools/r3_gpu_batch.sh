@@ -2,7 +2,7 @@
 set -o pipefail
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-O=gpurun_out/r3k
+O=gpurun_out/r3n
 mkdir -p $O
 timeout -k 10 700 python -m pytest tests -x -q -s -m gpu > $O/gpu_tests.txt 2>&1; echo "tests rc=$?"; tail -2 $O/gpu_tests.txt
 timeout -k 10 200 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_f -- python3 tools/pmc_kernel.py 6 > $O/pmc_f.txt 2>&1; echo "pmc f rc=$?"
@@ -14,4 +14,7 @@ timeout -k 10 200 python tools/stacksweep.py 400 > $O/sweep.txt 2>&1; grep -v am
 timeout -k 10 300 python tools/stackbench.py 400 > $O/stackbench.txt 2>&1; grep -v amdgpu $O/stackbench.txt | tail -9
 timeout -k 10 200 python bench.py --batch-per-gpu 8 --no-cpu-baseline > $O/bench_b8.json 2> $O/bench_b8.log; echo "b8 rc=$?"; cut -c1-200 $O/bench_b8.json
 timeout -k 10 300 python tools/longform.py > $O/longform.txt 2>&1; tail -3 $O/longform.txt
+timeout -k 10 120 python tools/dacbench.py 10 > $O/dacbench.txt 2>&1; tail -2 $O/dacbench.txt
+timeout -k 10 120 python tools/dacbench.py 10 8 > $O/dacbench_b8.txt 2>&1; tail -1 $O/dacbench_b8.txt
+timeout -k 10 200 python tools/prefillbench.py > $O/prefill.txt 2>&1; tail -1 $O/prefill.txt
 find $O -name "*kernel_trace.csv" -size +3M -delete
