@@ -76,6 +76,7 @@ static_assert(sizeof(StepAttnLds) <= ZN_SK_DYN_LDS, "the attention role's LDS fi
 // A wave that waits for a hand-off far in the future (the attention workgroups for q|k|v, the streaming ones for the attention
 // output) sleeps through most of the wait it measured one block earlier instead of polling through it (polls sit in the CU's
 // memory queue in front of its own prefetch and load the fabric; megakernel price list "polling-cost").
+#define ZN_SK_PACE_CAP 8192u            // 82 us in the 100 MHz ticks of s_memrealtime
 struct StepPacer {
   unsigned long long t_ref; unsigned prev;
   ZN_DEVINL void start() { t_ref = __builtin_amdgcn_s_memrealtime(); }
@@ -83,7 +84,13 @@ struct StepPacer {
     const unsigned long long until = t_ref + (ZN_SK_PACE_MARGIN > 0 ? (prev > ZN_SK_PACE_MARGIN ? prev - ZN_SK_PACE_MARGIN : 0u) : (prev - (prev >> ZN_SK_PACE_SHIFT)));
     while (__builtin_amdgcn_s_memrealtime() < until) __builtin_amdgcn_s_sleep(8);
   }
-  ZN_DEVINL void done() { prev = (unsigned)(__builtin_amdgcn_s_memrealtime() - t_ref); }
+  // What is learnt is capped at a few block times: a wait that contained a pause of the device (queue preemption; seen twice in some
+  // thousand generations, 20 - 30 ms each) must not become the next block's sleep - the waves that slept through 3/4 of such a "wait"
+  // kept everybody else polling past the hand-off timeout (profiles/r03_handoff_timeout_record.txt, second record).
+  ZN_DEVINL void done() {
+    const unsigned long long d = __builtin_amdgcn_s_memrealtime() - t_ref;
+    prev = d < ZN_SK_PACE_CAP ? (unsigned)d : ZN_SK_PACE_CAP;
+  }
 };
 
 // ------------------------------------------------------------------------------------------------ attention role
