@@ -4,6 +4,8 @@
 
 Every batch-1 test of tests/test_gpu_decode.py at the Zonos-v0.1 dimensions runs this path too (it is the default there);
 this file adds the smallest configuration the kernel serves, where the oracle can follow a whole generation."""
+import time
+
 import numpy as np
 import pytest
 import torch
@@ -283,3 +285,31 @@ def test_single_workgroup_sampler_matches_the_ticketed_sampler():
         eng.call("zn_debug_tune", 16, 1)
         eng.call("zn_debug_force_eos", -1)
         eng.call("zn_debug_eos_bias", 0.0)
+
+
+def test_a_device_pause_inside_the_attention_wait_is_survived(capfd):
+    """zn_debug_tune(14, 11): every whole-step launch of the next generation stops all its waves for 30 ms in block 2 - the attention
+    workgroups inside the wait their pacer measures, the streaming workgroups outside theirs - which is how a pause of the device
+    (queue preemption) looks from inside the kernel.  The pacer must not turn the 30 ms "wait" into the next block's sleep (uncapped it
+    did: the attention workgroups slept 22 ms while the streaming ones polled past the 20 ms / 4096-pass bound; the second record in
+    profiles/r03_handoff_timeout_record.txt): same codes as an undisturbed run, no timeout reported, the handle stays on the kernel."""
+    cfg, seed = synth.FULL_CFG, 1234
+    model, _ = build_model(cfg, seed, "cuda:0")
+    eng = model.engine(1)
+    cond = synth.conditioning(seed, "cond", 2, 24, cfg["d_model"]).to("cuda:0")
+    try:
+        eng.call("zn_debug_eos_bias", float("-inf"))
+        ref = model.generate(cond, max_new_tokens=12, sampling_params=GREEDY).cpu()
+        eng.call("zn_debug_tune", 14, 11)
+        t0 = time.perf_counter()
+        out = model.generate(cond, max_new_tokens=12, sampling_params=GREEDY).cpu()
+        dt = time.perf_counter() - t0
+        assert eng.lib.zn_decode_path_detail(eng.h) == 2, "the generation left the whole-step kernel"
+        again = model.generate(cond, max_new_tokens=12, sampling_params=GREEDY).cpu()
+        assert eng.lib.zn_decode_path_detail(eng.h) == 2
+    finally:
+        eng.call("zn_debug_eos_bias", 0.0)
+    err = capfd.readouterr().err
+    assert "hand-off" not in err, err
+    assert dt > 19 * 0.030, f"the pause hook did not run ({dt:.3f} s)"
+    assert torch.equal(out, ref) and torch.equal(again, ref)

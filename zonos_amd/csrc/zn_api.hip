@@ -88,6 +88,7 @@ struct zn_handle_s {
   int *lengths = nullptr, *codes = nullptr;
   int force_eos_step = -1;
   float eos_bias = 0.f;
+  unsigned dbg_pause = 0;           // ChainArgs::dbg_pause of this generation's whole-step launches
   int tune[20] = {256, 512, 512, 1024, 512, 704, 2, 2, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // target workgroups: in_proj, out_proj, fc1, fc2, heads; [5] longest context of the fused attention launch; [6] > 1: multi-step graphs; [7] > 1: LDS-staged small-M projections; [8] = 2: no persistent chain kernel (five launches per block instead); [9]: KV capacity above which the P.V pass splits per block (0 = 1408); [10] = 2: VALU prefill attention; [11] = 2: no in-workgroup-split small-M kernel
   const int* tok_override = nullptr;
   int tok_override_calls = 0;
@@ -613,7 +614,8 @@ static int launch_chain(zn_handle h, int li, const std::vector<const void*>& kv_
   a.ln2_w = (const bf16_t*)lw.norm2_w; a.ln2_b = (const bf16_t*)lw.norm2_b; a.eps = c.norm_eps; a.F = c.d_ff;
   a.a = h->o1; a.xin = xin ? xin : chain_x(h, li); a.xout = chain_x(h, li + 1);
   a.g_y1 = h->ch_gy1; a.g_x1 = h->ch_gx1; a.g_x2 = h->ch_gx2; a.g_m = h->ch_gm;
-  a.epoch = h->ch_epoch; a.tmo = &h->st->pad[0]; a.diag = h->ch_diag; a.stamp_layer = li;
+  a.epoch = h->ch_epoch; a.tmo = &h->st->pad[0]; a.diag = h->ch_diag;
+  a.dbg_pause = h->dbg_pause; a.stamp_layer = li;
   a.stamps = h->ch_stamps ? h->ch_stamps + (size_t)li * 32 : nullptr;
   if (!last) {
     const zn_layer_weights& nx = h->layers[li + 1];
@@ -693,6 +695,7 @@ static int launch_stack(zn_handle h, hipStream_t s) {
   a.xin = h->x_emb; a.xout = h->x;
   a.g_y1 = h->ch_gy1; a.g_x1 = h->ch_gx1; a.g_x2 = h->ch_gx2; a.g_m = h->ch_gm; a.g_qkv = h->ch_gqkv; a.g_a = h->ch_ga;
   a.epoch = h->ch_epoch; a.tmo = &h->st->pad[0]; a.diag = h->ch_diag;
+  a.dbg_pause = h->dbg_pause;
   a.stamps = h->ch_stamps; a.stamp_layer = c.n_layer / 2;
   a.rope = h->rope; a.lengths = h->lengths; a.max_len = h->max_len; a.hd = h->hd; a.n_heads = c.n_heads; a.n_heads_kv = c.n_heads_kv;
   a.rope_positions = c.rope_positions;
@@ -1000,6 +1003,8 @@ extern "C" int zn_gen_begin(zn_handle h, int32_t batch, const void* const* kv_la
   }
   GenState st{};
   st.offset = offset0; st.step = 0; st.all_done = 0; st.force_eos_step = h->force_eos_step; st.eos_bias = h->eos_bias;
+  h->dbg_pause = 0;
+  if (h->tune[14] == 11) { h->dbg_pause = 3000000u; h->tune[14] = 0; }   // test hook (zn_debug_tune(14, 11)): every launch of this generation pauses all its waves for 30 ms in block 2
   if (h->tune[14] == 9) { st.pad[0] = 1; h->tune[14] = 0; }   // test hook (zn_debug_tune(14, 9)): this generation's hand-off waits find the timeout word set
   HIPCHK(h, hipMemcpyAsync(h->st, &st, sizeof st, hipMemcpyHostToDevice, s));
   std::vector<int> rem(batch, t_total - offset0), stop(batch, 0);   // model.py:439-441

@@ -70,6 +70,7 @@ struct ChainArgs {
   int heads_rows;                                          // rows of the fused heads matrix (last block's op 4)
   bf16_t* trace;                                           // diagnostic [n_layer][8][2][d]: slot 0 x after the block, 1 attention output, 2 q
   unsigned* diag;                                          // [8] words describing the first hand-off wait that timed out (sweep_granules)
+  unsigned dbg_pause;                                      // test hook (step_kernel): every wave stops for this many 10 ns ticks in block 2, as a paused device would
 };
 struct StackLayer {
   const bf16_t *W_out, *W_fc1, *W_fc2, *W_in;              // W_in = NEXT block's in_proj, or the heads matrix (last block)

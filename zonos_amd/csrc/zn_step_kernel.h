@@ -76,7 +76,9 @@ static_assert(sizeof(StepAttnLds) <= ZN_SK_DYN_LDS, "the attention role's LDS fi
 // A wave that waits for a hand-off far in the future (the attention workgroups for q|k|v, the streaming ones for the attention
 // output) sleeps through most of the wait it measured one block earlier instead of polling through it (polls sit in the CU's
 // memory queue in front of its own prefetch and load the fabric; megakernel price list "polling-cost").
+#ifndef ZN_SK_PACE_CAP
 #define ZN_SK_PACE_CAP 8192u            // 82 us in the 100 MHz ticks of s_memrealtime
+#endif
 struct StepPacer {
   unsigned long long t_ref; unsigned prev;
   ZN_DEVINL void start() { t_ref = __builtin_amdgcn_s_memrealtime(); }
@@ -92,6 +94,12 @@ struct StepPacer {
     prev = d < ZN_SK_PACE_CAP ? (unsigned)d : ZN_SK_PACE_CAP;
   }
 };
+// Test hook (ChainArgs::dbg_pause, zn_debug_tune(14, 11)): what a pause of the device looks like from inside - every wave stops at about the
+// same wall-clock time, the attention workgroups inside their measured wait for q | k | v, the streaming workgroups outside theirs.
+ZN_DEVINL void step_debug_pause(unsigned ticks) {
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+  while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(127);
+}
 
 // ------------------------------------------------------------------------------------------------ attention role
 ZN_DEVINL void step_attention_role(const ChainArgs& a, StepAttnLds& S, const unsigned tag0, const int c, const int wave, const int lane) {
@@ -140,6 +148,7 @@ ZN_DEVINL void step_attention_role(const ChainArgs& a, StepAttnLds& S, const uns
 #pragma unroll 1
   for (int li = 0; li < a.n_layer; ++li) {
     const unsigned tag = tag0 + (unsigned)li;
+    if (a.dbg_pause && li == 3) step_debug_pause(a.dbg_pause);     // (inside the measured wait for block 3's q | k | v)
     const bool st_on = stamped && li == a.stamp_layer;
     auto stamp = [&](int i) { if (st_on) a.stamps[32 + i] = __builtin_amdgcn_s_memrealtime(); };
     stamp(0);
@@ -737,6 +746,7 @@ __global__ __launch_bounds__(ZN_SK_THREADS) void step_kernel(ChainArgs a) {
         stamp();
       }
     });
+    if (a.dbg_pause && li == 2) step_debug_pause(a.dbg_pause);     // (outside the measured wait)
     pace.start();                                          // the wait for the next block's attention output starts here
   }
   if (epi && sc == 0 && lane == 0) st_sc1_u32(a.epoch, tag0 + (unsigned)a.n_layer);   // every workgroup read the epoch before its first publish, which this one has seen
