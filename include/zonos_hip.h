@@ -186,8 +186,10 @@ int zn_debug_token_override(zn_handle h, const int32_t* tokens_dev, int32_t call
 int zn_debug_prefill_mode(zn_handle h, int32_t mode);
 /* Tuning hook: target workgroup count of a GEMV class (0 in_proj, 1 out_proj, 2 fc1, 3 fc2, 4 heads); 5: longest context of the
  * fused attention launch; 6: 1 = single-step graphs only; 8: 2 = per-op launches instead of the persistent chain kernel (also
- * ZN_CHAIN=0 at zn_create); 15: 3 = the opt-in whole-step kernel at batch 1 (also ZN_STACK=1 at zn_create), 1 = off.  Every path
- * gives bit-identical results. */
+ * ZN_CHAIN=0 at zn_create); 15: 2 = one chain launch per block instead of the whole-step kernel at batch 1, 4 = the three-role
+ * experiment; 16: 2 = the ticketed sampler launch instead of the one-workgroup step tail at batch 1.  Every path gives bit-identical
+ * results.  14: one-shot test hooks for the next generation (7: hand-off tags about to wrap; 9: the timeout word found set; 11: every
+ * whole-step launch stops all its waves for 30 ms in block 2, as a paused device would).  Keys 0 .. 19. */
 int zn_debug_tune(zn_handle h, int32_t key, int32_t value);
 /* Test/benchmark hook: add `bias` to the codebook-0 EOS logit on every step (-inf suppresses EOS so that all
  * max_new_tokens+7 steps run). */
@@ -275,7 +277,9 @@ typedef struct zn_dac_config { /* transformers DacConfig fields used by decode /
   int32_t encoder_hidden_size;         /* 64; 0 = no encoder */
 } zn_dac_config;
 typedef struct zn_dac_tensor { const char* name; const float* data_dev; int64_t numel; } zn_dac_tensor;
-/* Weights by their transformers state-dict names (fp32, device).  The library re-lays them out once. */
+/* Weights by their transformers state-dict names (fp32, device).  The library re-lays them out once.  Decode runs on the bf16 matrix
+ * cores with three-term fp32 operands (zn_conv3_kernels.h; waveform RMS error vs the reference 1e-6, as on the fp32 matrix cores);
+ * ZONOS_DAC_CONV=fp32 in the environment of this call keeps the decoder on the fp32 matrix cores (development: A/B of the two). */
 int zn_dac_create(const zn_dac_config* cfg, const zn_dac_tensor* tensors, int32_t n_tensors, zn_dac* out);
 int zn_dac_destroy(zn_dac d);
 const char* zn_dac_last_error(zn_dac d);
