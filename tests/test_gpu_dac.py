@@ -132,3 +132,19 @@ def test_encode_two_seconds_vs_oracle(dac):
     first, allc = float((got[:, 0] == ref[:, 0]).mean()), float((got == ref).mean())
     print(f"\n[DAC encode 2 s] first codebook equal {first:.4f}, all codes equal {allc:.4f}")
     assert first >= 0.995 and allc >= 0.99
+
+
+def test_clip_beyond_the_32_bit_offsets_takes_the_fp32_kernels(dac):
+    """The three-term kernels address one batch element's activations with 32-bit byte offsets: beyond 84 s of audio (7 300 frames here)
+    zn_dac_decode runs the fp32 kernels.  Size-independent check: the head of the long decode equals the decode of the head of the codes
+    (a different kernel family: within 1e-5 RMS) away from the cut."""
+    ae, _ = dac
+    codes = torch.from_numpy(synth.randint(9, "codes.long", (1, 9, 7300), 1024)).to("cuda:0")
+    long = ae.decode(codes)
+    assert long.shape == (1, 1, 7300 * 512) and bool(torch.isfinite(long).all())
+    head = ae.decode(codes[..., :200])
+    a, b = long[0, 0, :160 * 512].cpu().numpy(), head[0, 0, :160 * 512].cpu().numpy()
+    assert _rms(a, b) <= 1e-5
+    tail = ae.decode(codes[..., -200:])
+    a, b = long[0, 0, -160 * 512:].cpu().numpy(), tail[0, 0, -160 * 512:].cpu().numpy()
+    assert _rms(a, b) <= 1e-5

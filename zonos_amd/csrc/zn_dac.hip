@@ -485,7 +485,9 @@ extern "C" int zn_dac_decode(zn_dac d, const int32_t* codes, int32_t B, int32_t 
   }
   float *x = d->buf[0], *y = d->buf[1], *z = d->buf[2];
   hipLaunchKernelGGL(dac_codes_kernel, dim3(T, B), dim3(256), 0, s, codes, d->table, x, c.n_codebooks, T, c.hidden_size, c.codebook_size);
-  if (d->split3) {
+  // the three-term kernels address a batch element's activations with 32-bit byte offsets (buffer loads): 6 bytes per element, < 2 GiB per
+  // layer and batch element (84 s of audio at the last block's 96 channels); longer clips take the fp32 kernels
+  if (d->split3 && (need / (size_t)B) * 6 < 0x7fffffffull) {
     if (need > d->s3_elems) {
       DHIP(d, hipStreamSynchronize(s));
       for (auto& p : d->s3) { if (p) (void)hipFree(p); p = nullptr; }
