@@ -187,7 +187,7 @@ int zn_debug_prefill_mode(zn_handle h, int32_t mode);
 /* Tuning hook: target workgroup count of a GEMV class (0 in_proj, 1 out_proj, 2 fc1, 3 fc2, 4 heads); 5: longest context of the
  * fused attention launch; 6: 1 = single-step graphs only; 8: 2 = per-op launches instead of the persistent chain kernel (also
  * ZN_CHAIN=0 at zn_create); 15: 2 = one chain launch per block instead of the whole-step kernel at batch 1, 4 = the three-role
- * experiment; 16: 2 = the ticketed sampler launch instead of the one-workgroup step tail at batch 1.  Every path gives bit-identical
+ * experiment; 16: 2 = the ticketed sampler launch instead of the one-workgroup step tail at batch 1 (the default for greedy decoding), 3 = the one-workgroup tail also with a temperature.  Every path gives bit-identical
  * results.  14: one-shot test hooks for the next generation (7: hand-off tags about to wrap; 9: the timeout word found set; 11: every
  * whole-step launch stops all its waves for 30 ms in block 2, as a paused device would).  Keys 0 .. 19. */
 int zn_debug_tune(zn_handle h, int32_t key, int32_t value);

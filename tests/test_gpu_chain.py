@@ -268,7 +268,7 @@ def test_single_workgroup_sampler_matches_the_ticketed_sampler():
     try:
         for sp, force in cases:
             outs = []
-            for t16 in (2, 1):
+            for t16 in (2, 3):                              # 3: sample1_kernel also for the sampled cases (the default keeps it to greedy decoding)
                 eng.call("zn_debug_tune", 16, t16)
                 eng.call("zn_debug_eos_bias", float("-inf") if force is None else 0.0)
                 eng.call("zn_debug_force_eos", -1 if force is None else force)

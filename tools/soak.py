@@ -1,7 +1,7 @@
 """Soak of the default batch-1 decode path (whole-step kernel): N full-length generations (10 s each: prefill + 868 decode steps = 26 x 6
 in-kernel hand-offs per step), every one compared with the first (the kernels are deterministic) - codes must be identical, no hand-off
 wait may give up, the handle must still be on the whole-step kernel at the end.
-    python tools/soak.py [generations]"""
+    python tools/soak.py [generations] [sampled]      # "sampled": temperature 1.0 + min_p 0.1 with a fixed seed instead of greedy decoding"""
 import os
 import sys
 import time
@@ -13,6 +13,7 @@ from zonos_amd import synth  # noqa: E402
 from zonos_amd.testing import build_model  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 50
+SP = {"temperature": 1.0, "min_p": 0.1} if len(sys.argv) > 2 and sys.argv[2] == "sampled" else {"temperature": 0.0}
 model, _ = build_model(synth.FULL_CFG, 1234, "cuda:0")
 eng = model.engine(1)
 eng.call("zn_debug_eos_bias", float("-inf"))
@@ -23,7 +24,7 @@ worst = 0.0
 for i in range(n):
     torch.cuda.synchronize()
     ta = time.perf_counter()
-    out = model.generate(cond, max_new_tokens=861, sampling_params={"temperature": 0.0})
+    out = model.generate(cond, max_new_tokens=861, sampling_params=SP, seed=4242)
     torch.cuda.synchronize()
     dt = time.perf_counter() - ta
     worst = max(worst, dt)

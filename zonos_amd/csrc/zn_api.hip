@@ -952,9 +952,12 @@ static int enqueue_step(zn_handle h, hipStream_t s) {
   f.mask_id = c.mask_id; f.tokens = h->tok_raw; f.remaining = h->remaining; f.stopping = h->stopping; f.lengths = h->lengths;
   f.rows = h->rows; f.first = 0; f.override = h->tok_override; f.override_calls = h->tok_override_calls;
   if (fused) { a.ticket = h->tail_ticket; a.em = make_embed_args(h); }
-  // batch 1: sampling, bookkeeping and the next embedding in one workgroup (sample1_kernel; tune[16] = 2 keeps the ticketed kernel)
-  const bool one_wg = fused && h->batch == 1 && h->tune[16] != 2 && c.vocab_head <= 64 * ZN_S1_IT && c.n_codebooks <= 16 && !(h->sp.top_p > 0.f) &&
-                      h->sp.top_k <= 0 && !(h->sp.linear > 0.f) && (!a.use_penalty || h->sp.repetition_penalty_window <= 16) && h->rows <= 1024;
+  // batch 1, greedy decoding: sampling, bookkeeping and the next embedding in one workgroup (sample1_kernel: 0.8337 -> 0.8312 ms per step).  With a
+  // temperature its one wave per codebook carries 17 exp / log / hash evaluations per lane and the nine ticketed workgroups are ahead again (0.8396 vs
+  // 0.8415): they keep those steps.  tune[16] = 2: always the ticketed kernel; 3: the one-workgroup kernel for every parameter set it implements (tests).
+  const bool one_wg = fused && h->batch == 1 && h->tune[16] != 2 && (h->tune[16] == 3 || !(h->sp.temperature > 0.f)) && c.vocab_head <= 64 * ZN_S1_IT &&
+                      c.n_codebooks <= 16 && !(h->sp.top_p > 0.f) && h->sp.top_k <= 0 && !(h->sp.linear > 0.f) &&
+                      (!a.use_penalty || h->sp.repetition_penalty_window <= 16) && h->rows <= 1024;
   if (one_wg) { hipLaunchKernelGGL(sample1_kernel, dim3(1), dim3(1024), 0, s, a); return ZN_OK; }
   hipLaunchKernelGGL(sample_kernel, dim3(c.n_codebooks, h->batch), dim3(256), 0, s, a);
   if (!fused) hipLaunchKernelGGL(frame_update_kernel, dim3(1), dim3(256), 0, s, f);
