@@ -31,7 +31,7 @@ sys.path.insert(0, ROOT)
 FRAME_RATE = 44100 / 512          # 86.1328 DAC frames per second of audio
 HBM_PEAK = 8.0e12                 # B/s, MI355X spec (MI355X_MICROARCH.md)
 PMC_FILES = {5: os.path.join(ROOT, "profiles", "pmc_chain.json"), 6: os.path.join(ROOT, "profiles", "pmc_step_kernel.json")}
-KERNEL_SOURCES = ("zonos_amd/csrc/zn_step_kernel.h", "zonos_amd/csrc/zn_chain_kernel.h", "zonos_amd/csrc/zn_decode_kernels.h", "zonos_amd/csrc/zn_common.h")
+KERNEL_SOURCES = ("zonos_amd/csrc/zn_step_kernel.h", "zonos_amd/csrc/zn_step_sched.h", "zonos_amd/csrc/zn_chain_kernel.h", "zonos_amd/csrc/zn_decode_kernels.h", "zonos_amd/csrc/zn_common.h")
 STEP_KERNEL_CTX = 450             # keys in the cache for the whole-step kernel's roofline launches: the mean context of a 10 s utterance
 
 
