@@ -141,8 +141,11 @@ __global__ __launch_bounds__(256, 2) void dac_conv3_kernel(Conv3Args a) {
     }
     __syncthreads();
     if (ck + 1 < nck) fetch(ck + 1);
-#pragma unroll 1
-    for (int tap = 0; tap < (MAXT == 1 ? 1 : a.taps); ++tap) {
+#ifndef C3_TAP_UNROLL
+#define C3_TAP_UNROLL 1
+#endif
+#pragma unroll C3_TAP_UNROLL
+    for (int tap = 0; tap < MAXT; ++tap) {                  // a.taps == MAXT (zn_conv3_launch)
       const int r0 = wave * (32 * RB) + fr + a.off0 + tap * a.offstep - offmin;
       c3_bf16x8 A[RB][3], Bf[NT][3];
 #pragma unroll
@@ -273,6 +276,7 @@ template <int RB, int MAXT> static inline void zn_conv3_go(const Conv3Args& a, i
 }
 // 256-row tiles once they fill the chip's 512 workgroup slots, 128-row tiles for the short early layers
 static inline void zn_conv3_launch(const Conv3Args& a, int B, hipStream_t s) {
+  // (the decoder's layers have 7, 2 or 1 taps; the kernels' tap loops are compile-time)
   if (a.taps == 1) return zn_conv3_go<C3_K1_RB, 1>(a, B, s);
   const bool big = (long)((a.M + 255) / 256) * (a.CoutPad / C3_TN) * B * a.phases >= 512;
   if (a.taps == 2) { if (big) zn_conv3_go<2, 2>(a, B, s); else zn_conv3_go<1, 2>(a, B, s); return; }
