@@ -135,13 +135,13 @@ def test_encode_two_seconds_vs_oracle(dac):
 
 
 def test_clip_beyond_the_32_bit_offsets_takes_the_fp32_kernels(dac):
-    """The three-term kernels address one batch element's activations with 32-bit byte offsets: beyond 84 s of audio (7 300 frames here)
+    """The three-term kernels address one batch element's activations with 32-bit byte offsets: beyond 126 s of audio (11 000 frames here)
     zn_dac_decode runs the fp32 kernels.  Size-independent check: the head of the long decode equals the decode of the head of the codes
     (a different kernel family: within 1e-5 RMS) away from the cut."""
     ae, _ = dac
-    codes = torch.from_numpy(synth.randint(9, "codes.long", (1, 9, 7300), 1024)).to("cuda:0")
+    codes = torch.from_numpy(synth.randint(9, "codes.long", (1, 9, 11000), 1024)).to("cuda:0")
     long = ae.decode(codes)
-    assert long.shape == (1, 1, 7300 * 512) and bool(torch.isfinite(long).all())
+    assert long.shape == (1, 1, 11000 * 512) and bool(torch.isfinite(long).all())
     head = ae.decode(codes[..., :200])
     a, b = long[0, 0, :160 * 512].cpu().numpy(), head[0, 0, :160 * 512].cpu().numpy()
     assert _rms(a, b) <= 1e-5

@@ -6,15 +6,16 @@
 // core and accumulated in fp32.  v_mfma_f32_32x32x16_bf16 is 16 x the rate of v_mfma_f32_32x32x2_f32, so six of them do the
 // work of eight fp32 MFMAs in 3/8 of the issue time - and the Snake activation, which zn_conv_kernels.h applies to its
 // input rows once per output-channel tile (6 - 12 times per element), moves to the PRODUCER's epilogue: a layer stores the
-// next layer's input, activated and split, once.
+// next layer's input activated, once.
 //
-// Layouts.  Activations "S3": [B][T][C/16][3][16] bf16 - per time step and 16-channel chunk the three terms of the chunk, 96
-// contiguous bytes (what a workgroup stages per row and K chunk).  Weights "W3": [phase][Cin/16][tap][CoutPad][3][16].  The
-// residual stream a unit adds back at its end (DacResidualUnit, modeling_dac.py:175-209) stays fp32 [B][T][C].
+// Layouts.  Activations stay fp32 channels-last [B][T][C] in memory (4 bytes per element; a first version kept the three terms
+// there, 6 bytes: the decode wrote 4.4 GB of them per clip and needed an LDS transpose in every epilogue) and are split on the way
+// into LDS (8 VALU instructions per element and output-channel tile).  Weights are split once: "W3" [phase][Cin/16][tap][CoutPad][3][16].
+// The residual stream a unit adds back at its end (DacResidualUnit, modeling_dac.py:175-209) is a second fp32 tensor.
 // Workgroup: 256 threads, RB x 128 output times x 64 output channels; wave = RB x 32 rows x 64 channels; K advances 16 input
-// channels per stage: the rows a tile needs (with the dilation halo) and all taps of the stage's weights sit in LDS (96-byte
-// rows, the two 16-byte halves of a term swapped on rows with bit 3 set: conflict-free ds_read_b128 fragments without padding;
-// 71 KB at RB = 2, so two workgroups share a CU and one stages while the other multiplies).
+// channels per stage: the rows a tile needs (with the dilation halo) and all taps of the stage's weights sit in LDS as three-term
+// rows of 96 bytes (the two 16-byte halves of a term swapped on rows with bit 3 set: conflict-free ds_read_b128 fragments without
+// padding; 71 KB at RB = 2, so two workgroups share a CU and one stages while the other multiplies).
 #pragma once
 #include "zn_conv_kernels.h"
 
@@ -23,7 +24,6 @@ typedef __attribute__((ext_vector_type(8))) __bf16 c3_bf16x8;
 #define C3_KC 16
 #define C3_TN 64
 #define C3_ROW 96                      // LDS / S3 bytes per (row, 16-channel chunk): 3 terms x 16 bf16
-#define C3_IMG (128 * 2 * C3_ROW)      // epilogue image: 128 rows x 32 channels
 #ifndef C3_NFAST
 #define C3_NFAST 1                     // 1: output-channel tiles vary fastest in the dispatch order (workgroups of one time tile run together)
 #endif
@@ -32,13 +32,13 @@ typedef __attribute__((ext_vector_type(8))) __bf16 c3_bf16x8;
 #endif
 
 struct Conv3Args {
-  const bf16_t* in; int Tin, Cin;          // S3 [B][Tin][Cin/16][3][16]: already activated (or the raw latent)
+  const float* in; int Tin, Cin;           // fp32 [B][Tin][Cin]: already activated (or the raw latent)
   const bf16_t* w;                         // W3 [phase][Cin/16][tap][CoutPad][3][16]
   const float* bias;                       // [Cout]
-  const float* alpha;                      // Snake alpha of the NEXT layer (over this layer's output channels), or NULL: out3 holds the plain output
+  const float* alpha;                      // Snake alpha of the NEXT layer (over this layer's output channels), or NULL: out_act holds the plain output
   const float* skip;                       // fp32 residual [B][Tout][Cout], or NULL
-  float* out32;                            // fp32 output [B][Tout][Cout] (before the next Snake), or NULL; may alias skip
-  bf16_t* out3;                            // S3 output (after the next Snake), or NULL
+  float* out32;                            // fp32 output [B][Tout][Cout] before the next Snake (the residual stream), or NULL; may alias skip
+  float* out_act;                          // fp32 output after the next Snake (the next layer's input), or NULL
   int Tout, Cout, CoutPad;
   int M;                                   // GEMM rows per phase
   int taps, off0, offstep;                 // input row of GEMM row m, tap k: m + off0 + k*offstep
@@ -89,7 +89,7 @@ __global__ __launch_bounds__(256, 2) void dac_conv3_kernel(Conv3Args a) {
   const int offmin = a.off0 < offlast ? a.off0 : offlast, offmax = a.off0 < offlast ? offlast : a.off0;
   const int nrows = TM + offmax - offmin;
   const int nck = a.Cin / C3_KC;
-  const bf16_t* inb = a.in + (size_t)b * a.Tin * a.Cin * 3;
+  const float* inb = a.in + (size_t)b * a.Tin * a.Cin;
   const bf16_t* wp = a.w + (size_t)phase * nck * a.taps * a.CoutPad * 48;
   f32x16 acc[RB][NT];
 #pragma unroll
@@ -99,19 +99,20 @@ __global__ __launch_bounds__(256, 2) void dac_conv3_kernel(Conv3Args a) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[rb][nt][e] = 0.f;
 
-  // staging slots (16-byte pieces: 6 per row): the next stage's requests go out before this stage's MFMAs and land in LDS after them.
-  // Buffer loads: one 32-bit offset per piece (rows outside [0, Tin) fall outside the batch element's range and read as zeros: the
-  // convolution's zero padding), the K stage advances through the scalar offset.
-  constexpr int IN_P = (MAXROWS * 6 + 255) / 256, W_P = (MAXT * C3_TN * 6 + 255) / 256;
+  // staging slots: the next stage's requests go out before this stage's MFMAs and land in LDS after them.  Input pieces: 16 bytes = 4
+  // fp32 channels, 4 per row and stage; weight pieces: 16 bytes of a term, 6 per weight row.  Buffer loads: one 32-bit offset per
+  // piece (rows outside [0, Tin) fall outside the batch element's range and read as zeros: the convolution's zero padding), the K stage
+  // advances through the scalar offset.
+  constexpr int IN_P = (MAXROWS * 4 + 255) / 256, W_P = (MAXT * C3_TN * 6 + 255) / 256;
   u32x4 rin[IN_P], rw[W_P];
   int vin[IN_P], vw[W_P];
-  const int n_in = nrows * 6, n_w = a.taps * C3_TN * 6;
-  const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)inb, 0, (int)((size_t)a.Tin * nck * C3_ROW), 0x00020000);
+  const int n_in = nrows * 4, n_w = a.taps * C3_TN * 6;
+  const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)inb, 0, (int)((size_t)a.Tin * a.Cin * 4), 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)wp, 0, (int)((size_t)nck * a.taps * a.CoutPad * C3_ROW), 0x00020000);
 #pragma unroll
   for (int j = 0; j < IN_P; ++j) {
-    const int i = tid + j * 256, row = i / 6, q = i - row * 6;
-    vin[j] = i < n_in ? (m0 + offmin + row) * (nck * C3_ROW) + q * 16 : (int)0x80000000;
+    const int i = tid + j * 256, row = i >> 2, q = i & 3;
+    vin[j] = i < n_in ? (m0 + offmin + row) * (a.Cin * 4) + q * 16 : (int)0x80000000;
   }
 #pragma unroll
   for (int j = 0; j < W_P; ++j) {
@@ -121,7 +122,7 @@ __global__ __launch_bounds__(256, 2) void dac_conv3_kernel(Conv3Args a) {
   }
   auto fetch = [&](int ck) {
 #pragma unroll
-    for (int j = 0; j < IN_P; ++j) rin[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, vin[j], ck * C3_ROW, 0);
+    for (int j = 0; j < IN_P; ++j) rin[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, vin[j], ck * (C3_KC * 4), 0);
 #pragma unroll
     for (int j = 0; j < W_P; ++j) rw[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, vw[j], ck * a.taps * a.CoutPad * C3_ROW, 0);
   };
@@ -131,8 +132,17 @@ __global__ __launch_bounds__(256, 2) void dac_conv3_kernel(Conv3Args a) {
     __syncthreads();                                     // the previous stage's fragment reads are done
 #pragma unroll
     for (int j = 0; j < IN_P; ++j) {
-      const int i = tid + j * 256, row = i / 6, q = i - row * 6;
-      if (i < n_in) *(u32x4*)(s_in + c3_swz(row, q >> 1, q & 1)) = rin[j];
+      const int i = tid + j * 256, row = i >> 2, q = i & 3;
+      if (i < n_in) {                                    // channels 4 q .. 4 q + 3 of the stage: split, 8 bytes into each term's row
+        const float f[4] = {__uint_as_float(rin[j].x), __uint_as_float(rin[j].y), __uint_as_float(rin[j].z), __uint_as_float(rin[j].w)};
+        bf16_t t[3][4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) c3_split(f[e], t[0][e], t[1][e], t[2][e]);
+        unsigned char* d = s_in + c3_swz(row, 0, q >> 1) + (q & 1) * 8;
+#pragma unroll
+        for (int p3 = 0; p3 < 3; ++p3)
+          *(u32x2*)(d + p3 * 32) = u32x2{(unsigned)t[p3][0] | ((unsigned)t[p3][1] << 16), (unsigned)t[p3][2] | ((unsigned)t[p3][3] << 16)};
+      }
     }
 #pragma unroll
     for (int j = 0; j < W_P; ++j) {
@@ -168,69 +178,33 @@ __global__ __launch_bounds__(256, 2) void dac_conv3_kernel(Conv3Args a) {
             acc[rb][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[rb][PA[t6]], Bf[nt][PB[t6]], acc[rb][nt], 0, 0, 0);
     }
   }
-  // ---- epilogue.  C layout: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).  bias, residual, fp32 store from the
-  // registers; the S3 image of 128 rows x 32 channels (next Snake applied, split) goes through LDS so that it leaves in
-  // 16-byte pieces, 192 contiguous bytes per row.
-  unsigned char* s_o = c3_smem;                              // [128][2 chunks][96]
-  const int nchunk_out = a.Cout / C3_KC;
+  // ---- epilogue.  C layout: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5): a lane holds 16 times of one channel, a store
+  // instruction covers 32 consecutive channels of two rows.  bias, residual, the fp32 residual stream; the next Snake; the next layer's input.
 #pragma unroll
   for (int rb = 0; rb < RB; ++rb) {
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
-      __syncthreads();                                       // the fragment reads / the previous image's copy are done
       const int co = n0 + nt * 32 + fr;
-      const bool c_ok = co < a.Cout;
-      const float bv = (a.bias && c_ok) ? a.bias[co] : 0.f;
-      const float al = (a.alpha && c_ok) ? a.alpha[co] : 1.f;
+      if (co >= a.Cout) continue;
+      const float bv = a.bias ? a.bias[co] : 0.f;
+      const float al = a.alpha ? a.alpha[co] : 1.f;
       const float ial = 1.0f / (al + 1e-9f);
-      float v[16];
 #pragma unroll
       for (int reg = 0; reg < 16; ++reg) {
         const int rowi = (reg & 3) + 8 * (reg >> 2) + 4 * fh;
         const int m = m0 + wave * (32 * RB) + rb * 32 + rowi;
         const int to = m * a.ostride + a.ooff + phase;
-        v[reg] = acc[rb][nt][reg] + bv;
-        if (c_ok && m < a.M && to >= 0 && to < a.Tout) {
-          const size_t o = ((size_t)b * a.Tout + to) * a.Cout + co;
-          if (a.skip) v[reg] = a.skip[o] + v[reg];
-          if (a.out32) a.out32[o] = v[reg];
-        }
-      }
-      if (!a.out3) continue;
-#pragma unroll
-      for (int reg = 0; reg < 16; ++reg) {
-        const int rowi = (reg & 3) + 8 * (reg >> 2) + 4 * fh;
-        float x = v[reg];
-        if (a.alpha) x = x + ial * c3_sin2(al * x);
-        bf16_t h, mm, l;
-        c3_split(x, h, mm, l);
-        bf16_t* d = (bf16_t*)(s_o + (wave * 32 + rowi) * (2 * C3_ROW) + (fr >> 4) * C3_ROW) + (fr & 15);
-        d[0] = h; d[16] = mm; d[32] = l;
-      }
-      __syncthreads();
-#pragma unroll
-      for (int j = 0; j < 6; ++j) {
-        const int piece = tid + j * 256, irow = piece / 12, q = piece - irow * 12;     // 128 rows x 12 pieces
-        const int m = m0 + (irow >> 5) * (32 * RB) + rb * 32 + (irow & 31);
-        const int to = m * a.ostride + a.ooff + phase;
-        const int chunk = (n0 >> 4) + nt * 2 + q / 6;
-        if (m < a.M && to >= 0 && to < a.Tout && chunk < nchunk_out)
-          *(u32x4*)(a.out3 + (((size_t)b * a.Tout + to) * nchunk_out + chunk) * 48 + (q % 6) * 8) = *(const u32x4*)(s_o + irow * (2 * C3_ROW) + q * 16);
+        if (m >= a.M || to < 0 || to >= a.Tout) continue;
+        const size_t o = ((size_t)b * a.Tout + to) * a.Cout + co;
+        float v = acc[rb][nt][reg] + bv;
+        if (a.skip) v = a.skip[o] + v;
+        if (a.out32) a.out32[o] = v;
+        if (a.out_act) a.out_act[o] = a.alpha ? v + ial * c3_sin2(al * v) : v;
       }
     }
   }
 }
 
-// fp32 [n] -> S3 split of a channels-last tensor [rows][C] (the latent the decoder starts from)
-__global__ __launch_bounds__(256) void dac_split3_kernel(const float* x, bf16_t* o, size_t n, int C) {
-  for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-    const size_t row = i / C; const int c = (int)(i - row * C);
-    bf16_t h, m, l;
-    c3_split(x[i], h, m, l);
-    bf16_t* d = o + (row * (C / C3_KC) + (c >> 4)) * 48 + (c & 15);
-    d[0] = h; d[16] = m; d[32] = l;
-  }
-}
 // conv weight [Cout][Cin][K] -> W3 [Cin/16][K][CoutPad][3][16]
 __global__ void dac_w3conv_kernel(const float* w, bf16_t* o, int Cout, int Cin, int K, int CoutPad) {
   const size_t n = (size_t)K * Cin * CoutPad;
@@ -255,8 +229,7 @@ __global__ void dac_w3convt_kernel(const float* w, bf16_t* o, int Cin, int Cout,
 }
 
 template <int RB, int MAXT> static inline size_t zn_conv3_lds() {
-  const size_t stage = (size_t)(RB * 128 + (MAXT == 7 ? 54 : (MAXT == 2 ? 1 : 0))) * C3_ROW + (size_t)MAXT * C3_TN * C3_ROW;
-  return stage > C3_IMG ? stage : C3_IMG;
+  return (size_t)(RB * 128 + (MAXT == 7 ? 54 : (MAXT == 2 ? 1 : 0))) * C3_ROW + (size_t)MAXT * C3_TN * C3_ROW;
 }
 template <int RB, int MAXT> static inline hipError_t zn_conv3_attr() {
   return hipFuncSetAttribute((const void*)dac_conv3_kernel<RB, MAXT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)zn_conv3_lds<RB, MAXT>());

@@ -257,8 +257,6 @@ struct zn_dac_s {
   // decode on the bf16 matrix cores with three-term operands (zn_conv3_kernels.h): the default.  ZONOS_DAC_CONV=fp32 in the environment of
   // zn_dac_create keeps the decoder on the fp32 matrix cores (zn_conv_kernels.h; development: A/B of the two paths)
   bool split3 = true;
-  bf16_t* s3[2] = {nullptr, nullptr};
-  size_t s3_elems = 0;
   // encoder (optional: present when the state dict carries encoder.* and quantizer in_proj tensors)
   bool has_encoder = false;
   const float *enc_w1 = nullptr, *enc_b1 = nullptr;
@@ -278,7 +276,6 @@ extern "C" int zn_dac_destroy(zn_dac d) {
   if (!d) return ZN_OK;
   for (float* p : d->owned) (void)hipFree(p);
   for (float* p : d->buf) if (p) (void)hipFree(p);
-  for (bf16_t* p : d->s3) if (p) (void)hipFree(p);
   delete d;
   return ZN_OK;
 }
@@ -452,12 +449,12 @@ static int launch_conv(zn_dac d, const ConvLayer& L, const float* in, int Tin, c
   return launch_conv_args(a, L.CoutPad, B, s);
 }
 
-// Three-term path: `in3` is the layer's input as the producer left it (activated, split); alpha_next = the Snake the consumer of this layer's
+// Three-term path: `in` is the layer's input as the producer left it (activated, fp32); alpha_next = the Snake the consumer of this layer's
 // output applies (NULL: none / the consumer reads out32).
-static void launch_conv3(const ConvLayer& L, const bf16_t* in3, int Tin, const float* skip, float* out32, bf16_t* out3, const float* alpha_next,
+static void launch_conv3(const ConvLayer& L, const float* in, int Tin, const float* skip, float* out32, float* out_act, const float* alpha_next,
                          int Tout, int B, bool transpose, hipStream_t s) {
   Conv3Args a{};
-  a.in = in3; a.Tin = Tin; a.Cin = L.Cin; a.w = L.w3; a.bias = L.bias; a.alpha = alpha_next; a.skip = skip; a.out32 = out32; a.out3 = out3;
+  a.in = in; a.Tin = Tin; a.Cin = L.Cin; a.w = L.w3; a.bias = L.bias; a.alpha = alpha_next; a.skip = skip; a.out32 = out32; a.out_act = out_act;
   a.Tout = Tout; a.Cout = L.Cout; a.CoutPad = zn_conv3_pad(L.Cout);
   if (!transpose) {
     a.M = Tin; a.taps = L.K; a.off0 = -((L.K - 1) * L.dil) / 2; a.offstep = L.dil; a.ostride = 1; a.ooff = 0; a.phases = 1;
@@ -485,20 +482,12 @@ extern "C" int zn_dac_decode(zn_dac d, const int32_t* codes, int32_t B, int32_t 
   }
   float *x = d->buf[0], *y = d->buf[1], *z = d->buf[2];
   hipLaunchKernelGGL(dac_codes_kernel, dim3(T, B), dim3(256), 0, s, codes, d->table, x, c.n_codebooks, T, c.hidden_size, c.codebook_size);
-  // the three-term kernels address a batch element's activations with 32-bit byte offsets (buffer loads): 6 bytes per element, < 2 GiB per
-  // layer and batch element (84 s of audio at the last block's 96 channels); longer clips take the fp32 kernels
-  if (d->split3 && (need / (size_t)B) * 6 < 0x7fffffffull) {
-    if (need > d->s3_elems) {
-      DHIP(d, hipStreamSynchronize(s));
-      for (auto& p : d->s3) { if (p) (void)hipFree(p); p = nullptr; }
-      for (auto& p : d->s3) DHIP(d, hipMalloc(&p, need * 3 * sizeof(bf16_t)));
-      d->s3_elems = need;
-    }
-    // x: the fp32 residual stream (a unit's conv2 adds to it in place); p / q: the activated, split input of the next convolution
-    bf16_t *p = d->s3[0], *q = d->s3[1];
-    { const size_t n = (size_t)B * T * c.hidden_size;
-      hipLaunchKernelGGL(dac_split3_kernel, dim3((unsigned)std::min<size_t>((n + 255) / 256, 4096)), dim3(256), 0, s, x, p, n, c.hidden_size); }
-    launch_conv3(d->conv1, p, T, nullptr, nullptr, q, d->blocks[0].convt.alpha, T, B, false, s);     // decoder.conv1 -> block 0's snake1
+  // the three-term kernels address a batch element's activations with 32-bit byte offsets (buffer loads): 4 bytes per element, < 2 GiB per
+  // layer and batch element (126 s of audio at the last block's 96 channels); longer clips take the fp32 kernels
+  if (d->split3 && (need / (size_t)B) * 4 < 0x7fffffffull) {
+    // x: the fp32 residual stream (a unit's conv2 adds to it in place); p / q: the activated input of the next convolution
+    float *p = y, *q = z;
+    launch_conv3(d->conv1, x, T, nullptr, nullptr, q, d->blocks[0].convt.alpha, T, B, false, s);     // decoder.conv1 on the latent -> block 0's snake1
     std::swap(p, q);
     int t = T;
     for (int bi = 0; bi < c.n_ratios; ++bi) {
