@@ -2,7 +2,7 @@
 set -o pipefail
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-O=gpurun_out/r3o
+O=gpurun_out/r3v
 mkdir -p $O
 timeout -k 10 700 python -m pytest tests -x -q -s -m gpu > $O/gpu_tests.txt 2>&1; echo "tests rc=$?"; tail -2 $O/gpu_tests.txt
 timeout -k 10 200 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_f -- python3 tools/pmc_kernel.py 6 > $O/pmc_f.txt 2>&1; echo "pmc f rc=$?"
