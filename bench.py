@@ -206,6 +206,16 @@ def run_rank(args) -> int:
             torch.cuda.synchronize()
         log(f"rank {rank}: warmup {i} done")
     fence()
+
+    def handoff_state():
+        # hand-off timeouts are never silent (include/zonos_hip.h zn_get_counters): reported timeouts, generations that ran the launches path
+        # because a timeout had demoted the handle, generations Zonos.generate repeated after one
+        if dry:
+            return (0, 0, 0)
+        hc = model.handoff_counters()
+        engines = [hc[k] for k in ("engine", "spare") if k in hc]
+        return (sum(e["handoff_timeouts"] for e in engines), sum(e["fallback_generations"] for e in engines), hc["repeated_generations"])
+    h0 = handoff_state()
     t0 = time.perf_counter()
     frames = 0
     for _ in range(args.steps):
@@ -213,6 +223,8 @@ def run_rank(args) -> int:
         frames += sum(int(c.shape[-1]) for c in mine)
     fence()
     elapsed = time.perf_counter() - t0
+    h1 = handoff_state()
+    timed_events = [b - a for a, b in zip(h0, h1)]
     log(f"rank {rank}: {args.steps} timed steps in {elapsed:.3f} s")
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -221,6 +233,9 @@ def run_rank(args) -> int:
         fr = torch.tensor([frames], dtype=torch.float64, device=dev)
         dist.all_reduce(fr, op=dist.ReduceOp.SUM)
         frames = int(fr.item())
+        ev = torch.tensor(timed_events + list(h1), dtype=torch.float64, device=dev)
+        dist.all_reduce(ev, op=dist.ReduceOp.SUM)
+        timed_events, h1 = [int(v) for v in ev[:3].tolist()], tuple(int(v) for v in ev[3:].tolist())
     assert all(c.shape[-1] == max_new for c in mine), [c.shape for c in mine]
 
     audio_s = frames / FRAME_RATE
@@ -237,6 +252,10 @@ def run_rank(args) -> int:
         "frames_per_sec": round(frames / elapsed, 1),
         "setup_s": round(setup_s, 1),
         "ranks_seen": ranks_seen,
+        # all ranks: bounded in-kernel hand-off waits that gave up (each voids a generation), generations that ran the launches path because of
+        # one, generations repeated after one - since the handles were created, and inside the timed region (any of those fails the run)
+        "handoff_timeouts": h1[0], "fallback_generations": h1[1], "repeated_generations": h1[2],
+        "handoff_events_in_timed_region": {"timeouts": timed_events[0], "fallback_generations": timed_events[1], "repeated_generations": timed_events[2]},
     }
     if dry:
         result["dry_run"] = True
@@ -292,6 +311,9 @@ def run_rank(args) -> int:
     if dist is not None:
         fence()
         dist.destroy_process_group()
+    if any(timed_events):
+        log(f"FAILED: the timed region contained hand-off events {result['handoff_events_in_timed_region']}: its steps did not all run the measured path")
+        return 4
     return 0
 
 

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define ZN_ABI_VERSION 4
+#define ZN_ABI_VERSION 5
 
 enum zn_status {
   ZN_OK = 0,
@@ -142,15 +142,22 @@ int zn_sample_first(zn_handle h, zn_stream stream);
 int zn_decode_steps(zn_handle h, int32_t n, zn_stream stream);
 /* 1 if the decode step is currently replayed as an instantiated hipGraph, 0 if launched kernel by kernel. */
 int zn_graph_active(zn_handle h);
-/* 1 if the decode steps of the generation begun by zn_gen_begin run the persistent per-block chain kernel (batch 1 on a
- * model whose shapes it serves), 0 if every op is a launch of its own.  Both paths give bit-identical results. */
+/* 1 if the decode steps of the generation begun by zn_gen_begin run the persistent kernels (batch 1 on a model whose shapes they
+ * serve), 0 if every op is a launch of its own.  Both paths give bit-identical results at the Zonos-v0.1 shapes (same tiles, same
+ * summation order in every GEMV; ONE arithmetic for the decode attention on every path: scores on the matrix cores, contexts of one
+ * 512-key block accumulated in place, longer ones block by block with the partials combined in block order). */
 int zn_decode_path(zn_handle h);
-/* Which kernels served the decode step enqueued last: 0 = one launch per op, 1 = one attention launch + one persistent chain
- * launch per block, 2 / 3 = a whole-step persistent kernel (every block of the step in one launch; contexts up to 1024 keys):
- * 2 = two workgroup roles (attention / streaming, the default), 3 = three roles (attention / projection / bulk: zn_debug_tune(15, 4),
- * an experiment kept for the record - bit-identical, slower).
- * All give bit-identical results (the per-block path with its fused attention launch: zn_debug_tune(5, ...)). */
+/* Which kernels served the decode step enqueued last: 0 = one launch per op, 1 = one attention launch (two beyond 512 keys) + one
+ * persistent chain launch per block, 2 = the whole-step persistent kernel (every block of the step in one launch; contexts up to
+ * 6144 keys: attention workgroups per value slice up to 512 keys, per 512-key block beyond), 3 = its three-role variant (attention /
+ * projection / bulk: an experiment, compiled only with -DZN_WITH_STEP3 and then selected by zn_debug_tune(15, 4)).
+ * All give bit-identical results. */
 int zn_decode_path_detail(zn_handle h);
+/* Hand-off timeouts are never silent: out[0] = bounded in-kernel hand-off waits that gave up and were reported on this handle (each voids
+ * its generation; zn_all_stopped* returns the error), [1] generations begun, [2] batch-1 generations that ran the launches path because
+ * an earlier timeout had demoted the handle, [3] 1 while the handle is demoted, [4] times it was re-armed (automatically after 4 clean
+ * generations on the launches path, or by zn_debug_tune(8, 1)), [5] clean generations since the demotion.  n <= 6 values are written. */
+int zn_get_counters(zn_handle h, int64_t* out, int32_t n);
 /* Ends the generation begun by zn_gen_begin: releases the device's persistent-kernel tenancy (below) so that another handle's next
  * generation may take it.  The handle's state stays readable (zn_decode_path, zn_get_step_outputs); further steps need a new
  * zn_gen_begin.  Optional: zn_gen_begin of the same handle and zn_destroy release too. */
@@ -185,14 +192,13 @@ int zn_debug_token_override(zn_handle h, const int32_t* tokens_dev, int32_t call
  * position through the decode kernels (both reproduce the reference's rounding points). */
 int zn_debug_prefill_mode(zn_handle h, int32_t mode);
 /* Tuning hook: target workgroup count of a GEMV class (0 in_proj, 1 out_proj, 2 fc1, 3 fc2, 4 heads); 5: longest context of the
- * fused attention launch; 6: 1 = single-step graphs only; 8: 2 = per-op launches instead of the persistent chain kernel (also
- * ZN_CHAIN=0 at zn_create); 15: 2 = one chain launch per block instead of the whole-step kernel at batch 1, 4 = the three-role
- * experiment; 16: 2 = the ticketed sampler launch instead of the one-workgroup step tail at batch 1 (the default for greedy decoding), 3 = the one-workgroup tail also with a temperature.  Every path gives bit-identical
+ * fused attention launch (at most 512 keys, one block: beyond, every path walks the blocks with the split pass); 6: 1 = single-step
+ * graphs only; 8: 2 = per-op launches instead of the persistent kernels (also ZN_CHAIN=0 at zn_create), 1 = back to the default and
+ * re-arm a handle demoted by a hand-off timeout; 15: 2 = one chain launch per block instead of the whole-step kernel at batch 1 (4 = the
+ * three-role experiment where compiled in); 17: 2 = the whole-step kernel's key-block attention role also for contexts of one block; 16: 2 = the ticketed sampler launch instead of the one-workgroup step tail at batch 1 (the default for greedy decoding), 3 = the one-workgroup tail also with a temperature.  Every path gives bit-identical
  * results.  14: one-shot test hooks for the next generation (7: hand-off tags about to wrap; 9: the timeout word found set; 11: every
  * whole-step launch stops all its waves for 30 ms in block 2, as a paused device would).  Keys 0 .. 19. */
 int zn_debug_tune(zn_handle h, int32_t key, int32_t value);
-/* Test/benchmark hook: add `bias` to the codebook-0 EOS logit on every step (-inf suppresses EOS so that all
- * max_new_tokens+7 steps run, SURVEY.md §8d config 2). */
 /* Diagnostic: workgroup 0 of every persistent chain launch records s_memrealtime (100 MHz) stamps of its phases into
  * stamps_dev [2 * n_layer][32] (NULL = off); rows n_layer.. hold the fused attention launch's (start, length known, scores
  * issued, scores done, P.V done, reduced, stored).  Stamp order per launch: input ready; then per op: results ready, arrived,
@@ -202,6 +208,8 @@ int zn_debug_chain_stamps(zn_handle h, uint64_t* stamps_dev);
  * rotated queries, the gated MLP values m [rows][d_ff <= 4 d_model] (slots 3..6) and the residual stream after the attention
  * half (slot 7) into trace_dev [n_layer][8][rows][d_model] bf16 (NULL = off). */
 int zn_debug_trace(zn_handle h, void* trace_dev);
+/* Test/benchmark hook: add `bias` to the codebook-0 EOS logit on every step (-inf suppresses EOS so that all
+ * max_new_tokens+7 steps run, SURVEY.md §8d config 2). */
 int zn_debug_eos_bias(zn_handle h, float bias);
 
 /* The backbone plugin seam (zonos/backbone/__init__.py:24-36; TorchZonosBackbone.forward _torch.py:213-238,
@@ -219,7 +227,11 @@ int zn_op_backbone_forward(zn_handle h, const void* hidden_dev, void* out_dev, c
  * which: 0 = LayerNorm+fc1+SiLU-gate, 1 = fc2+residual, 2 = out_proj+residual, 3 = LayerNorm+heads,
  * 4 = LayerNorm+in_proj+RoPE+KV-append (into a scratch cache), 5 = the persistent post-attention chain of one block
  * (out_proj twice, LayerNorm+fc1+SiLU-gate, fc2, next block's LayerNorm+in_proj+RoPE+KV-append in ONE launch: batch 1 only;
- * bytes = those four weight matrices, out_proj counted once). */
+ * bytes = those four weight matrices, out_proj counted once), 6 = the whole-step kernel (every block of a decode step and the heads in
+ * ONE launch, batch 1 only) on scratch KV caches of its own holding `ctx` keys per row; bytes = every weight the step reads once
+ * (in_proj of block 0 excluded: it is a launch of its own) + K/V of ctx keys read and one row written per layer.
+ * rows: bits 0-7 = activation rows; bit 8 = keep streaming layer 0's weights (cache-hot variant); bits 16-30 = ctx for which == 6
+ * (0 = 450, the mean context of a 10 s utterance). */
 int zn_bench_kernel(zn_handle h, int32_t which, int32_t rows, int32_t iters, float* ms_per_launch,
                     double* bytes_per_launch, zn_stream stream);
 

@@ -69,6 +69,41 @@ def test_persistent_kernel_tenancy_is_one_owner_per_device(lib):
     assert lib.zn_tenant_try_claim(64, a) == 0 and lib.zn_tenant_try_claim(-1, a) == 0 and lib.zn_tenant_try_claim(0, None) == 0
 
 
+def test_handoff_timeout_policy_is_not_silent(monkeypatch, capsys):
+    """`Zonos._with_timeout_policy` (the only place a voided generation is repeated): with ZONOS_HIP_NO_TIMEOUT_RETRY=1 - what
+    tests/conftest.py sets for every test - a reported hand-off timeout is raised; without it the generation is repeated once, counted
+    and announced; a caller that has seen frames, or any other error, always gets the exception."""
+    import os
+    import types
+    from zonos_amd import _lib
+    from zonos_amd.model import Zonos
+    assert os.environ.get("ZONOS_HIP_NO_TIMEOUT_RETRY") == "1", "tests/conftest.py must disable the retry for every test"
+    m = types.SimpleNamespace(_repeats=0)
+    calls = []
+
+    def run():
+        calls.append(1)
+        if len(calls) == 1:
+            raise _lib.ZonosHipError("zn_all_stopped_end failed (status -3): decode chain: 1 hand-off wait(s) timed out - ...")
+        return "codes"
+    with pytest.raises(_lib.ZonosHipError, match="hand-off wait"):
+        Zonos._with_timeout_policy(m, run, caller_saw_frames=False)
+    assert m._repeats == 0 and len(calls) == 1
+    monkeypatch.delenv("ZONOS_HIP_NO_TIMEOUT_RETRY")
+    calls.clear()
+    assert Zonos._with_timeout_policy(m, run, caller_saw_frames=False) == "codes"
+    assert m._repeats == 1 and len(calls) == 2 and "repeating the generation" in capsys.readouterr().err
+    calls.clear()
+    with pytest.raises(_lib.ZonosHipError):
+        Zonos._with_timeout_policy(m, run, caller_saw_frames=True)
+    assert m._repeats == 1
+
+    def other():
+        raise _lib.ZonosHipError("zn_prefill failed (status -2): something else")
+    with pytest.raises(_lib.ZonosHipError, match="something else"):
+        Zonos._with_timeout_policy(m, other, caller_saw_frames=False)
+
+
 def test_persistent_kernels_use_no_scratch_and_fit_one_workgroup_per_cu(lib, tmp_path):
     """The persistent kernels' hand-offs wait on every workgroup of the grid: all 256 must be resident at once, whatever else the
     queue's scratch pool is doing.  Build-time facts checked on the shipped code object: no private segment (no scratch-wave slots
@@ -89,7 +124,7 @@ def test_persistent_kernels_use_no_scratch_and_fit_one_workgroup_per_cu(lib, tmp
                 g = lambda key: int(re.search(r"\.%s:\s+(\d+)" % key, k).group(1))
                 seen[name] = dict(scratch=g("private_segment_fixed_size"), spill=g("vgpr_spill_count"), vgpr=g("vgpr_count"),
                                   lds=g("group_segment_fixed_size"), threads=g("max_flat_workgroup_size"))
-    assert len(seen) == 7, sorted(seen)
+    assert len(seen) == 10, sorted(seen)                 # 6 chain instantiations + 4 whole-step ones (legacy attention role; key-block role for <= 6 / 8 / 12 blocks)
     for name, r in seen.items():
         assert r["scratch"] == 0 and r["spill"] == 0, (name, r)
         waves = r["threads"] // 64
@@ -159,15 +194,21 @@ def test_chain_kernel_handoffs_are_granules_and_sc1_sweeps(kernels_isa):
     """The persistent chain publishes 8-byte {tag, data} granules with ONE write-through store each (the data is the flag:
     Guideline 16 R2) and every load of handed-off bytes is an sc1 buffer load."""
     names = [n for n in kernels_isa if n.startswith("_Z12chain_kernel") or n.startswith("_Z11step_kernel")]
-    assert len(names) == 7                                                            # 6 chain instantiations + the whole-step kernel
+    assert len(names) == 10                                                           # 6 chain instantiations + 4 whole-step ones
     for n in names:
         ins = kernels_isa[n]
+        assert not any(l.startswith("scratch_") for l in ins), n
         sweeps = [l for l in ins if l.startswith("buffer_load_dwordx4")]
         if n.startswith("_Z11step_kernel"):
             # the attention workgroups' K / V prefetch reads cache rows written by EARLIER launches (the newest row comes through
-            # granules): plain buffer loads, 16 + 16 + 4 + 4 per issue site, two sites (kernel start, end of a block)
+            # granules): plain buffer loads, two issue sites (kernel start, end of a block); legacy role 16 + 16 + 4 + 4 per site (K of two
+            # blocks, a value slice of each), key-block role 16 + 16 (K and full-width V of one block)
             plain = [l for l in sweeps if " sc1" not in l]
-            assert len(plain) == 80, (n, len(plain))
+            legacy = re.match(r"_Z11step_kernelILi\d+ELi\d+ELi\d+ELi\d+ELi\d+ELi0EE", n) is not None
+            assert len(plain) == (80 if legacy else 64), (n, len(plain))
+            if not legacy:                                                            # e sums of the partials: one 8-byte granule per block
+                assert any(l.startswith("buffer_load_dwordx2") and " sc1" in l for l in ins), n
+                assert all(" sc1" in l for l in ins if l.startswith("buffer_load_dwordx2")), n
             sweeps = [l for l in sweeps if " sc1" in l]
             assert len(sweeps) >= 20, n
         assert sweeps and all(" sc1" in l for l in sweeps), n

@@ -41,3 +41,4 @@ def test_mel_filterbank_shape_and_coverage():
     assert np.all(np.diff(centres) >= 0) and centres[0] < 5 and centres[-1] > 240   # ordered, spanning 0 .. Nyquist
     peaks = fb.max(0).values
     assert float(peaks.max()) <= 1.0 + 1e-6                  # triangular filters with unit peak (norm=None)
+

@@ -63,20 +63,22 @@ def test_chain_generate_vs_oracle():
     assert worst <= 0.06
 
 
-@pytest.mark.parametrize("which", ["chain512", "full-chain", "full-step", "full-step3"])
+@pytest.mark.parametrize("which", ["chain512", "full-chain", "full-step", "full-step-kb"])
 def test_chain_is_bit_identical_to_the_launches_path(which):
     """Free-running greedy generation through the persistent kernels and through the per-op launches (zn_debug_tune(8, 2)).  At the
     Zonos-v0.1-transformer dimensions every path cuts every dot product the same way (fc2's K = 8192 in four quarters): equal
     codes and bit-equal logits at every step (200 steps: 8-step graphs, the fused attention arithmetic, hand-offs replayed
-    26 x 6 x 200 times), for one chain launch per block (zn_debug_tune(15, 2)), for the whole-step kernel (the default) and for its
-    three-role variant (zn_debug_tune(15, 4), an experiment kept for the record).  At
+    26 x 6 x 200 times), for one chain launch per block (zn_debug_tune(15, 2)), for the whole-step kernel (the default: 32 attention
+    workgroups, one per value slice) and for the whole-step kernel with its key-block attention role at one block (zn_debug_tune(17, 2):
+    8 attention workgroups, 248 streaming ones).  At
     d_model 512 the launches path keeps fc2's K = 2048 in one wave while the chain splits it in quarters - another summation
     order: equal codes, logits within one bf16 ulp of a hidden value."""
     cfg, seed, n = (synth.CHAIN_CFG, 55, 60) if which == "chain512" else (synth.FULL_CFG, 1234, 200)
     model, _ = build_model(cfg, seed, "cuda:0")
     eng = model.engine(1)
     cond = synth.conditioning(seed, "cond", 2, 24, cfg["d_model"])
-    eng.call("zn_debug_tune", 15, {"full-chain": 2, "full-step3": 4}.get(which, 1))
+    eng.call("zn_debug_tune", 15, {"full-chain": 2}.get(which, 1))
+    eng.call("zn_debug_tune", 17, 2 if which == "full-step-kb" else 1)
     try:
         a, la, pa = _run(model, cond, n, chain=True)
         b, lb, pb = _run(model, cond, n, chain=False)
@@ -94,18 +96,19 @@ def test_chain_is_bit_identical_to_the_launches_path(which):
             assert same > 0.98 and worst <= 0.04
         a2, la2, _ = _run(model, cond, n, chain=True)           # replay: no state survives a generation (counters, timeout word)
         assert torch.equal(a, a2) and torch.equal(la.view(torch.int32), la2.view(torch.int32))
+        assert eng.counters()["handoff_timeouts"] == 0
     finally:
         eng.call("zn_debug_tune", 15, 1)
+        eng.call("zn_debug_tune", 17, 1)
 
 
 def test_whole_step_kernel_is_bit_identical_to_the_chain_path():
-    """The whole-step kernel (csrc/zn_step_kernel.h: every block of the decode step in ONE launch, 32 weight-free attention
-    workgroups + 224 streaming workgroups; the default at batch 1) against one attention launch + one chain launch per block
-    (zn_debug_tune(15, 2)) at the Zonos-v0.1-transformer dimensions: free-running greedy codes equal and the logits of every step
-    bit-equal, over single-step launches (trace mode, 40 steps) and over 8-step graphs (300 steps: contexts 26 .. 333), with an
-    audio prefix (contexts 426 .. 700) and across the second 512-key block up to the kernel's limit (contexts 650 .. 1024, the
-    per-block path's fused attention launch raised to 1024 keys for the comparison; beyond the limit both runs take the per-block
-    path).  A hand-off timeout is an error (the bounded waits describe themselves: zn_last_error)."""
+    """The whole-step kernel (csrc/zn_step_kernel.h: every block of the decode step in ONE launch; the default at batch 1) against one
+    attention launch (two beyond 512 keys) + one chain launch per block (zn_debug_tune(15, 2)) at the Zonos-v0.1-transformer dimensions:
+    free-running greedy codes equal and the logits of every step bit-equal, over single-step launches (trace mode, 40 steps) and over
+    8-step graphs (300 steps: contexts 26 .. 333), with an audio prefix (contexts 426 .. 700, across the 512-key boundary where the
+    attention role changes from one workgroup per value slice to one per key block) and through the second and third block (contexts
+    650 .. 1050, logits of every step).  A hand-off timeout is an error (the bounded waits describe themselves: zn_last_error)."""
     cfg, seed = synth.FULL_CFG, 1234
     model, _ = build_model(cfg, seed, "cuda:0")
     eng = model.engine(1)
@@ -130,19 +133,64 @@ def test_whole_step_kernel_is_bit_identical_to_the_chain_path():
         for t15 in (2, 1):
             eng.call("zn_debug_tune", 15, t15)
             outs.append(model.generate(cond.to("cuda:0"), audio_prefix_codes=pre, max_new_tokens=268, sampling_params=GREEDY).cpu())
+            assert eng.lib.zn_decode_path_detail(eng.h) == (1 if t15 == 2 else 2)
         assert torch.equal(outs[0], outs[1])
         pre = torch.from_numpy(synth.randint(seed, "prefix2", (1, 9, 620), 1024)).to("cuda:0")
         outs = []
-        eng.call("zn_debug_tune", 5, 1024)
         for t15 in (2, 1):
             eng.call("zn_debug_tune", 15, t15)
             tr = {"logits": []}
             o = model.generate(cond.to("cuda:0"), audio_prefix_codes=pre, max_new_tokens=400, sampling_params=GREEDY, _trace=tr)
             outs.append((o.cpu(), torch.stack(tr["logits"]).cpu()))
+            assert eng.lib.zn_decode_path_detail(eng.h) == (1 if t15 == 2 else 2)
         assert torch.equal(outs[0][0], outs[1][0])
         assert torch.equal(outs[0][1].view(torch.int32), outs[1][1].view(torch.int32))
+        assert eng.counters()["handoff_timeouts"] == 0
     finally:
-        eng.call("zn_debug_tune", 5, 704)
+        eng.call("zn_debug_tune", 15, 1)
+        eng.call("zn_debug_eos_bias", 0.0)
+
+
+def test_whole_step_kernel_at_long_contexts_is_bit_identical_to_the_per_block_path():
+    """Contexts beyond 1024 keys (the reference's default call is 30 s = 2.6 k keys, `zonos/model.py:359`; BASELINE config 5 runs at
+    2.6 - 5.2 k): the whole-step kernel's key-block attention role (one workgroup per (row, kv head, 512-key block), K and full-width V of
+    the block in registers a block ahead, block maxima and partials exchanged as granules, the in-order combine of the split P.V pass)
+    against the per-block path (attn_scores_kernel + attn_pv_kernel<.., 2> + one chain launch per block, zn_debug_tune(15, 2)) and, for
+    the traced steps, against the launches path (zn_debug_tune(8, 2)): equal codes over the whole run (8-step graphs; contexts 1025 ..
+    2725, 2585 .. 5225 = config 5, and across the 3072- and 4096-key changes of instantiation, up to the kernel's 6144-key limit and
+    past it, where both runs take the per-block path) and bit-equal logits at every traced step."""
+    cfg, seed = synth.FULL_CFG, 1234
+    model, _ = build_model(cfg, seed, "cuda:0")
+    eng = model.engine(1)
+    cond = synth.conditioning(seed, "cond", 2, 24, cfg["d_model"]).to("cuda:0")
+    for prefix, new, traced in ((1000, 1700, 40), (2560, 2640, 24), (3060, 40, 40), (4080, 40, 40), (5590, 640, 16)):
+        _long_context_case(model, eng, cond, seed, prefix, new, traced)
+
+
+def _long_context_case(model, eng, cond, seed, prefix, new, traced):
+    pre = torch.from_numpy(synth.randint(seed, f"longprefix{prefix}", (1, 9, prefix), 1024)).to("cuda:0")
+    try:
+        eng.call("zn_debug_eos_bias", float("-inf"))
+        outs = []
+        for t15 in (2, 1):
+            eng.call("zn_debug_tune", 15, t15)
+            outs.append(model.generate(cond, audio_prefix_codes=pre, max_new_tokens=new, sampling_params=GREEDY).cpu())
+            want = 1 if (t15 == 2 or 24 + prefix + new + 8 > 6144) else 2
+            assert eng.lib.zn_decode_path_detail(eng.h) == want, (t15, eng.lib.zn_decode_path_detail(eng.h))
+        assert outs[0].shape[-1] == prefix + new and torch.equal(outs[0], outs[1])
+        logs = []
+        for t15, t8 in ((2, 1), (1, 1), (1, 2)):
+            eng.call("zn_debug_tune", 15, t15)
+            eng.call("zn_debug_tune", 8, t8)
+            tr = {"logits": []}
+            o = model.generate(cond, audio_prefix_codes=pre, max_new_tokens=traced, sampling_params=GREEDY, _trace=tr)
+            logs.append((o.cpu(), torch.stack(tr["logits"]).cpu()))
+        for o, lg in logs[1:]:
+            assert torch.equal(o, logs[0][0])
+            assert torch.equal(lg.view(torch.int32), logs[0][1].view(torch.int32))
+        assert eng.counters()["handoff_timeouts"] == 0
+    finally:
+        eng.call("zn_debug_tune", 8, 1)
         eng.call("zn_debug_tune", 15, 1)
         eng.call("zn_debug_eos_bias", 0.0)
 
@@ -191,11 +239,12 @@ def test_handoff_tags_restart_before_they_can_wrap():
     assert torch.equal(a, c) and torch.equal(la.view(torch.int32), lc.view(torch.int32))
 
 
-def test_a_reported_handoff_timeout_is_survived(capfd):
-    """A bounded hand-off wait that gives up voids the generation, makes the handle fall back to the launches path and - when the caller
-    has not seen any frame of it yet - `Zonos.generate` repeats the generation there.  zn_debug_tune(14, 9) sets the sticky timeout word
-    for the next generation (every wait gives up at once): the call must still return the right codes, say what happened, and leave the
-    handle on the launches path until zn_debug_tune(8, 1)."""
+def test_a_reported_handoff_timeout_is_survived(capfd, monkeypatch):
+    """A bounded hand-off wait that gives up voids the generation and demotes the handle to the launches path.  Under the test suite's
+    setting (ZONOS_HIP_NO_TIMEOUT_RETRY=1, tests/conftest.py) `Zonos.generate` raises; without it - and when the caller has not seen any
+    frame yet - it repeats the generation on the launches path, says so on stderr and counts it.  zn_debug_tune(14, 9) sets the sticky
+    timeout word for the next generation (every wait gives up at once).  The demotion is visible (zn_get_counters) and temporary: four
+    clean generations on the launches path, or zn_debug_tune(8, 1), re-arm the persistent kernels."""
     cfg, seed = synth.FULL_CFG, 1234
     model, _ = build_model(cfg, seed, "cuda:0")
     eng = model.engine(1)
@@ -203,15 +252,30 @@ def test_a_reported_handoff_timeout_is_survived(capfd):
     eng.call("zn_debug_eos_bias", float("-inf"))
     try:
         ref = model.generate(cond, max_new_tokens=40, sampling_params=GREEDY).cpu()
-        assert eng.lib.zn_decode_path_detail(eng.h) == 2
+        assert eng.lib.zn_decode_path_detail(eng.h) == 2 and eng.counters()["handoff_timeouts"] == 0
+        eng.call("zn_debug_tune", 14, 9)                        # the suite's setting: the timeout is an error
+        with pytest.raises(Exception, match="hand-off wait"):
+            model.generate(cond, max_new_tokens=40, sampling_params=GREEDY)
+        c = eng.counters()
+        assert c["handoff_timeouts"] == 1 and c["demoted"] == 1 and model.handoff_counters()["repeated_generations"] == 0
+        eng.call("zn_debug_tune", 8, 1)                         # re-arm at once
+        assert eng.counters()["demoted"] == 0 and eng.counters()["rearms"] == 1
+        monkeypatch.delenv("ZONOS_HIP_NO_TIMEOUT_RETRY")        # production behaviour: repeat once, loudly
         eng.call("zn_debug_tune", 14, 9)
         out = model.generate(cond, max_new_tokens=40, sampling_params=GREEDY).cpu()
         err = capfd.readouterr().err
         assert "hand-off wait" in err and "repeating the generation" in err
         assert torch.equal(out, ref)
         assert eng.lib.zn_decode_path(eng.h) == 0, "after a reported timeout the handle runs the launches path"
+        c = eng.counters()
+        assert c["handoff_timeouts"] == 2 and c["demoted"] == 1 and c["fallback_generations"] == 1 and model.handoff_counters()["repeated_generations"] == 1
+        for k in range(3):                                      # clean generations 2 .. 4 on the launches path (the repeat was the first)
+            assert torch.equal(model.generate(cond, max_new_tokens=40, sampling_params=GREEDY).cpu(), ref)
+            assert eng.lib.zn_decode_path(eng.h) == 0
+        again = model.generate(cond, max_new_tokens=40, sampling_params=GREEDY).cpu()     # the fifth: re-armed
+        c = eng.counters()
+        assert torch.equal(again, ref) and eng.lib.zn_decode_path_detail(eng.h) == 2 and c["demoted"] == 0 and c["rearms"] == 2 and c["fallback_generations"] == 4
         eng.call("zn_debug_tune", 14, 9)                        # with a callback the caller has seen frames: the error is raised, not hidden
-        eng.call("zn_debug_tune", 8, 1)
         with pytest.raises(Exception, match="hand-off wait"):
             model.generate(cond, max_new_tokens=40, sampling_params=GREEDY, callback=lambda f, s_, m: True)
         eng.call("zn_debug_tune", 8, 1)

@@ -50,6 +50,20 @@ def _teacher_forced(model, cond, max_new, inputs, prefix=None):
     return torch.stack(tr["logits"]).cpu().numpy()
 
 
+def _ref_variation(head):
+    """The reference's OWN variation at the Zonos-v0.1 dimensions (tests/golden/ref_thread_sensitivity.json, recorded by
+    tools/ref_thread_sensitivity.py from the real reference run with 1, 2, 3, 5 and 8 host threads; `head` = "gaussian" | "peaky"):
+    (largest teacher-forced |dlogit| between two thread counts, largest reference top-2 margin at which two thread counts disagreed on an
+    argmax).  Two runs whose logits lie within d of each other can only disagree on an argmax whose margin is <= 2 d: "decisive" in the
+    full-dims tests below means a reference margin above 2 d, and the HIP path's own |dlogit| against the 8-thread reference must not
+    exceed d - i.e. the HIP path is held to the reference's own reproducibility, not to a hand-picked tolerance."""
+    import json
+    import os
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_thread_sensitivity.json")) as f:
+        h = json.load(f)["heads"][head]
+    return float(h["largest_tf_abs_dlogit"]), float(h["largest_margin_of_any_disagreement"])
+
+
 def _teacher_forced_tokens(model, cond, g, dec_margin=0.5):
     """Teacher-forced greedy tokens over every step of a golden run: returns (fraction of (step, codebook) pairs whose
     HIP argmax equals the reference token, all pairs with reference margin > dec_margin equal?)."""
@@ -69,7 +83,8 @@ def _teacher_forced_tokens(model, cond, g, dec_margin=0.5):
           f"all decisive equal: {bool(agree[decisive].all())}")
     bad = np.argwhere(~agree)
     if len(bad):
-        print("  disagreements (call, b, cb, ref margin):", [(int(a), int(b), int(c), float(g["margin"][a, b, c])) for a, b, c in bad[:24]])
+        ms = sorted((float(g["margin"][a, b, c]) for a, b, c in bad), reverse=True)
+        print(f"  {len(bad)} disagreements; their reference margins, largest first: {ms[:12]}")
     return float(agree.mean()), bool(agree[decisive].all())
 
 
@@ -186,12 +201,13 @@ def test_forced_eos_output_length_matches_reference(golden_dir, tiny):
         eng.lib.zn_debug_force_eos(eng.h, -1)
 
 
-@pytest.mark.parametrize("fused_limit", [2048, 1], ids=["fused-launch", "two-pass"])
+@pytest.mark.parametrize("fused_limit", [512, 1], ids=["fused-launch", "two-pass"])
 def test_attention_decode_vs_cpu_sdpa(full, fused_limit):
     """zn_op_attn_decode vs torch CPU SDPA (the op the reference calls at _torch.py:415) on random bf16 q/K/V at
     L = 1..1500: bit-equal fraction must exceed 0.99 (the kernel reproduces the 512-key blocking, fexp_u20 /
     libm exp split, bf16 P and reciprocal-multiply of the CPU flash kernel; residual = fp32 summation order).
-    Both launch shapes: the fused one (scores in LDS via MFMA, short KV capacities) and scores + P.V passes."""
+    Both launch shapes: the fused one (scores in LDS via MFMA + pass 2 in one launch: KV capacities of one 512-key block) and the
+    scores launch + the per-block P.V pass with its in-order combine (every longer capacity; also forced for the short ones)."""
     import torch.nn.functional as F
     model, _ = full
     eng = model.engine(1)
@@ -199,25 +215,26 @@ def test_attention_decode_vs_cpu_sdpa(full, fused_limit):
     st = _lib.stream_ptr()
     gen = torch.Generator().manual_seed(0)
     for L in (1, 5, 16, 17, 31, 300, 512, 513, 530, 900, 1500):
+        cap = min(L + 3, 512) if (fused_limit > 1 and L <= 512) else 1504      # the launch shape follows the cache's capacity
         q = torch.randn(2, 16, 1, 128, generator=gen).to(torch.bfloat16)
-        kv = torch.randn(2, 1504, 2, 4, 128, generator=gen).to(torch.bfloat16)
+        kv = torch.randn(2, cap, 2, 4, 128, generator=gen).to(torch.bfloat16)
         ref = F.scaled_dot_product_attention(q, kv[:, :L, 0].transpose(1, 2), kv[:, :L, 1].transpose(1, 2), enable_gqa=True)
         qd = q.transpose(1, 2).reshape(2, 2048).contiguous().to("cuda:0")
         kvd = kv.to("cuda:0")
         lengths = torch.full((2,), L - 1, dtype=torch.int32, device="cuda:0")
         out = torch.empty(2, 2048, dtype=torch.bfloat16, device="cuda:0")
-        eng.call("zn_op_attn_decode", qd.data_ptr(), kvd.data_ptr(), 1504, lengths.data_ptr(), None, out.data_ptr(), 2, st)
+        eng.call("zn_op_attn_decode", qd.data_ptr(), kvd.data_ptr(), cap, lengths.data_ptr(), None, out.data_ptr(), 2, st)
         torch.cuda.synchronize()
         got = out.cpu().view(2, 16, 128)
         r = ref[:, :, 0]
         eq = float((got.view(torch.int16) == r.contiguous().view(torch.int16)).float().mean())
         print(f"\n[attn L={L}] bit-equal {eq:.5f} max|d| {(got.float() - r.float()).abs().max().item():.3g}")
         assert eq > 0.99, (L, eq)
-    eng.call("zn_debug_tune", 5, 704)
+    eng.call("zn_debug_tune", 5, 512)
 
 
 def test_attention_long_context_split_pass_vs_cpu_sdpa(full):
-    """KV capacities above 1408 run the P.V pass as one workgroup per 512-key block with a ticketed in-order combine
+    """KV capacities above 512 run the P.V pass as one workgroup per 512-key block with a ticketed in-order combine
     (acc = acc * f_j + pv_j, the reference's recurrence): same bar as the other launch shapes, contexts up to 4600 keys."""
     import torch.nn.functional as F
     model, _ = full
@@ -304,14 +321,14 @@ def test_attention_other_group_sizes_vs_cpu_sdpa(n_kv):
         refd = F.scaled_dot_product_attention(q[:, :, -1:], k, v, enable_gqa=True)[:, :, 0]
         qd1 = q[:, :, -1].reshape(2, 1024).contiguous().to("cuda:0")
         lengths = torch.full((2,), S - 1, dtype=torch.int32, device="cuda:0")
-        for fused_limit in (2048, 1):
+        for fused_limit in (512, 1):                                     # S = 37, 300: the fused launch and the two passes; 700: two passes
             eng.call("zn_debug_tune", 5, fused_limit)
             o1 = torch.empty(2, 1024, dtype=torch.bfloat16, device="cuda:0")
             eng.call("zn_op_attn_decode", qd1.data_ptr(), kvd.data_ptr(), cap, lengths.data_ptr(), None, o1.data_ptr(), 2, st)
             torch.cuda.synchronize()
             eqd = float((o1.cpu().view(2, 8, 128).view(torch.int16) == refd.contiguous().view(torch.int16)).float().mean())
             assert eqd > 0.99, (n_kv, S, fused_limit, eqd)
-    eng.call("zn_debug_tune", 5, 704)
+    eng.call("zn_debug_tune", 5, 512)
 
 
 def test_layer0_decode_vs_reference_block(golden_dir, full):
@@ -401,7 +418,9 @@ def test_full_dims_teacher_forced_vs_reference(golden_dir, full):
     cond = synth.conditioning(1234, "cond", 2, int(g["l_c"]), 2048)
     got = _teacher_forced(model, cond, int(g["max_new"]), g["inputs"])
     steps = g["logit_steps"]
-    _compare_logits(got[steps], g["logits"], g["margin"][steps], "full", tol=0.1)
+    spread, flip = _ref_variation("gaussian")
+    print(f"\n[full] the reference's own variation across host thread counts: max |dlogit| {spread}, largest margin of an argmax flip {flip}")
+    _compare_logits(got[steps], g["logits"], g["margin"][steps], "full", tol=spread)       # |dlogit| <= the reference's own spread; argmax equal beyond 2 x it
     # greedy tokens of every step vs the reference's tokens, on decisive margins
     ref_tok = g["tokens"].astype(np.int64)              # [calls, 1, 9]
     bias_free = got.copy()
@@ -414,9 +433,11 @@ def test_full_dims_teacher_forced_vs_reference(golden_dir, full):
             lg = zo.repetition_penalty(lg, hist, 3.0, 2)
         ga.append(lg.argmax(-1).numpy())
     ga = np.stack(ga)
-    decisive = g["margin"] > 0.2
+    decisive = g["margin"] > 2 * spread
     agree = (ga == ref_tok)
-    print(f"\n[full] greedy tokens equal on {agree.mean():.4f} of all (step,codebook); decisive pairs {decisive.mean():.3f}")
+    worst = float(g["margin"][~agree].max()) if (~agree).any() else 0.0
+    print(f"\n[full] greedy tokens equal on {agree.mean():.4f} of all (step,codebook); decisive (margin > {2 * spread}) pairs {decisive.mean():.3f}; "
+          f"largest reference margin of a HIP-vs-reference flip {worst} (the reference against itself: {flip})")
     assert agree[decisive].all()
 
 
@@ -433,8 +454,11 @@ def test_full_dims_free_running(golden_dir, full):
     try:
         model.fused_heads.weight.data.copy_(heads.to("cuda:0"))
         _free_run(model, cond, gp, "full peaky")
-        # peaky logits reach |l| ~ 100-200 where one bf16 ulp is 0.5-1.0: "decisive" = margin > 4.0 (>= 4 ulps)
-        agree, dec = _teacher_forced_tokens(model, cond, gp, dec_margin=4.0)
+        # peaky logits reach |l| ~ 100-200 where one bf16 ulp is 0.5-1.0; the reference itself, run with another thread count, moves them by
+        # up to `spread` and flips argmaxes at margins up to `flip`: "decisive" = margin > 2 x spread
+        spread, flip = _ref_variation("peaky")
+        print(f"\n[full peaky] the reference's own variation: max |dlogit| {spread}, largest margin of an argmax flip {flip}")
+        agree, dec = _teacher_forced_tokens(model, cond, gp, dec_margin=2 * spread)
     finally:
         model.fused_heads.weight.data.copy_(keep)
     assert agree > 0.95 and dec, (agree, dec)

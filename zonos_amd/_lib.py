@@ -12,7 +12,7 @@ import sys
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ZONOS_HIP_LIB") or os.path.join(_HERE, "libzonos_hip.so")   # the override selects an experimental build (A/B runs)
 
-ZN_ABI_VERSION = 4
+ZN_ABI_VERSION = 5
 
 
 class ZonosHipError(RuntimeError):
@@ -69,6 +69,7 @@ SIGNATURES = {
     "zn_tenant_release": (C.c_int, [C.c_int32, C.c_void_p]),
     "zn_decode_path": (C.c_int, [C.c_void_p]),
     "zn_decode_path_detail": (C.c_int, [C.c_void_p]),
+    "zn_get_counters": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.c_int32]),
     "zn_all_stopped": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.c_void_p]),
     "zn_all_stopped_begin": (C.c_int, [C.c_void_p, C.c_void_p]),
     "zn_all_stopped_end": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
@@ -118,14 +119,14 @@ def load() -> C.CDLL:
         return _lib
     path = os.environ.get("ZONOS_HIP_LIB_VARIANT")      # development only (tools/build_variants.py: A/B of compile-time kernel parameters)
     if path:
-        path = os.path.join(os.path.dirname(os.path.dirname(LIB_PATH)), "build", "variants", f"libzonos_hip_{path}.so")
+        path = os.path.join(os.path.dirname(_HERE), "build", "variants", f"libzonos_hip_{path}.so")
         if not os.path.exists(path):
             raise ZonosHipError(f"{path} not found (ZONOS_HIP_LIB_VARIANT)")
         print(f"[zonos_amd] loading variant library {path}", file=sys.stderr, flush=True)
     else:
         path = LIB_PATH
-    if not os.path.exists(LIB_PATH):
-        raise ZonosHipError(f"{LIB_PATH} not found: build it with `python -m zonos_amd.build` "
+    if not os.path.exists(path):
+        raise ZonosHipError(f"{path} not found: build it with `python -m zonos_amd.build` "
                             "(the HIP library is the only execution path; there is no CPU fallback)")
     import torch  # noqa: F401  -- must come first: the library shares torch's HIP runtime (same libamdhip64 SONAME);
     #                      loading /opt/rocm's copy before torch's leaves two runtimes in the process

@@ -223,6 +223,13 @@ class HipEngine:
         with self.lock, torch.cuda.device(self.device):
             _lib.check(getattr(self.lib, name)(self.h, *args), self.h, name)
 
+    def counters(self) -> dict:
+        """zn_get_counters: hand-off timeouts reported, generations, generations that ran the launches path because of a demotion, ..."""
+        buf = (C.c_int64 * 6)()
+        self.call("zn_get_counters", buf, 6)
+        keys = ("handoff_timeouts", "generations", "fallback_generations", "demoted", "rearms", "clean_since_demotion")
+        return dict(zip(keys, (int(v) for v in buf)))
+
     def stream(self) -> int:
         """The caller's current torch stream on this engine's device."""
         return torch.cuda.current_stream(self.device).cuda_stream

@@ -4,7 +4,9 @@
 #include "zn_decode_kernels.h"
 #include "zn_chain_kernel.h"
 #include "zn_step_kernel.h"
-#include "zn_step3_kernel.h"
+#ifdef ZN_WITH_STEP3
+#include "zn_step3_kernel.h"     // the three-role whole-step experiment: not in the default library
+#endif
 #include "zn_prefill_kernels.h"
 #include "zn_cond_kernels.h"
 #include "zn_mamba_kernels.h"
@@ -21,6 +23,7 @@ static thread_local std::string g_create_err;
 #define ZN_GRAPH_STEPS 8
 #define ZN_G16_PART_BYTES ((size_t)8 << 20)
 #define ZN_G16_MAX_GROUPS 1024
+#define ZN_REARM_AFTER 4
 
 struct zn_handle_s {
   zn_config cfg;
@@ -41,6 +44,10 @@ struct zn_handle_s {
   // the launch epoch (tag), the second residual-stream buffer (blocks alternate h->x / ch_x2)
   unsigned long long *ch_gy1 = nullptr, *ch_gx1 = nullptr, *ch_gx2 = nullptr, *ch_gm = nullptr;
   unsigned long long *ch_gqkv = nullptr, *ch_ga = nullptr;   // whole-step kernel: q | k | v of the next block, attention output
+  unsigned long long *ch_gbmax = nullptr, *ch_gpart = nullptr;   // key-block attention role: per-block score maxima and P.V partials (zn_step_kernel.h)
+  int stack_nbk = 0;                         // attention role of the whole-step launches being enqueued: 0 = legacy (one workgroup per value slice), n >= 1 = one per key block, n blocks
+  int graph_nbk[8] = {};                     // ... that a captured graph was built with
+  bool stackv_ok[4] = {};                    // whole-step kernel instantiations that fit this model and device (stack_variant_ok)
   StackLayer* stack_layers = nullptr;        // device table [n_layer], rebuilt by zn_gen_begin (it holds the KV cache pointers)
   bool use_stack = false, stack_ok = false, stack_checked = false, stack3_ok = false;   // stack3: the three-role whole-step kernel (zn_step3_kernel.h)                    // the steps being enqueued run the whole-step kernel
   unsigned* ch_epoch = nullptr;
@@ -55,6 +62,13 @@ struct zn_handle_s {
   unsigned long long* at_stamps = nullptr;   // diagnostic: [n_layer][8] timeline of the fused attention launch (second half of the chain stamp buffer)
   unsigned long long* ch_stamps = nullptr;   // diagnostic: [n_layer][32] timeline stamps of workgroup 0 (zn_debug_chain_stamps)
   int device = 0;              // the HIP device the handle was created on
+  // hand-off timeouts (zn_get_counters): a reported timeout demotes the handle to the launches path (no in-launch hand-offs) until ZN_REARM_AFTER
+  // generations in a row have completed there cleanly, or zn_debug_tune(8, 1) re-arms it at once
+  bool demoted = false;
+  int clean_since_demotion = 0;
+  long long n_timeouts = 0, n_generations = 0, n_fallback_generations = 0, n_rearms = 0;
+  bool gen_timed_out = false;         // this generation reported a hand-off timeout
+  hipStream_t gen_stream = nullptr;   // the stream the generation's steps were last enqueued on (handoff_timeout drains it)
   bool persist_ok = true;      // this handle may launch the persistent kernels (zn_gen_begin: it holds the device's tenancy, or nobody competes)
   int ch_variant = 0;          // 0 = shapes do not fit (launches path), 1 = <4,1,8,4,2> (Zonos-v0.1 dims), 2 = <1,1,2,1,1> (d_model 512)
   float* g16_part = nullptr;   // gemm16s_kernel: split-K partial tiles
@@ -89,7 +103,7 @@ struct zn_handle_s {
   int force_eos_step = -1;
   float eos_bias = 0.f;
   unsigned dbg_pause = 0;           // ChainArgs::dbg_pause of this generation's whole-step launches
-  int tune[20] = {256, 512, 512, 1024, 512, 704, 2, 2, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // target workgroups: in_proj, out_proj, fc1, fc2, heads; [5] longest context of the fused attention launch; [6] > 1: multi-step graphs; [7] > 1: LDS-staged small-M projections; [8] = 2: no persistent chain kernel (five launches per block instead); [9]: KV capacity above which the P.V pass splits per block (0 = 1408); [10] = 2: VALU prefill attention; [11] = 2: no in-workgroup-split small-M kernel
+  int tune[20] = {256, 512, 512, 1024, 512, 512, 2, 2, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // target workgroups: in_proj, out_proj, fc1, fc2, heads; [5] longest context of the fused attention launch (<= 512); [6] > 1: multi-step graphs; [7] > 1: LDS-staged small-M projections; [8] = 2: no persistent chain kernel (five launches per block instead); [9]: unused (was: KV capacity above which the P.V pass splits per block; it now always does beyond one block); [10] = 2: VALU prefill attention; [11] = 2: no in-workgroup-split small-M kernel
   const int* tok_override = nullptr;
   int tok_override_calls = 0;
   hipStream_t cap_stream = nullptr;
@@ -168,7 +182,7 @@ extern "C" int zn_destroy(zn_handle h) {
   if (!h) return ZN_OK;
   (void)zn_tenant_release(h->device, h);
   free_graph(h);
-  void* ptrs[] = {h->emb_tables_dev, h->x, h->q, h->o1, h->mbuf, h->nbuf, h->logits_raw, h->last_logits, h->tok_raw, h->scores, h->cmax, h->pv_part, h->pv_tickets, h->pf_x, h->pf_n, h->pf_qkv, h->pf_a, h->pf_u, h->pf_m, h->pf_res, h->pf_zx, h->pf_xbc, h->pf_y, h->pf_g, h->qkv_tmp, h->fw_lengths, h->st, h->remaining, h->stopping, h->res, h->hn, h->m_zx, h->m_xbc, h->m_y, h->m_g, h->m_vg, h->g16_part, h->g16_tickets, h->ch_gy1, h->ch_gx1, h->ch_gx2, h->ch_gm, h->ch_epoch, h->ch_x2, h->x_emb, h->tail_ticket, h->ch_gqkv, h->ch_ga, h->stack_layers, h->ch_diag};
+  void* ptrs[] = {h->emb_tables_dev, h->x, h->q, h->o1, h->mbuf, h->nbuf, h->logits_raw, h->last_logits, h->tok_raw, h->scores, h->cmax, h->pv_part, h->pv_tickets, h->pf_x, h->pf_n, h->pf_qkv, h->pf_a, h->pf_u, h->pf_m, h->pf_res, h->pf_zx, h->pf_xbc, h->pf_y, h->pf_g, h->qkv_tmp, h->fw_lengths, h->st, h->remaining, h->stopping, h->res, h->hn, h->m_zx, h->m_xbc, h->m_y, h->m_g, h->m_vg, h->g16_part, h->g16_tickets, h->ch_gy1, h->ch_gx1, h->ch_gx2, h->ch_gm, h->ch_epoch, h->ch_x2, h->x_emb, h->tail_ticket, h->ch_gqkv, h->ch_ga, h->ch_gbmax, h->ch_gpart, h->stack_layers, h->ch_diag};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (h->done_host) (void)hipHostFree(h->done_host);
   if (h->stop_event) (void)hipEventDestroy(h->stop_event);
@@ -269,6 +283,9 @@ extern "C" int zn_create(const zn_config* cfg, const zn_weights* w, int32_t max_
   { const size_t nqkv = (size_t)(c.n_heads + 2 * c.n_heads_kv) * hd;
     ZC(hipMalloc(&h->ch_gqkv, R * (nqkv / 2 + 1) * 8)); ZC(hipMemset(h->ch_gqkv, 0, R * (nqkv / 2 + 1) * 8));
     ZC(hipMalloc(&h->ch_ga, R * (c.d_model / 2) * 8)); ZC(hipMemset(h->ch_ga, 0, R * (c.d_model / 2) * 8));
+    { const size_t nbm = (size_t)2 * c.n_heads_kv * ZN_SK_KB_MAXNB * 4 * 8, npt = (size_t)2 * c.n_heads_kv * ZN_SK_KB_MAXNB * ZN_SK_KB_PSZ * 8;
+      ZC(hipMalloc(&h->ch_gbmax, nbm)); ZC(hipMemset(h->ch_gbmax, 0, nbm));
+      ZC(hipMalloc(&h->ch_gpart, npt)); ZC(hipMemset(h->ch_gpart, 0, npt)); }
     ZC(hipMalloc(&h->stack_layers, (size_t)c.n_layer * sizeof(StackLayer))); }
   ZC(hipMalloc(&h->ch_gm, R * (c.d_ff / 2 + 1) * 8));
   ZC(hipMemset(h->ch_gm, 0, R * (c.d_ff / 2 + 1) * 8));
@@ -470,9 +487,14 @@ static int run_gemv(zn_handle h, GemvArgs a, int rows, int target_blocks, hipStr
   return ZN_OK;
 }
 
-// fused attention launch iff no row can hold more than tune[5] keys after this call (LDS score buffer: ZN_AFUSED_MAX)
+// ONE arithmetic for the decode attention on every path (launches, per-block chain, whole-step kernels): scores on the matrix cores in
+// one summation order; contexts of one 512-key block (the reference's block size) are walked in place, longer ones block by block with
+// the blocks' unnormalised partials combined by the reference's recurrence acc = acc * f_j + pv_j in block order (attn_pv_kernel<.., 2>,
+// the key-block attention role of zn_step_kernel.h).  So the fused launch (scores + pass 2 in one launch, in-place accumulation over the
+// blocks) serves contexts up to 512 keys only: tune[5] may lower that limit (tests), never raise it.
+#define ZN_AFUSED_LIMIT 512
 static bool attn_fused_for(zn_handle h, int keys_upper_bound) {
-  const int lim = h->tune[5] < ZN_AFUSED_MAX ? h->tune[5] : ZN_AFUSED_MAX;
+  const int lim = h->tune[5] < ZN_AFUSED_LIMIT ? h->tune[5] : ZN_AFUSED_LIMIT;
   return keys_upper_bound <= lim;
 }
 
@@ -482,8 +504,7 @@ static int launch_attn_g(const AttnArgs& a, int G, dim3 grid, bool fused, hipStr
 #define ZN_ATTN_CASE(GG) case GG: \
     if (fused) { hipLaunchKernelGGL((attn_pv_kernel<HD, GG, 1>), dim3((HD / 32) * grid.y * grid.z), dim3(512), 0, s, a); return 0; } \
     hipLaunchKernelGGL((attn_scores_kernel<HD, GG>), grid, dim3(256), 0, s, a); \
-    if (a.nbcap > 0) { hipLaunchKernelGGL((attn_pv_kernel<HD, GG, 2>), dim3(HD / 32, grid.y, grid.z * a.nbcap), dim3(512), 0, s, a); return 0; } \
-    hipLaunchKernelGGL((attn_pv_kernel<HD, GG, 0>), dim3(HD / 32, grid.y, grid.z), dim3(512), 0, s, a); return 0;
+    hipLaunchKernelGGL((attn_pv_kernel<HD, GG, 2>), dim3(HD / 32, grid.y, grid.z * a.nbcap), dim3(512), 0, s, a); return 0;
     ZN_ATTN_CASE(1) ZN_ATTN_CASE(2) ZN_ATTN_CASE(4) ZN_ATTN_CASE(8)
 #undef ZN_ATTN_CASE
   }
@@ -518,11 +539,11 @@ static int run_attention(zn_handle h, const bf16_t* q, const bf16_t* kv, int max
   a.scores = h->scores; a.cmax = h->cmax; a.out = out; a.rows = rows; a.stamps = stamps;
   const int hd = h->hd;
   dim3 grid((max_len + ZN_ACHUNK - 1) / ZN_ACHUNK, c.n_heads_kv, rows);
-  // one fused launch for short contexts (the caller bounds the context: h->attn_fused), two passes beyond
+  // one fused launch for contexts of one 512-key block (the caller bounds the context: h->attn_fused); beyond: scores, then the P.V pass
+  // with one workgroup per (slice, kv head, row, 512-key block) and the ticketed in-order combine
   const bool fused = h->attn_fused;
-  // long KV capacities: the P.V pass runs one workgroup per 512-key block (tune[9] = capacity from which it does; 0 = 1408)
-  const int split_from = h->tune[9] > 0 ? h->tune[9] : 1408;   // measured crossover: ~1400 keys of capacity
-  a.part = h->pv_part; a.tickets = h->pv_tickets; a.nbcap = (!fused && max_len > split_from && h->lcap / 512 <= 32) ? h->lcap / 512 : 0;
+  a.part = h->pv_part; a.tickets = h->pv_tickets; a.nbcap = (max_len + 511) / 512;
+  if (a.nbcap > 32) ZN_FAIL(h, ZN_ERR_ARG, "attention: %d keys of capacity exceed the 32 blocks the split pass combines", max_len);
   int r2 = hd == 128 ? launch_attn_g<128>(a, h->G, grid, fused, s) : hd == 64 ? launch_attn_g<64>(a, h->G, grid, fused, s)
                                                                              : launch_attn_g<32>(a, h->G, grid, fused, s);
   if (r2) ZN_FAIL(h, ZN_ERR_UNSUPPORTED, "attention: unsupported group %d", h->G);
@@ -589,7 +610,7 @@ static int layer_decode(zn_handle h, int li, bf16_t* x, bf16_t* kv, int max_len,
 
 // The persistent chain serves the step when the model fits an instantiation, at batch 1 (two rows), unless switched off
 // (zn_debug_tune(8, 2), or ZN_CHAIN=0 in the environment at zn_create): 1.07 vs 1.16 ms per decode step at the Zonos-v0.1 dimensions.
-static bool chain_active(zn_handle h, int rows) { return h->ch_variant != 0 && rows == 2 && h->tune[8] != 2 && h->persist_ok; }
+static bool chain_active(zn_handle h, int rows) { return h->ch_variant != 0 && rows == 2 && h->tune[8] != 2 && !h->demoted && h->persist_ok; }
 
 // The chain never updates the residual stream in place (zn_chain_kernel.h): block li reads it from one buffer and leaves it
 // in the other.
@@ -642,33 +663,55 @@ static int launch_chain(zn_handle h, int li, const std::vector<const void*>& kv_
   return ZN_OK;
 }
 
-// Whole-step kernel (zn_step_kernel.h): batch 1 at the Zonos-v0.1 shapes, contexts up to ZN_SK_MAXKEYS keys: in_proj(0) + ONE launch per
-// decode step.  The default at batch 1; zn_debug_tune(15, 2) or ZN_STACK=0 in the environment at zn_create selects one chain launch per block.
-#define ZN_SK_T 4, 2, 10, 5, 6
-static bool stack_shapes_ok(zn_handle h) {
+// Whole-step kernel (zn_step_kernel.h): batch 1 at the Zonos-v0.1 shapes: in_proj(0) + ONE launch per decode step.  The default at batch 1;
+// zn_debug_tune(15, 2) or ZN_STACK=0 in the environment at zn_create selects one chain launch per block.  Instantiations (static tile schedules
+// for the streaming workgroups the attention role leaves):
+//   variant 0  <4, 2, 10, 5, 6, 0>  legacy attention role, 32 workgroups (one per value slice): contexts of one 512-key block
+//   variant 1  <4, 2, 10, 5, 6, 6>  key-block attention role, 1 .. 6 blocks  (8 .. 48 attention workgroups: contexts up to 3072 keys)
+//   variant 2  <4, 2, 11, 6, 7, 8>  7 .. 8 blocks   (up to 4096 keys)
+//   variant 3  <4, 2, 13, 7, 8, 12>  9 .. 12 blocks  (up to 6144 keys); longer contexts take the per-block path
+#define ZN_SK_T0 4, 2, 10, 5, 6, 0
+#define ZN_SK_T1 4, 2, 10, 5, 6, 6
+#define ZN_SK_T2 4, 2, 11, 6, 7, 8
+#define ZN_SK_T3 4, 2, 13, 7, 8, 12
+static int stack_variant_of(int mode) { return mode <= 0 ? 0 : mode <= 6 ? 1 : mode <= 8 ? 2 : 3; }
+template <int NCH, int T_OUT, int T_FC1, int T_FC2, int T_IN, int ATT>
+static bool stack_variant_ok(zn_handle h, int natt) {
   const zn_config& c = h->cfg;
-  if (h->ch_variant != 1 || h->hd != 128 || c.n_heads_kv < 1 || c.n_heads != 4 * c.n_heads_kv) return false;
-  const int natt = 2 * c.n_heads_kv * (h->hd / 32), nsw = ZN_CH_GRID - natt;
+  const int nsw = ZN_CH_GRID - natt;
   if (nsw < 64) return false;
   auto most = [&](int units) { return (units + nsw - 1) / nsw; };                     // units of the fullest streaming workgroup
   const int nqkv = (c.n_heads + 2 * c.n_heads_kv) * h->hd;
   const int p_out = most(c.d_model / 2), p_fc1 = 2 * most(c.d_ff / 2), p_qkv = most((nqkv + 1) / 2), p_hd = most((c.n_codebooks * c.vocab_head + 1) / 2);
-  if (p_out > ZN_SK_CW * 2 || p_out > 5 || p_fc1 > ZN_SK_CW * 10 || p_qkv > ZN_SK_CW * 6 || p_hd > ZN_SK_CW * 6) return false;   // the static schedule <4, 2, 10, 5, 6>
-  if (p_out * 2 > 64 || p_fc1 > 64 || p_qkv * 2 > 64 || p_hd * 2 > 64 || nqkv % 2) return false;                               // one epilogue lane per (unit, row)
+  if (p_out > ZN_SK_CW * T_OUT || p_out > T_FC2 || p_fc1 > ZN_SK_CW * T_FC1 || p_qkv > ZN_SK_CW * T_IN || p_hd > ZN_SK_CW * T_IN) return false;   // the static schedule
+  if (p_out * 2 > 64 || p_out * 4 > 64 || p_fc1 > 64 || p_qkv * 2 > 64 || p_hd * 2 > 64 || nqkv % 2) return false;              // one epilogue lane per (unit, row); s_res slots
   // every workgroup of the grid must be resident at once (the hand-offs wait on all of them): one per CU by its LDS, no scratch
+  const void* fn = (const void*)step_kernel<NCH, T_OUT, T_FC1, T_FC2, T_IN, ATT>;
   int dev = 0, n_cus = 0, per_cu = 0;
   if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) { (void)hipGetLastError(); return false; }
-  if (hipFuncSetAttribute((const void*)step_kernel<ZN_SK_T>, hipFuncAttributeMaxDynamicSharedMemorySize, ZN_SK_DYN_LDS) != hipSuccess) { (void)hipGetLastError(); return false; }
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, step_kernel<ZN_SK_T>, ZN_SK_THREADS, ZN_SK_DYN_LDS) != hipSuccess) { (void)hipGetLastError(); return false; }
+  if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, ZN_SK_DYN_LDS) != hipSuccess) { (void)hipGetLastError(); return false; }
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, step_kernel<NCH, T_OUT, T_FC1, T_FC2, T_IN, ATT>, ZN_SK_THREADS, ZN_SK_DYN_LDS) != hipSuccess) { (void)hipGetLastError(); return false; }
   hipFuncAttributes fa{};
-  if (hipFuncGetAttributes(&fa, (const void*)step_kernel<ZN_SK_T>) != hipSuccess) { (void)hipGetLastError(); return false; }
+  if (hipFuncGetAttributes(&fa, fn) != hipSuccess) { (void)hipGetLastError(); return false; }
   return per_cu >= 1 && n_cus >= ZN_CH_GRID && fa.localSizeBytes == 0;
 }
-// The three-role whole-step kernel (zn_step3_kernel.h: attention / projection / bulk workgroups): opt-in, zn_debug_tune(15, 4); bit-identical, measured slower.
+static bool stack_shapes_ok(zn_handle h) {
+  const zn_config& c = h->cfg;
+  if (h->ch_variant != 1 || h->hd != 128 || c.n_heads_kv < 1 || c.n_heads != 4 * c.n_heads_kv) return false;
+  const int npairs = 2 * c.n_heads_kv;
+  h->stackv_ok[0] = stack_variant_ok<ZN_SK_T0>(h, npairs * (h->hd / 32));
+  h->stackv_ok[1] = stack_variant_ok<ZN_SK_T1>(h, npairs * 6);
+  h->stackv_ok[2] = stack_variant_ok<ZN_SK_T2>(h, npairs * 8);
+  h->stackv_ok[3] = stack_variant_ok<ZN_SK_T3>(h, npairs * ZN_SK_KB_MAXNB);
+  return h->stackv_ok[0] || h->stackv_ok[1];
+}
+#ifdef ZN_WITH_STEP3
+// The three-role whole-step kernel (zn_step3_kernel.h: attention / projection / bulk workgroups): a measured experiment (bit-identical, slower),
+// compiled only with -DZN_WITH_STEP3 and then selected by zn_debug_tune(15, 4).
 #define ZN_S3_T 4, 13, 7, 8
 static bool stack3_shapes_ok(zn_handle h) {
   const zn_config& c = h->cfg;
-  if (!h->stack_ok) return false;                            // same model family, same attention role
+  if (!h->stackv_ok[0]) return false;                        // same model family, same attention role
   const int natt = 2 * c.n_heads_kv * (h->hd / 32), nbw = ZN_CH_GRID - natt - ZN_S3_NPROJ;
   const int nqkv = (c.n_heads + 2 * c.n_heads_kv) * h->hd;
   if (nbw < 64 || c.n_layer < 2) return false;
@@ -684,16 +727,33 @@ static bool stack3_shapes_ok(zn_handle h) {
   if (hipFuncGetAttributes(&fa, (const void*)step3_kernel<ZN_S3_T>) != hipSuccess) { (void)hipGetLastError(); return false; }
   return per_cu >= 1 && fa.localSizeBytes == 0;
 }
-static bool stack_active(zn_handle h, int rows, int keys_upper_bound) {
-  return chain_active(h, rows) && h->tune[15] != 2 && keys_upper_bound <= ZN_SK_MAXKEYS && h->stack_ok;
+static bool stack3_selected(zn_handle h) { return h->stack3_ok && h->tune[15] == 4; }
+#else
+static bool stack3_shapes_ok(zn_handle) { return false; }
+static bool stack3_selected(zn_handle) { return false; }
+#endif
+// The attention role a whole-step launch covering `keys_upper_bound` keys would run with: -1 = the whole-step kernel does not serve the step
+// (the per-block path does), 0 = legacy role, n >= 1 = key-block role with n blocks.  One 512-key block: the legacy role by default
+// (zn_debug_tune(17, 2): the key-block role there too; both give the same bits).  Longer contexts: the key-block role - its block-by-block
+// combine is the library's definition of the attention beyond one block (attn_fused_for).
+static int stack_mode_for(zn_handle h, int rows, int keys_upper_bound) {
+  if (!chain_active(h, rows) || h->tune[15] == 2 || !h->stack_ok) return -1;
+  const int nb = (keys_upper_bound + 511) / 512;
+  if (nb <= 1) {
+    if (stack3_selected(h)) return 0;
+    if (h->tune[17] == 2 && h->stackv_ok[1]) return 1;
+    return h->stackv_ok[0] ? 0 : h->stackv_ok[1] ? 1 : -1;
+  }
+  if (stack3_selected(h) || nb > ZN_SK_KB_MAXNB) return -1;
+  return h->stackv_ok[stack_variant_of(nb)] ? nb : -1;
 }
-static bool stack3_selected(zn_handle h) { return h->stack3_ok && h->tune[15] == 4; }   // zn_debug_tune(15, 4): the three-role kernel (measured slower: zn_step3_kernel.h)
 static int launch_stack(zn_handle h, hipStream_t s) {
   const zn_config& c = h->cfg;
   ChainArgs a{};
   a.eps = c.norm_eps; a.F = c.d_ff; a.nqkv = (c.n_heads + 2 * c.n_heads_kv) * h->hd;
   a.xin = h->x_emb; a.xout = h->x;
   a.g_y1 = h->ch_gy1; a.g_x1 = h->ch_gx1; a.g_x2 = h->ch_gx2; a.g_m = h->ch_gm; a.g_qkv = h->ch_gqkv; a.g_a = h->ch_ga;
+  a.g_bmax = h->ch_gbmax; a.g_part = h->ch_gpart;
   a.epoch = h->ch_epoch; a.tmo = &h->st->pad[0]; a.diag = h->ch_diag;
   a.dbg_pause = h->dbg_pause;
   a.stamps = h->ch_stamps; a.stamp_layer = c.n_layer / 2;
@@ -701,8 +761,18 @@ static int launch_stack(zn_handle h, hipStream_t s) {
   a.rope_positions = c.rope_positions;
   a.layers = h->stack_layers; a.n_layer = c.n_layer; a.q0 = h->q; a.scale = (float)(1.0 / std::sqrt((double)h->hd));
   a.heads_rows = c.n_codebooks * c.vocab_head; a.heads_out = h->logits_raw; a.trace = h->dbg_trace;
-  if (stack3_selected(h)) hipLaunchKernelGGL((step3_kernel<ZN_S3_T>), dim3(ZN_CH_GRID), dim3(ZN_SK_THREADS), ZN_S3_DYN_LDS, s, a);
-  else hipLaunchKernelGGL((step_kernel<ZN_SK_T>), dim3(ZN_CH_GRID), dim3(ZN_SK_THREADS), ZN_SK_DYN_LDS, s, a);
+  const int mode = h->stack_nbk, npairs = 2 * c.n_heads_kv;
+  a.natt = mode <= 0 ? npairs * (h->hd / 32) : npairs * mode;
+  const dim3 grid(ZN_CH_GRID), block(ZN_SK_THREADS);
+#ifdef ZN_WITH_STEP3
+  if (mode == 0 && stack3_selected(h)) { hipLaunchKernelGGL((step3_kernel<ZN_S3_T>), grid, block, ZN_S3_DYN_LDS, s, a); return ZN_OK; }
+#endif
+  switch (stack_variant_of(mode)) {
+    case 0: hipLaunchKernelGGL((step_kernel<ZN_SK_T0>), grid, block, ZN_SK_DYN_LDS, s, a); break;
+    case 1: hipLaunchKernelGGL((step_kernel<ZN_SK_T1>), grid, block, ZN_SK_DYN_LDS, s, a); break;
+    case 2: hipLaunchKernelGGL((step_kernel<ZN_SK_T2>), grid, block, ZN_SK_DYN_LDS, s, a); break;
+    default: hipLaunchKernelGGL((step_kernel<ZN_SK_T3>), grid, block, ZN_SK_DYN_LDS, s, a); break;
+  }
   return ZN_OK;
 }
 // device table of the whole-step kernel (KV cache pointers of this generation)
@@ -993,11 +1063,19 @@ extern "C" int zn_gen_begin(zn_handle h, int32_t batch, const void* const* kv_la
     for (unsigned long long* g : {h->ch_gy1, h->ch_gx1, h->ch_gx2, h->ch_ga}) HIPCHK(h, hipMemsetAsync(g, 0, R * (h->cfg.d_model / 2) * 8, s));
     HIPCHK(h, hipMemsetAsync(h->ch_gqkv, 0, R * (nqkv / 2 + 1) * 8, s));
     HIPCHK(h, hipMemsetAsync(h->ch_gm, 0, R * (h->cfg.d_ff / 2 + 1) * 8, s));
+    HIPCHK(h, hipMemsetAsync(h->ch_gbmax, 0, (size_t)2 * h->cfg.n_heads_kv * ZN_SK_KB_MAXNB * 4 * 8, s));
+    HIPCHK(h, hipMemsetAsync(h->ch_gpart, 0, (size_t)2 * h->cfg.n_heads_kv * ZN_SK_KB_MAXNB * ZN_SK_KB_PSZ * 8, s));
     const unsigned one = 1;
     HIPCHK(h, hipMemcpyAsync(h->ch_epoch, &one, sizeof one, hipMemcpyHostToDevice, s));
     HIPCHK(h, hipStreamSynchronize(s));
     h->epoch_bound = 1;
   }
+  // A handle demoted by a reported hand-off timeout goes back to the persistent kernels after ZN_REARM_AFTER generations in a row
+  // that completed on the launches path (a pause of the device is transient; a demotion for the handle's whole life would cost 25 % of
+  // every later utterance on a say-so of one event).
+  h->n_generations++;
+  if (h->demoted && h->clean_since_demotion >= ZN_REARM_AFTER) { h->demoted = false; h->clean_since_demotion = 0; h->n_rearms++; }
+  if (h->demoted && h->cfg.arch == 0 && h->ch_variant != 0 && batch == 1 && h->tune[8] != 2) h->n_fallback_generations++;
   // batch 1 on a model the persistent kernels serve: claim the device for them, or run this generation on the launches path
   h->persist_ok = !(h->cfg.arch == 0 && h->ch_variant != 0 && batch == 1) || zn_tenant_try_claim(h->device, h) != 0;
   if (h->cfg.arch == 0 && h->ch_variant == 1) {
@@ -1020,6 +1098,8 @@ extern "C" int zn_gen_begin(zn_handle h, int32_t batch, const void* const* kv_la
   for (int v : len0) if (v > h->len_hi) h->len_hi = v;
   h->gen_active = true;
   h->gen_ended = false;
+  h->gen_timed_out = false;
+  h->gen_stream = s;
   h->stop_pending = false;
   h->emb_valid = false;
   return ZN_OK;
@@ -1327,6 +1407,7 @@ extern "C" int zn_decode_steps(zn_handle h, int32_t n, zn_stream stream) {
   if (!h->gen_active || h->gen_ended) ZN_FAIL(h, ZN_ERR_STATE, "zn_decode_steps before zn_gen_begin");
   if (n < 0) ZN_FAIL(h, ZN_ERR_ARG, "n < 0");
   hipStream_t s = (hipStream_t)stream;
+  h->gen_stream = s;
   if (n > 0 && tail_fused(h) && !h->emb_valid) {   // first step of the generation: later ones find the embedding their predecessor's tail left
     hipLaunchKernelGGL(embed_kernel, dim3(h->batch), dim3(256), 0, s, make_embed_args(h));
     h->emb_valid = true;
@@ -1335,14 +1416,24 @@ extern "C" int zn_decode_steps(zn_handle h, int32_t n, zn_stream stream) {
     // this step appends one key per row; a run of ZN_GRAPH_STEPS steps with one launch shape replays the long graph
     const bool fused = attn_fused_for(h, h->len_hi + 1);
     const bool want_run = n - i >= ZN_GRAPH_STEPS && h->tune[6] > 1;
-    // the whole-step kernel serves every step whose context fits its two 512-key blocks (its attention is the fused launch's arithmetic;
-    // the two-pass launches of the per-block path at contexts above tune[5] sum q.k in another order, within the same tolerance)
+    // the whole-step kernel serves every step whose context fits one of its instantiations (stack_mode_for); a run of steps takes the
+    // attention role its LAST step needs (workgroups of key blocks past a step's context leave at once)
     const bool st_ok = tail_fused(h);
-    const bool stack_run = st_ok && want_run && stack_active(h, h->rows, h->len_hi + ZN_GRAPH_STEPS);
-    const bool stack = stack_run || (st_ok && stack_active(h, h->rows, h->len_hi + 1));
+    const int mode_run = (st_ok && want_run) ? stack_mode_for(h, h->rows, h->len_hi + ZN_GRAPH_STEPS) : -1;
+    const int mode_one = st_ok ? stack_mode_for(h, h->rows, h->len_hi + 1) : -1;
+    const bool stack_run = mode_run >= 0, stack = stack_run || mode_one >= 0;
+    const int mode = stack_run ? mode_run : mode_one;
     const int run = stack ? (stack_run ? ZN_GRAPH_STEPS : 1) : ((want_run && attn_fused_for(h, h->len_hi + ZN_GRAPH_STEPS) == fused) ? ZN_GRAPH_STEPS : 1);
     const int k = stack ? (4 | (run > 1 ? 2 : 0)) : ((fused ? 1 : 0) | (run > 1 ? 2 : 0));
     h->attn_fused = fused; h->use_stack = stack;
+    if (stack) {
+      if (h->graph_nbk[k] != mode && (h->graph_exec[k] || h->graph_tried[k])) {       // the attention role changed (another 512-key block): capture anew
+        if (h->graph_exec[k]) { (void)hipGraphExecDestroy(h->graph_exec[k]); h->graph_exec[k] = nullptr; }
+        if (h->graph[k]) { (void)hipGraphDestroy(h->graph[k]); h->graph[k] = nullptr; }
+        h->graph_tried[k] = false;
+      }
+      h->stack_nbk = h->graph_nbk[k] = mode;
+    }
     if (!h->graph_exec[k] && !h->graph_tried[k] && n > 1) {
       // capture; every step-varying quantity (column, positions) is read from device memory
       h->graph_tried[k] = true;
@@ -1369,7 +1460,17 @@ extern "C" int zn_decode_steps(zn_handle h, int32_t n, zn_stream stream) {
 extern "C" int zn_gen_end(zn_handle h) {
   if (!h) return ZN_ERR_ARG;
   (void)zn_tenant_release(h->device, h);
+  if (h->gen_active && !h->gen_ended && h->demoted && !h->gen_timed_out) h->clean_since_demotion++;
   h->gen_ended = true;
+  return ZN_OK;
+}
+
+// [0] hand-off timeouts reported on this handle, [1] generations begun, [2] of those, batch-1 generations that ran the launches path because an
+// earlier timeout had demoted the handle, [3] 1 while demoted, [4] times the handle was re-armed, [5] clean generations since the demotion
+extern "C" int zn_get_counters(zn_handle h, int64_t* out, int32_t n) {
+  if (!h || !out || n < 0) return ZN_ERR_ARG;
+  const long long v[6] = {h->n_timeouts, h->n_generations, h->n_fallback_generations, h->demoted ? 1 : 0, h->n_rearms, h->clean_since_demotion};
+  for (int i = 0; i < n && i < 6; ++i) out[i] = v[i];
   return ZN_OK;
 }
 
@@ -1385,18 +1486,23 @@ extern "C" int zn_graph_active(zn_handle h) {
 }
 
 // A bounded hand-off wait of the persistent kernels gave up (sweep_granules): the generation's results are void.  The message names the
-// wait (stage: 1 y1, 2 x1, 3 m, 4 x2, 5 q|k|v, 6 attention output; block; workgroup; wave; the tag waited for and the first stale granule),
+// wait (stage: 1 y1, 2 x1, 3 m, 4 x2, 5 q|k|v, 6 attention output, 7 block maxima and 8 partials of the key-block attention role; block; workgroup; wave; the tag waited for and the first stale granule),
 // the handle falls back to one launch per op (no in-launch hand-offs) for its later generations, and the sticky word is cleared so
 // that a new generation can run.
 static int handoff_timeout(zn_handle h, int count) {
+  // zn_all_stopped_end only waited for the stop event: in deferred mode up to 16 further steps (graph launches) may still be queued behind
+  // it.  Drain the generation's stream before the diagnostic words are read and cleared and before the graphs those steps run from are
+  // destroyed (on a non-blocking stream the null-stream copies below would not wait for them).
+  if (h->gen_stream) (void)hipStreamSynchronize(h->gen_stream);
   (void)hipMemcpy(h->diag_host, h->ch_diag, sizeof h->diag_host, hipMemcpyDeviceToHost);
   (void)hipMemset(h->ch_diag, 0, 64);
   (void)hipMemset(&h->st->pad[0], 0, sizeof(int));
-  h->tune[8] = 2; free_graph(h);
+  h->demoted = true; h->clean_since_demotion = 0; h->n_timeouts++; h->gen_timed_out = true;
+  free_graph(h);
   const unsigned* d = h->diag_host;
   ZN_FAIL(h, ZN_ERR_HIP, "decode chain: %d hand-off wait(s) timed out - the results of this generation are invalid. First: stage %u of block %u, workgroup %u wave %u lane %u "
-          "waited for tag %u, granule at byte %u carried tag %u after %u passes. This handle now runs the launches path (zn_debug_tune(8, 1) re-enables the persistent kernels)",
-          count, d[0] >> 8, d[0] & 255u, d[1], d[2], d[6], d[3], d[4], d[5], d[7]);
+          "waited for tag %u, granule at byte %u carried tag %u after %u passes. This handle runs the launches path for its next %d generations (zn_debug_tune(8, 1) re-arms the persistent kernels at once; zn_get_counters)",
+          count, d[0] >> 8, d[0] & 255u, d[1], d[2], d[6], d[3], d[4], d[5], d[7], ZN_REARM_AFTER);
 }
 
 extern "C" int zn_all_stopped(zn_handle h, int32_t* out, zn_stream stream) {
@@ -1450,6 +1556,7 @@ extern "C" int zn_debug_token_override(zn_handle h, const int32_t* tokens_dev, i
 extern "C" int zn_debug_tune(zn_handle h, int32_t key, int32_t value) {
   if (!h || key < 0 || key >= 20 || value < 1) return ZN_ERR_ARG;
   h->tune[key] = value; free_graph(h); h->emb_valid = false;
+  if (key == 8 && value == 1 && h->demoted) { h->demoted = false; h->clean_since_demotion = 0; h->n_rearms++; }
   return ZN_OK;
 }
 extern "C" int zn_debug_trace(zn_handle h, void* trace_dev) {
@@ -1473,6 +1580,7 @@ extern "C" int zn_bench_kernel(zn_handle h, int32_t which, int32_t rows, int32_t
   if (!h) return ZN_ERR_ARG;
   if (!ms_per_launch || !bytes_per_launch || iters < 1 || (rows & 0xff) < 1 || (rows & 0xff) > h->max_rows || which < 0 || which > 6)
     ZN_FAIL(h, ZN_ERR_ARG, "zn_bench_kernel: bad argument");
+  h->gen_stream = (hipStream_t)stream;
   const bool same_layer = (rows & 0x100) != 0;   // measurement variant: keep hitting layer 0 (weights stay in the Infinity Cache)
   const int ctx_arg = (rows >> 16) & 0x7fff;     // which == 6: keys already in the cache (0 = 450, the mean context of a 10 s utterance)
   rows &= 0xff;
@@ -1499,7 +1607,8 @@ extern "C" int zn_bench_kernel(zn_handle h, int32_t which, int32_t rows, int32_t
   if (which == 6) {
     if (!chain_active(h, rows)) ZN_FAIL(h, ZN_ERR_UNSUPPORTED, "zn_bench_kernel: the whole-step kernel serves batch 1 (2 rows) of the transformer only");
     if (!h->stack_checked) { h->stack_ok = stack_shapes_ok(h); h->stack3_ok = stack3_shapes_ok(h); h->stack_checked = true; }
-    if (!h->stack_ok || ctx + 1 > ZN_SK_MAXKEYS) ZN_FAIL(h, ZN_ERR_UNSUPPORTED, "zn_bench_kernel: the whole-step kernel does not serve this model / context");
+    h->stack_nbk = stack_mode_for(h, rows, ctx + 1);
+    if (h->stack_nbk < 0) ZN_FAIL(h, ZN_ERR_UNSUPPORTED, "zn_bench_kernel: the whole-step kernel does not serve this model / context");
     const int cap = ctx + 8;
     std::vector<int> lens(rows, ctx);
     HIPCHK(h, hipMalloc(&tlen, (size_t)rows * sizeof(int)));

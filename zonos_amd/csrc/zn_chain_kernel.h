@@ -71,6 +71,11 @@ struct ChainArgs {
   bf16_t* trace;                                           // diagnostic [n_layer][8][2][d]: slot 0 x after the block, 1 attention output, 2 q
   unsigned* diag;                                          // [8] words describing the first hand-off wait that timed out (sweep_granules)
   unsigned dbg_pause;                                      // test hook (step_kernel): every wave stops for this many 10 ns ticks in block 2, as a paused device would
+  // ---- whole-step kernel, key-block attention role (contexts beyond one 512-key block): the first `natt` workgroups of the grid are
+  // attention workgroups, one per (row, kv head, 512-key block); their hand-offs among themselves:
+  int natt;                                                // attention workgroups at the front of the grid (legacy role: rows * kv heads * hd / 32)
+  unsigned long long* g_bmax;                              // granules {tag, fp32 bits} [rows * kv heads][ZN_SK_KB_MAXNB][4]: per-block score maxima of the pair's 4 heads
+  unsigned long long* g_part;                              // granules [rows * kv heads][ZN_SK_KB_MAXNB][ZN_SK_KB_PSZ]: per-block unnormalised P.V [4][128] and e sums [4]
 };
 struct StackLayer {
   const bf16_t *W_out, *W_fc1, *W_fc2, *W_in;              // W_in = NEXT block's in_proj, or the heads matrix (last block)
@@ -83,6 +88,7 @@ template <int I, int N, class Fn> ZN_DEVINL void zn_static_for(Fn&& f) {
   if constexpr (I < N) { f(std::integral_constant<int, I>{}); zn_static_for<I + 1, N>(f); }
 }
 ZN_DEVINL u32x4 ld_sc1_16(__amdgpu_buffer_rsrc_t rs, int byte_off) { return __builtin_amdgcn_raw_buffer_load_b128(rs, byte_off, 0, 16); }   // aux 16 = sc1
+ZN_DEVINL u32x2 ld_sc1_8(__amdgpu_buffer_rsrc_t rs, int byte_off) { return __builtin_amdgcn_raw_buffer_load_b64(rs, byte_off, 0, 16); }     // one granule
 ZN_DEVINL __amdgpu_buffer_rsrc_t zn_rsrc(const void* p) { return __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, 0x7fffffff, 0x00020000); }
 ZN_DEVINL void st_sc1_u32(void* p, unsigned v) { __hip_atomic_store((unsigned*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 ZN_DEVINL unsigned ld_sc1_u32(const void* p) { return __hip_atomic_load((const unsigned*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -104,8 +110,10 @@ ZN_DEVINL void st_granule(unsigned long long* g, unsigned tag, unsigned value) {
 // (stage << 8 | block), workgroup, wave, the tag it waited for, the byte offset and the tag of its first stale granule, the lane that
 // held it and the passes made; zn_all_stopped prints them.  Later waits see tmo != 0 and return at once (the results are void anyway).
 struct SweepWho { unsigned code; unsigned* diag; };
-template <int N>
-ZN_DEVINL bool sweep_granules(__amdgpu_buffer_rsrc_t rs, const int (&off)[N], unsigned tag, u32x4 (&data)[N], int* tmo, int lane, SweepWho who, unsigned* passes_out = nullptr) {
+// (the byte offsets come from a functor evaluated at every use, not from an array: in the larger whole-step instantiations an offset array
+// survived as a dead 32-byte stack object and gave the kernel a private segment, which a persistent kernel must not have)
+template <int N, class OffFn>
+ZN_DEVINL bool sweep_granules_at(__amdgpu_buffer_rsrc_t rs, OffFn off, unsigned tag, u32x4 (&data)[N], int* tmo, int lane, SweepWho who, unsigned* passes_out = nullptr) {
   const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
   unsigned np = 0;
   for (;;) {
@@ -113,7 +121,8 @@ ZN_DEVINL bool sweep_granules(__amdgpu_buffer_rsrc_t rs, const int (&off)[N], un
     bool ok = true;
 #pragma unroll
     for (int i = 0; i < N; ++i) {
-      const u32x4 l0 = ld_sc1_16(rs, off[i]), l1 = ld_sc1_16(rs, off[i] + 16);
+      const int o = off(i);
+      const u32x4 l0 = ld_sc1_16(rs, o), l1 = ld_sc1_16(rs, o + 16);
       ok &= (l0.y == tag) & (l0.w == tag) & (l1.y == tag) & (l1.w == tag);
       data[i] = u32x4{l0.x, l0.z, l1.x, l1.z};
     }
@@ -125,11 +134,12 @@ ZN_DEVINL bool sweep_granules(__amdgpu_buffer_rsrc_t rs, const int (&off)[N], un
         unsigned badoff = 0xffffffffu, badtag = 0;            // the first stale granule of this lane, read once more
 #pragma unroll
         for (int i = N - 1; i >= 0; --i) {
-          const u32x4 l0 = ld_sc1_16(rs, off[i]), l1 = ld_sc1_16(rs, off[i] + 16);
-          if (l1.w != tag) { badoff = off[i] + 24; badtag = l1.w; }
-          if (l1.y != tag) { badoff = off[i] + 16; badtag = l1.y; }
-          if (l0.w != tag) { badoff = off[i] + 8; badtag = l0.w; }
-          if (l0.y != tag) { badoff = off[i]; badtag = l0.y; }
+          const int o = off(i);
+          const u32x4 l0 = ld_sc1_16(rs, o), l1 = ld_sc1_16(rs, o + 16);
+          if (l1.w != tag) { badoff = o + 24; badtag = l1.w; }
+          if (l1.y != tag) { badoff = o + 16; badtag = l1.y; }
+          if (l0.w != tag) { badoff = o + 8; badtag = l0.w; }
+          if (l0.y != tag) { badoff = o; badtag = l0.y; }
         }
         who.diag[0] = who.code; who.diag[1] = blockIdx.x; who.diag[2] = threadIdx.x >> 6; who.diag[3] = tag;
         who.diag[4] = badoff; who.diag[5] = badtag; who.diag[6] = (unsigned)lane; who.diag[7] = np;
@@ -138,6 +148,26 @@ ZN_DEVINL bool sweep_granules(__amdgpu_buffer_rsrc_t rs, const int (&off)[N], un
     }
   }
 }
+template <int N>
+ZN_DEVINL bool sweep_granules(__amdgpu_buffer_rsrc_t rs, const int (&off)[N], unsigned tag, u32x4 (&data)[N], int* tmo, int lane, SweepWho who, unsigned* passes_out = nullptr) {
+  return sweep_granules_at<N>(rs, [&](int i) { return off[i]; }, tag, data, tmo, lane, who, passes_out);
+}
+
+// The same bounded, self-describing wait for sweeps whose requests do not have sweep_granules' shape (the key-block attention role's
+// block maxima and partials): pass() after every failed pass says whether to give up; report() is sweep_granules' diagnostic record.
+struct SpinBound {
+  unsigned long long t0; unsigned np;
+  ZN_DEVINL void begin() { t0 = __builtin_amdgcn_s_memrealtime(); np = 0; }
+  ZN_DEVINL bool give_up(int* tmo) const {
+    return (np >= ZN_CH_TIMEOUT_PASSES && __builtin_amdgcn_s_memrealtime() - t0 > ZN_CH_TIMEOUT_TICKS) || __hip_atomic_load(tmo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+  }
+  ZN_DEVINL void report(int* tmo, SweepWho who, unsigned long long bad, int lane, unsigned tag, unsigned badoff, unsigned badtag) const {
+    if (lane == (int)__builtin_ctzll(bad) && atomicAdd(tmo, 1) == 0 && who.diag) {
+      who.diag[0] = who.code; who.diag[1] = blockIdx.x; who.diag[2] = threadIdx.x >> 6; who.diag[3] = tag;
+      who.diag[4] = badoff; who.diag[5] = badtag; who.diag[6] = (unsigned)lane; who.diag[7] = np;
+    }
+  }
+};
 
 // nn.LayerNorm on ONE row held as gemv_kernel holds it (lane owns elements (c*64 + lane)*8 .. +8), through the helpers
 // gemv_kernel's PRO_LN prologue uses (explicit roundings, rows independent of each other): identical statistics and outputs.

@@ -889,50 +889,54 @@ struct AttnArgs {
 
 // A single CU sustains only a few tens of GB/s, so the KV read of a (row, kv-head) pair is spread over one workgroup
 // per 64-key chunk (grid = chunks x Hkv x rows, ~112 workgroups at 10 s of context).  Pass 1: scores + chunk maxima.
+// The scores are formed on the matrix cores exactly as every other attention kernel of this library forms them (the fused launch
+// below, the whole-step kernels' attention roles): S[head][key] = Q K^T as 16x16x32 tiles (A = the G query heads padded to 16 rows,
+// B = 16 keys, k = 32 consecutive head dims per step, steps in ascending order), fp32 accumulate, then the reference's fp32
+// scale - ONE summation order for q.k on every path, so that the paths stay bit-identical to one another at every context length.
+// Each wave owns one 16-key tile and requests its keys straight in the B-fragment layout (lane = (key l & 15, k-group l >> 4)).
 template <int HD, int G>
 __global__ __launch_bounds__(256) void attn_scores_kernel(AttnArgs a) {
-  constexpr int LPP = HD / 8;      // lanes per key
-  constexpr int PPW = 64 / LPP;    // keys per wave-wide load
-  constexpr int NKL = 16 / PPW;    // loads per wave (16 keys per wave)
+  static_assert(HD % 32 == 0 && G <= 16, "score tile shape");
+  constexpr int KST = HD / 32;     // MFMA steps over the head dimension
+  typedef __attribute__((ext_vector_type(4))) float f32x4_t;
   const int chunk = blockIdx.x, kvh = blockIdx.y, r = blockIdx.z;
   // The length is requested first and every other request is issued before it is needed (addresses clamped to the
   // cache capacity, results masked at use): one memory round trip on the launch-bound chain instead of two.
   const int Lraw = a.lengths[r];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int sub = lane % LPP, grp = lane / LPP;
+  const int kn = lane & 15, kg = lane >> 4;
   const size_t kvrow = (size_t)2 * a.n_heads_kv * HD;
-  const bf16_t* kbase = a.kv + (size_t)r * a.max_len * kvrow + (size_t)kvh * HD + sub * 8;
-  u32x4 kk[NKL];
+  const int t = chunk * ZN_ACHUNK + wave * 16 + kn;
+  const bf16_t* kp = a.kv + ((size_t)r * a.max_len + (size_t)min(t, a.max_len - 1)) * kvrow + (size_t)kvh * HD + 8 * kg;
+  u32x4 kk[KST];
 #pragma unroll
-  for (int i = 0; i < NKL; ++i) {
-    const int t = chunk * ZN_ACHUNK + wave * 16 + i * PPW + grp;
-    kk[i] = ld16(kbase + (size_t)min(t, a.max_len - 1) * kvrow);
+  for (int st = 0; st < KST; ++st) kk[st] = ld16(kp + 32 * st);
+  zn_bf16x8 qa[KST];
+#pragma unroll
+  for (int st = 0; st < KST; ++st) {
+    u32x4 v = u32x4{0, 0, 0, 0};
+    if (kn < G) v = ld16(a.q + ((size_t)r * a.n_heads + kvh * G + kn) * HD + 32 * st + 8 * kg);
+    qa[st] = __builtin_bit_cast(zn_bf16x8, v);
   }
-  u32x4 qv[G];
-#pragma unroll
-  for (int g = 0; g < G; ++g) qv[g] = ld16(a.q + ((size_t)r * a.n_heads + kvh * G + g) * HD + sub * 8);
   __builtin_amdgcn_sched_barrier(0);
   const int L = Lraw + 1;
   if (chunk * ZN_ACHUNK >= L) return;
-  float mx[G];
+  f32x4_t c = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int g = 0; g < G; ++g) mx[g] = -INFINITY;
+  for (int st = 0; st < KST; ++st) c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa[st], __builtin_bit_cast(zn_bf16x8, kk[st]), c, 0, 0, 0);
+  float mx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};     // D: col = key l & 15, row = head 4 * (l >> 4) + reg
 #pragma unroll
-  for (int i = 0; i < NKL; ++i) {
-    const int t = chunk * ZN_ACHUNK + wave * 16 + i * PPW + grp;
-    const bool ok = t < L;
-#pragma unroll
-    for (int g = 0; g < G; ++g) {
-      const float s = __fmul_rn(group_sum<LPP>(dot8(kk[i], qv[g], 0.f)), a.scale);
-      if (ok) {
-        mx[g] = fmaxf(mx[g], s);
-        if (sub == 0) a.scores[((size_t)r * a.n_heads + kvh * G + g) * a.lcap + t] = s;
-      }
+  for (int reg = 0; reg < 4; ++reg) {
+    const int head = 4 * kg + reg;
+    if (head < G && t < L) {
+      const float sv = __fmul_rn(c[reg], a.scale);
+      mx[reg] = sv;
+      a.scores[((size_t)r * a.n_heads + kvh * G + head) * a.lcap + t] = sv;
     }
   }
   __shared__ float sm[4][G];
 #pragma unroll
-  for (int g = 0; g < G; ++g) { const float m = wave_max(mx[g]); if (lane == 0) sm[wave][g] = m; }
+  for (int g = 0; g < G; ++g) { const float m = wave_max(kg == g / 4 ? mx[g % 4] : -INFINITY); if (lane == 0) sm[wave][g] = m; }
   __syncthreads();
   if (threadIdx.x < G) {
     const int g = threadIdx.x;
@@ -940,22 +944,23 @@ __global__ __launch_bounds__(256) void attn_scores_kernel(AttnArgs a) {
   }
 }
 
-// Pass 2: one workgroup per (32-wide value slice, kv head, row) walks ALL keys in the reference's order (512-key blocks,
-// running max taken from the chunk maxima of pass 1), forms e/P with the reference's rounding, accumulates P.V on its
-// value columns and writes the final bf16 output — no cross-workgroup partials, no combine launch.  V is read as
-// 64-B row pieces (L x 64 B per workgroup, ~58 KB at 10 s of context).
+// Pass 2 runs in one of two shapes, both with the reference's rounding (512-key blocks, running max, e / P = bf16(e), P.V in fp32):
 //
-// FUSED (contexts up to ZN_AFUSED_MAX keys, i.e. every step of a 10-20 s utterance): the same workgroup first computes
-// the scores of ALL keys of its kv head into LDS (identical arithmetic to attn_scores_kernel; the HD/32 slice
-// workgroups of one (row, kv head) repeat it, and the 1-D grid puts them on one XCD so that K comes from that XCD's
-// L2 after the first touch) and then runs pass 2 from LDS: one launch instead of two on the latency-bound chain.
+// MODE 1, FUSED (contexts of ONE 512-key block, i.e. up to 512 keys; the host never selects it beyond): one workgroup per (32-wide
+// value slice, kv head, row) first computes the scores of all keys of its kv head into LDS (the arithmetic of attn_scores_kernel; the
+// HD/32 slice workgroups of one (row, kv head) repeat it, and the 1-D grid puts them on one XCD so that K comes from that XCD's L2
+// after the first touch) and then runs pass 2 from LDS: one launch instead of two on the latency-bound chain.  (Its block loop can walk
+// further blocks accumulating in place - acc = acc * f + p.v per key - which rounds differently from the combine below; that is why the
+// host keeps it to one block, where the two coincide.)
+// MODE 2, SPLIT (longer contexts): one workgroup per (slice, kv head, row, 512-key BLOCK): the block's running max comes from the chunk
+// maxima of all earlier chunks, its unnormalised P.V and e sums leave as write-through partials, and the last workgroup of a (row, kv
+// head, slice) to arrive (ticket, no waiting) replays the reference's recurrence acc = acc * f_j + pv_j over the blocks in order and
+// normalises.  This is the library's definition of the decode attention beyond one block: the whole-step kernel's key-block attention
+// role (zn_step_kernel.h) reproduces it bit for bit.
 #define ZN_AFUSED_MAX 2048
-// MODE 2 (long contexts): one workgroup per (slice, kv head, row, 512-key BLOCK) instead of one per (slice, kv head, row)
-// walking every block: the block's running max comes from the chunk maxima of all earlier chunks, its unnormalised P.V
-// and e sums leave as write-through partials, and the last workgroup of a (row, kv head, slice) to arrive (ticket, no
-// waiting) replays the reference's recurrence acc = acc * f_j + pv_j over the blocks in order and normalises.
 template <int HD, int G, int MODE>
 __global__ __launch_bounds__(512) void attn_pv_kernel(AttnArgs a) {
+  static_assert(MODE == 1 || MODE == 2, "fused (one block) or split (one workgroup per block)");
   constexpr bool FUSED = MODE == 1, SPLIT = MODE == 2;
   constexpr int NW = 8;                                   // waves per workgroup; 16 keys per wave-load -> 128 keys per round
   constexpr int NR = 512 / (NW * 16);                     // rounds per 512-key block
@@ -967,8 +972,7 @@ __global__ __launch_bounds__(512) void attn_pv_kernel(AttnArgs a) {
     const int npairs = a.n_heads_kv * a.rows;
     const int pair = blockIdx.x % npairs;
     slice = blockIdx.x / npairs; kvh = pair % a.n_heads_kv; r = pair / a.n_heads_kv;
-  } else if constexpr (SPLIT) { slice = blockIdx.x; kvh = blockIdx.y; r = blockIdx.z / a.nbcap; }
-  else { slice = blockIdx.x; kvh = blockIdx.y; r = blockIdx.z; }
+  } else { slice = blockIdx.x; kvh = blockIdx.y; r = blockIdx.z / a.nbcap; }
   const int jb = SPLIT ? (int)(blockIdx.z % a.nbcap) : 0;       // SPLIT: the block this workgroup owns
   int nst = 0;
   auto stamp = [&]() { if (FUSED && a.stamps && blockIdx.x == 0 && threadIdx.x == 0) a.stamps[nst] = __builtin_amdgcn_s_memrealtime(); ++nst; };
@@ -1162,20 +1166,6 @@ __global__ __launch_bounds__(512) void attn_pv_kernel(AttnArgs a) {
 #pragma unroll
           for (int i = 0; i < NR; ++i) vnext[i] = ld16(vbase + (size_t)min(t0 + 1024 + i * (NW * 16) + wave * 16 + vkey, L - 1) * kvrow);
         }
-      }
-    } else if (!SPLIT && j + 1 < nb) {                    // next block's requests fly during this block's arithmetic
-#pragma unroll
-      for (int i = 0; i < NR; ++i) {
-        const int nidx = t0 + 512 + i * (NW * 16) + wave * 16 + vkey;
-        vnext[i] = ld16(vbase + (size_t)min(nidx, L - 1) * kvrow);
-        if constexpr (!FUSED) {
-#pragma unroll
-          for (int q = 0; q < GL; ++q) scn[i][q] = srow[q][min(nidx, a.lcap - 1)];
-        }
-      }
-      if constexpr (!FUSED) {
-#pragma unroll
-        for (int q = 0; q < GL; ++q) cmn[q] = crow[q][min(8 * (j + 1) + (lane >> 3), cstride - 1)];
       }
     }
     // running max of the block (max over its <= 8 chunk maxima: lanes 8c..8c+7 hold chunk c), rescale factors

@@ -351,11 +351,342 @@ ZN_DEVINL void step_attention_role(const ChainArgs& a, StepAttnLds& S, const uns
   }
 }
 
+// ------------------------------------------------------------------------------------------------ attention role, one workgroup per KEY BLOCK
+// Contexts beyond one 512-key block (the legacy role above holds two blocks and makes its four value-slice workgroups repeat every score).
+// Here the first natt = 8 * NBK workgroups of the grid are one per (row, kv head, 512-key block): a workgroup holds K of its block in the
+// MFMA B-fragment layout (64 VGPRs) and V at full width (64 VGPRs), both requested a block ahead, computes its 512 x 4 scores once,
+// exchanges the block maxima with the other blocks of its (row, kv head) pair (the running max m_j of the reference's recurrence is the
+// max over blocks 0 .. j), runs pass 2 on its keys for the four 32-wide value slices in turn (attn_pv_kernel<128, 4, 2>'s per-lane order and
+// reduction tree per slice: the same partials bit for bit) and publishes the unnormalised P.V and e sums as granules; the workgroup of
+// block 0 sweeps the partials of all blocks, replays acc = acc * f_j + pv_j in block order (that kernel's combine), normalises and
+// publishes the attention output.  One block (contexts up to 512 keys): no exchange, no partials - the workgroup normalises and
+// publishes itself, 8 attention workgroups instead of 32, i.e. 248 streaming workgroups.  Workgroups of blocks past the context
+// (the grid is sized for the launch's upper bound) leave at once.  (_torch.py:413-417)
+#define ZN_SK_KB_MAXNB 12                                   // key blocks covered: 6144 keys
+#define ZN_SK_KB_PSZ 520                                    // granules per (pair, block): P.V [4][128], e sums [4] (as two 16-byte pairs), padding to 64 B
+struct StepKbLds {
+  float sc[4][512];                                         // scores [head][key of the block]
+  float bm[8][4];                                           // per (wave, head) maxima of the block
+  float bmall[ZN_SK_KB_MAXNB][4];                           // maxima of every block of the pair
+  float acc[32][4][128];                                    // per (wave, 16-lane row) partial P.V, the four value slices side by side
+  float l[8][4];
+  __attribute__((aligned(16))) bf16_t q[4][128];            // the kv head's 4 query heads
+  __attribute__((aligned(16))) bf16_t knew[128], vnew[128]; // newest key / value row of the kv head
+  __attribute__((aligned(16))) bf16_t out[4][128];          // normalised result (one-block contexts)
+};
+static_assert(sizeof(StepKbLds) <= ZN_SK_DYN_LDS, "the key-block attention role's LDS fits the launch's dynamic LDS");
+
+template <int NBV>          // blocks this instantiation's launches can be asked to cover (<= ZN_SK_KB_MAXNB): the unroll bound of the combine
+ZN_DEVINL void step_attention_kb_role(const ChainArgs& a, StepKbLds& S, const unsigned tag0, const int c, const int wave, const int lane_in) {
+  static_assert(NBV >= 1 && NBV <= ZN_SK_KB_MAXNB, "blocks covered");
+  constexpr int HD = 128, G = 4, NW = 8, NR = 4, KST = HD / 32, TPW = 4, R = 2, NSL = HD / 32, MAXNB = ZN_SK_KB_MAXNB, PSZ = ZN_SK_KB_PSZ;
+  typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+  const int npairs = a.n_heads_kv * R;
+  const int pair = c % npairs, jb = c / npairs, kvh = pair % a.n_heads_kv, ar = pair / a.n_heads_kv;
+  const int nq = a.n_heads * HD, nk = a.n_heads_kv * HD, D = nq;
+  const int L = a.lengths[ar] + 1, nb = (L + 511) >> 9;     // keys including this step's
+  if (jb >= nb) return;                                      // a block past the context: nothing to do in this launch
+  const int tb = jb * 512, nkeys = min(512, L - tb), tend = tb + nkeys;
+  const bool has_newest = jb == nb - 1;                      // row L-1 (this step's key and value) comes from the hand-off, not from the cache
+  const int hi = L >= 2 ? L - 2 : 0;                         // rows 0 .. L-2 are in the cache from earlier launches
+  const size_t kvrow = (size_t)2 * nk;
+  const bool stamped = a.stamps && c == 0 && wave == 0 && lane_in == 0;
+  u32x4 kk[TPW][KST], vv[NSL][NR];
+  const int rowbytes = (int)kvrow * 2;
+  // (offsets formed at every issue from a value the optimiser cannot see through, as in the legacy role: hoisted they spill)
+  // Everything derived from the lane index is formed anew in every block from a copy of it the optimiser cannot see through: hoisted out
+  // of the block loop, the per-lane LDS addresses and granule offsets (~80 VGPRs) stayed live beside the 128 K / V registers and spilled.
+  auto issue_kv = [&](const bf16_t* kv, int opq, int ln) {
+    const int kn = ln & 15, kg = ln >> 4, vsub = ln & 3, vkey = ln >> 2;
+    const __amdgpu_buffer_rsrc_t rs = zn_rsrc(kv);
+    const int kbase = ar * a.max_len * rowbytes + (kvh * HD + 8 * kg) * 2, kr0 = opq + tb + wave * 16 + kn;
+#pragma unroll
+    for (int tl = 0; tl < TPW; ++tl)
+#pragma unroll
+      for (int st = 0; st < KST; ++st) kk[tl][st] = __builtin_amdgcn_raw_buffer_load_b128(rs, kbase + min(kr0 + tl * NW * 16, hi) * rowbytes + 64 * st, 0, 0);
+    const int vbase = ar * a.max_len * rowbytes + ((a.n_heads_kv + kvh) * HD + vsub * 8) * 2, vr0 = opq + tb + wave * 16 + vkey;
+#pragma unroll
+    for (int sl = 0; sl < NSL; ++sl)
+#pragma unroll
+      for (int i = 0; i < NR; ++i) vv[sl][i] = __builtin_amdgcn_raw_buffer_load_b128(rs, vbase + min(vr0 + i * (NW * 16), hi) * rowbytes + 64 * sl, 0, 0);
+  };
+  issue_kv(a.layers[0].kv, 0, lane_in);
+  const __amdgpu_buffer_rsrc_t rs_bmax = zn_rsrc(a.g_bmax), rs_part = zn_rsrc(a.g_part);
+  StepPacer pace{0ull, 0u};
+#pragma unroll 1
+  for (int li = 0; li < a.n_layer; ++li) {
+    const unsigned tag = tag0 + (unsigned)li;
+    if (a.dbg_pause && li == 3) step_debug_pause(a.dbg_pause);     // (inside the measured wait for block 3's q | k | v)
+    const bool st_on = stamped && li == a.stamp_layer;
+    auto stamp = [&](int i) { if (st_on) a.stamps[32 + i] = __builtin_amdgcn_s_memrealtime(); };
+    stamp(0);
+    int lane = lane_in;
+    asm volatile("" : "+v"(lane));
+    const int kn = lane & 15, kg = lane >> 4;
+    const int vsub = lane & 3, vkey = lane >> 2, row = lane >> 4;
+    const int tid = wave * 64 + lane;
+    // ---- q (4 heads) and, in the newest block's workgroup, this step's key and value row of the kv head -> LDS
+    if (wave == ZN_SK_CW || (wave == ZN_SK_CW + 1 && has_newest)) {
+      const bool first = wave == ZN_SK_CW;
+      if (li == 0) {                                         // from the in_proj launch before this one: plain loads
+        if (first) *(u32x4*)&S.q[lane >> 4][(lane & 15) * 8] = ld16(a.q0 + ((size_t)ar * a.n_heads + kvh * G + (lane >> 4)) * HD + (lane & 15) * 8);
+        else if (lane < 32) {
+          const bf16_t* rowp = a.layers[0].kv + ((size_t)ar * a.max_len + (L - 1)) * kvrow + (size_t)(lane < 16 ? 0 : nk) + (size_t)kvh * HD + (lane & 15) * 8;
+          const u32x4 v = ld16(rowp);
+          if (lane < 16) *(u32x4*)&S.knew[lane * 8] = v; else *(u32x4*)&S.vnew[(lane - 16) * 8] = v;
+        }
+      } else {                                               // granules of the block before (tag - 1)
+        const int qoff = (ar * (a.nqkv / 2) + ((kvh * G) * HD) / 2 + lane * 4) * 8;
+        const int kvsel = lane < 16 ? nq + kvh * HD : nq + nk + kvh * HD;
+        const int koff = (ar * (a.nqkv / 2) + kvsel / 2 + (lane & 15) * 4) * 8;
+        int off1[1] = {first ? qoff : koff};
+        u32x4 d1[1];
+        pace.sleep();
+        sweep_granules<1>(zn_rsrc(a.g_qkv), off1, tag - 1u, d1, a.tmo, lane, SweepWho{(5u << 8) | (unsigned)li, a.diag});
+        pace.done();
+        if (first) *(u32x4*)&S.q[lane >> 4][(lane & 15) * 8] = d1[0];
+        else if (lane < 16) *(u32x4*)&S.knew[lane * 8] = d1[0];
+        else if (lane < 32) *(u32x4*)&S.vnew[(lane - 16) * 8] = d1[0];
+      }
+    }
+    __syncthreads();                                         // K1: q (and the newest rows) are in LDS
+    stamp(1);
+    // ---- the block's scores on the matrix cores (the arithmetic of attn_scores_kernel / the fused launch): S[head][key] as 16x16x32 tiles
+    {
+      zn_bf16x8 qa[KST];
+#pragma unroll
+      for (int st = 0; st < KST; ++st) {
+        u32x4 v = u32x4{0, 0, 0, 0};
+        if (kn < G) v = *(const u32x4*)&S.q[kn][32 * st + 8 * kg];
+        qa[st] = __builtin_bit_cast(zn_bf16x8, v);
+      }
+      u32x4 knew_frag[KST];
+#pragma unroll
+      for (int st = 0; st < KST; ++st) knew_frag[st] = *(const u32x4*)&S.knew[32 * st + 8 * kg];
+      float mx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+      for (int tl = 0; tl < TPW; ++tl) {
+        const int tt = tb + (tl * NW + wave) * 16;
+        if (tt < tend) {                                     // wave-uniform
+          const bool newest = tt + kn >= L - 1;
+          f32x4_t cc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int st = 0; st < KST; ++st) {
+            const u32x4 bfrag = newest ? knew_frag[st] : kk[tl][st];
+            cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa[st], __builtin_bit_cast(zn_bf16x8, bfrag), cc, 0, 0, 0);
+          }
+          const int t = tt + kn;
+#pragma unroll
+          for (int reg = 0; reg < 4; ++reg) {
+            const int head = 4 * kg + reg;
+            if (head < G && t < tend) {
+              const float sv = __fmul_rn(cc[reg], a.scale);
+              mx[reg] = fmaxf(mx[reg], sv);
+              S.sc[head][t - tb] = sv;
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        const float m = wave_max(kg == g / 4 ? mx[g % 4] : -INFINITY);
+        if (lane == 0) S.bm[wave][g] = m;
+      }
+    }
+    __syncthreads();                                         // K2: every score and per-wave maximum of the block is in LDS
+    stamp(2);
+    // ---- block maxima of the pair's blocks: publish this block's, sweep all of them (one block: nothing to exchange)
+    if (wave == 0) {
+      float bmx = -INFINITY;
+      if (lane < G) {
+#pragma unroll
+        for (int w = 0; w < NW; ++w) bmx = fmaxf(bmx, S.bm[w][lane]);
+      }
+      if (nb > 1) {
+        if (lane < G) st_granule(a.g_bmax + ((size_t)pair * MAXNB + jb) * G + lane, tag, __float_as_uint(bmx));
+        const bool act = lane < 2 * nb;                      // lane = (block lane >> 1, head pair lane & 1): one 16-byte load = two granules
+        const int off = ((pair * MAXNB) * G + 2 * (act ? lane : 0)) * 8;
+        SpinBound sb; sb.begin();
+        for (;;) {
+          ++sb.np;
+          const u32x4 v = ld_sc1_16(rs_bmax, off);
+          const bool ok = !act || ((v.y == tag) & (v.w == tag));
+          const unsigned long long bad = __builtin_amdgcn_ballot_w64(!ok);
+          if (bad == 0ull) {
+            if (act) { S.bmall[lane >> 1][2 * (lane & 1)] = __uint_as_float(v.x); S.bmall[lane >> 1][2 * (lane & 1) + 1] = __uint_as_float(v.z); }
+            break;
+          }
+          if (sb.give_up(a.tmo)) { sb.report(a.tmo, SweepWho{(7u << 8) | (unsigned)li, a.diag}, bad, lane, tag, (unsigned)off + (v.y != tag ? 0u : 8u), v.y != tag ? v.y : v.w); break; }
+        }
+      } else if (lane < G) S.bmall[0][lane] = bmx;
+    }
+    __syncthreads();                                         // K3: the running maxima are known
+    stamp(3);
+    // ---- pass 2 on this block's keys (attn_pv_kernel<128, 4, 2>: lane = (key vkey, head / 8-wide value piece vsub)), slice by slice
+    {
+      float m_run = -INFINITY;
+      for (int j = 0; j < jb; ++j) m_run = fmaxf(m_run, S.bmall[j][vsub]);
+      const float mnew = fmaxf(m_run, S.bmall[jb][vsub]);
+      const int nvec = nkeys & ~15;                          // decode steps: the reference's block loop spans exactly the context
+      float ev[NR], lsum = 0.f;
+#pragma unroll
+      for (int i = 0; i < NR; ++i) {
+        const int base = i * (NW * 16), idx = base + wave * 16 + vkey;
+        const bool ok = idx < nkeys;
+        const float x = __fsub_rn(ok ? S.sc[vsub][idx] : 0.f, mnew);
+        if (base + NW * 16 <= nvec) ev[i] = ok ? zn_fexp_u20(x) : 0.f;
+        else ev[i] = ok ? ((idx < nvec) ? zn_fexp_u20(x) : expf(x)) : 0.f;
+        lsum += ev[i];
+      }
+#pragma unroll
+      for (int sl = 0; sl < NSL; ++sl) {
+        const u32x4 vnew_piece = *(const u32x4*)&S.vnew[sl * 32 + vsub * 8];
+        float acc[G][8];
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) acc[g][e] = 0.f;
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+          const int idx = i * (NW * 16) + wave * 16 + vkey;
+          u32x4 v = vv[sl][i];
+          if (tb + idx >= L - 1) v = vnew_piece;
+          if (!(idx < nkeys)) v = u32x4{0, 0, 0, 0};
+          const float v0 = lo_f(v.x), v1 = hi_f(v.x), v2f = lo_f(v.y), v3 = hi_f(v.y);
+          const float v4 = lo_f(v.z), v5 = hi_f(v.z), v6 = lo_f(v.w), v7 = hi_f(v.w);
+#pragma unroll
+          for (int g = 0; g < G; ++g) {
+            float pr = bfround(ev[i]);
+            pr = (g % 4 == 0) ? dpp_mov<0x00>(pr) : (g % 4 == 1) ? dpp_mov<0x55>(pr) : (g % 4 == 2) ? dpp_mov<0xAA>(pr) : dpp_mov<0xFF>(pr);
+            acc[g][0] = fmaf(pr, v0, acc[g][0]); acc[g][1] = fmaf(pr, v1, acc[g][1]);
+            acc[g][2] = fmaf(pr, v2f, acc[g][2]); acc[g][3] = fmaf(pr, v3, acc[g][3]);
+            acc[g][4] = fmaf(pr, v4, acc[g][4]); acc[g][5] = fmaf(pr, v5, acc[g][5]);
+            acc[g][6] = fmaf(pr, v6, acc[g][6]); acc[g][7] = fmaf(pr, v7, acc[g][7]);
+          }
+        }
+        // reduce: 4 key lanes per 16-lane row by DPP, the rows of the workgroup through LDS in the split kernel's order
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+          float red[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) red[e] = row_stride4_sum(acc[g][e]);
+          if ((lane & 15) < 4) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) S.acc[wave * 4 + row][g][sl * 32 + (lane & 3) * 8 + e] = red[e];
+          }
+        }
+      }
+      float ls = row_stride4_sum(lsum);
+      ls = (readlane_f(ls, 0) + readlane_f(ls, 16)) + (readlane_f(ls, 32) + readlane_f(ls, 48));
+      float l1 = row_stride4_sum(lsum); l1 = (readlane_f(l1, 1) + readlane_f(l1, 17)) + (readlane_f(l1, 33) + readlane_f(l1, 49));
+      float l2 = row_stride4_sum(lsum); l2 = (readlane_f(l2, 2) + readlane_f(l2, 18)) + (readlane_f(l2, 34) + readlane_f(l2, 50));
+      float l3 = row_stride4_sum(lsum); l3 = (readlane_f(l3, 3) + readlane_f(l3, 19)) + (readlane_f(l3, 35) + readlane_f(l3, 51));
+      if (lane == 0) { S.l[wave][0] = ls; S.l[wave][1] = l1; S.l[wave][2] = l2; S.l[wave][3] = l3; }
+    }
+    __syncthreads();                                         // K4: partial sums of all 8 waves
+    stamp(4);
+    {
+      const int g = tid >> 7, d = tid & 127;                 // 512 threads = 4 heads x 128 value columns
+      float v = 0.f, l = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW * 4; ++w) v += S.acc[w][g][d];
+#pragma unroll
+      for (int w = 0; w < NW; ++w) l += S.l[w][g];
+      if (nb == 1) S.out[g][d] = f2bf(__fmul_rn(v, 1.0f / l));
+      else {
+        unsigned long long* pp = a.g_part + ((size_t)pair * MAXNB + jb) * PSZ;
+        st_granule(pp + g * 128 + d, tag, __float_as_uint(v));
+        if (d == 0) st_granule(pp + G * 128 + g, tag, __float_as_uint(l));
+      }
+    }
+    if (nb == 1) __syncthreads();                            // K5 (workgroup-uniform): the result is in LDS
+    stamp(5);
+    if (wave < 4 && (nb == 1 || jb == 0)) {                  // 256 granules of the pair's attention output: lane = (head, column pair)
+      const int p = tid, g = p >> 6, dp = p & 63;
+      unsigned o;
+      if (nb == 1) o = *(const unsigned*)&S.out[g][2 * dp];
+      else {
+        // the combine of attn_pv_kernel<.., 2>: the reference's recurrence over the blocks, in order
+        const int voff = ((pair * MAXNB) * PSZ + g * 128 + 2 * dp) * 8, loff = ((pair * MAXNB) * PSZ + G * 128 + g) * 8;
+        // in chunks of CH blocks (every pass requests all CH entries of its chunk, blocks past the context repeating the last one: an
+        // entry that kept its value from the pass before would be carried around the retry loop in a second set of registers)
+        constexpr int CH = 6;
+        float tot0 = 0.f, tot1 = 0.f, lt = 0.f, mprev = -INFINITY;
+#pragma unroll
+        for (int j0 = 0; j0 < NBV; j0 += CH) {
+          if (j0 < nb) {                                      // uniform
+            u32x4 pv[CH];
+            u32x2 pl[CH];                                     // {e sum, tag} of head g: one granule
+            SpinBound sb; sb.begin();
+            for (;;) {
+              ++sb.np;
+#pragma unroll
+              for (int j = 0; j < CH; ++j) {
+                const int jo = min(j0 + j, nb - 1) * (PSZ * 8);
+                pv[j] = ld_sc1_16(rs_part, voff + jo);
+                pl[j] = ld_sc1_8(rs_part, loff + jo);
+              }
+              bool ok = true;
+#pragma unroll
+              for (int j = 0; j < CH; ++j) ok &= (pv[j].y == tag) & (pv[j].w == tag) & (pl[j].y == tag);
+              const unsigned long long bad = __builtin_amdgcn_ballot_w64(!ok);
+              if (bad == 0ull) break;
+              if (sb.give_up(a.tmo)) {
+                unsigned badoff = 0, badtag = 0;
+#pragma unroll
+                for (int j = CH - 1; j >= 0; --j) {
+                  const bool okj = (pv[j].y == tag) & (pv[j].w == tag) & (pl[j].y == tag);
+                  if (!okj) { badoff = (unsigned)(voff + min(j0 + j, nb - 1) * (PSZ * 8)); badtag = pv[j].y != tag ? pv[j].y : pv[j].w != tag ? pv[j].w : pl[j].y; }
+                }
+                sb.report(a.tmo, SweepWho{(8u << 8) | (unsigned)li, a.diag}, bad, lane, tag, badoff, badtag);
+                break;
+              }
+            }
+#pragma unroll
+            for (int j = 0; j < CH; ++j) {
+              if (j0 + j < nb) {
+                const float mj = fmaxf(mprev, S.bmall[j0 + j][g]);
+                const float fj = (j0 + j == 0) ? 0.f : expf(mprev - mj);
+                mprev = mj;
+                tot0 = __fadd_rn(__fmul_rn(tot0, fj), __uint_as_float(pv[j].x));
+                tot1 = __fadd_rn(__fmul_rn(tot1, fj), __uint_as_float(pv[j].z));
+                lt = __fadd_rn(__fmul_rn(lt, fj), __uint_as_float(pl[j].x));
+              }
+            }
+          }
+        }
+        const float inv = 1.0f / lt;
+        o = pack2(__fmul_rn(tot0, inv), __fmul_rn(tot1, inv));
+      }
+      st_granule(a.g_a + (size_t)ar * (D / 2) + ((kvh * G + g) * HD) / 2 + dp, tag, o);
+      if (a.trace) *(unsigned*)(a.trace + ((size_t)(8 * li + 1) * R + ar) * D + (kvh * G + g) * HD + 2 * dp) = o;
+    }
+    if (a.trace && jb == 0 && wave == ZN_SK_CW)
+      *(u32x4*)(a.trace + ((size_t)(8 * li + 2) * R + ar) * D + (kvh * G + (lane >> 4)) * HD + (lane & 15) * 8) = *(const u32x4*)&S.q[lane >> 4][(lane & 15) * 8];
+    stamp(6);
+    // the key and value registers are free: the next block's rows are requested now, a whole block (~20 us) ahead of their use
+    if (li + 1 < a.n_layer) {
+      int opq = 0;
+      asm volatile("" : "+v"(opq));
+      issue_kv(a.layers[li + 1].kv, opq, lane);
+    }
+    pace.start();                                            // the wait for the next block's q | k | v starts here
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ the launch
 // T_* = tiles per compute wave per op (upper bounds: the matrices do not divide evenly over 224 workgroups; a wave skips the tiles
 // its workgroup does not have).  d_model = 512 * NCH, d_ff = 4 * d_model (host-checked, as are the bounds).
-template <int NCH, int T_OUT, int T_FC1, int T_FC2, int T_IN>
-__global__ __launch_bounds__(ZN_SK_THREADS) void step_kernel(ChainArgs a) {
+// ATT: 0 = the legacy attention role (32 workgroups per value slice, contexts up to ZN_SK_MAXKEYS); n >= 1 = one attention workgroup per key block,
+// launches covering up to n blocks (a.natt = 8 * blocks of the launch's context bound).
+template <int NCH, int T_OUT, int T_FC1, int T_FC2, int T_IN, int ATT = 0>
+__global__ __launch_bounds__(ZN_SK_THREADS) void step_kernel(ChainArgs a_in) {
+  // Integer arguments that the whole kernel keeps using are detached from the kernarg segment's wide scalar loads: read as parts of an
+  // s_load_dwordx8 they made the register allocator spill the 256-bit tuple, rematerialise it instead, and leave its 32-byte stack slot
+  // behind - a private segment without a single scratch instruction, which a persistent kernel must not have (tests/test_abi.py).
+  // (Pointers are left alone: an asm operand has no address space, and accesses through a laundered pointer become flat_ instructions.)
+  ChainArgs a = a_in;
+  asm volatile("" : "+s"(a.max_len), "+s"(a.hd), "+s"(a.n_heads), "+s"(a.n_heads_kv), "+s"(a.rope_positions), "+s"(a.F), "+s"(a.nqkv), "+s"(a.natt), "+s"(a.dbg_pause));
   constexpr int R = 2, D = NCH * 512, CW = ZN_SK_CW;
   constexpr int NS = 2 * T_OUT + T_FC1 + T_FC2 + T_IN;         // slots of a block (StepSched)
   constexpr int NOPS = 5;
@@ -369,9 +700,10 @@ __global__ __launch_bounds__(ZN_SK_THREADS) void step_kernel(ChainArgs a) {
   const int F = a.F;
   const unsigned tag0 = ld_sc1_u32(a.epoch);
   extern __shared__ __attribute__((aligned(16))) unsigned char zn_dyn_lds[];
-  const int natt = a.n_heads_kv * R * (a.hd / 32);
+  const int natt = a.natt;
   if (c < natt) {
-    step_attention_role(a, *reinterpret_cast<StepAttnLds*>(zn_dyn_lds), tag0, c, wave, lane);
+    if constexpr (ATT == 0) step_attention_role(a, *reinterpret_cast<StepAttnLds*>(zn_dyn_lds), tag0, c, wave, lane);
+    else step_attention_kb_role<ATT>(a, *reinterpret_cast<StepKbLds*>(zn_dyn_lds), tag0, c, wave, lane);
     return;
   }
   // ------------------------------------------------------------------------------------------------ streaming role
@@ -405,7 +737,7 @@ __global__ __launch_bounds__(ZN_SK_THREADS) void step_kernel(ChainArgs a) {
   struct WT { u32x4 a[NCH], b[NCH]; };
   // tile of slot s for compute wave w: exists?, weight pointers of rows A and B (lane's first chunk), result index
   struct LW { const bf16_t *out, *fc1, *fc2, *in; };           // the block's weight matrices, read from the layer table ONCE per block (SGPRs)
-  auto tile_of = [&](const LW Lr, int rows_in, int n_in, int s_in, int s, int w, bool& ok, const bf16_t*& pa, const bf16_t*& pb, int& ridx) {
+  auto tile_of = [&](const LW& Lr, int rows_in, int n_in, int s_in, int s, int w, bool& ok, const bf16_t*& pa, const bf16_t*& pb, int& ridx) {
     const int op = op_of(s), t = s - first_of(op);
     if (op == 3) {
       const int qt = w, j = t;
@@ -572,14 +904,11 @@ __global__ __launch_bounds__(ZN_SK_THREADS) void step_kernel(ChainArgs a) {
           }
           if constexpr (op == 3) {
             // fc2's input m [2][4 d]: this wave's K quarter straight from the granules (no LDS, no barrier)
-            int off[NCH * R];
             u32x4 dat[NCH * R];
-#pragma unroll
-            for (int c2 = 0; c2 < NCH; ++c2)
-#pragma unroll
-              for (int r = 0; r < R; ++r) off[c2 * R + r] = (r * (2 * D) + wave * (D / 2) + (c2 * 64 + lane) * 4) * 8;
+            const int mbase = (wave * (D / 2) + lane * 4) * 8;
             if constexpr (ZN_SK_MSWEEP_DELAY > 0) __builtin_amdgcn_s_sleep(ZN_SK_MSWEEP_DELAY);
-            sweep_granules<NCH * R>(zn_rsrc(a.g_m), off, tag, dat, a.tmo, lane, SweepWho{(3u << 8) | (unsigned)li, a.diag});
+            sweep_granules_at<NCH * R>(zn_rsrc(a.g_m), [&](int i) { return mbase + ((i % R) * (2 * D) + (i / R) * 256) * 8; }, tag, dat, a.tmo, lane,
+                                       SweepWho{(3u << 8) | (unsigned)li, a.diag});
 #pragma unroll
             for (int c2 = 0; c2 < NCH; ++c2)
 #pragma unroll
