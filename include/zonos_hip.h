@@ -149,9 +149,7 @@ int zn_graph_active(zn_handle h);
 int zn_decode_path(zn_handle h);
 /* Which kernels served the decode step enqueued last: 0 = one launch per op, 1 = one attention launch (two beyond 512 keys) + one
  * persistent chain launch per block, 2 = the whole-step persistent kernel (every block of the step in one launch; contexts up to
- * 6144 keys: attention workgroups per value slice up to 512 keys, per 512-key block beyond), 3 = its three-role variant (attention /
- * projection / bulk: an experiment, compiled only with -DZN_WITH_STEP3 and then selected by zn_debug_tune(15, 4)).
- * All give bit-identical results. */
+ * 6144 keys: one attention workgroup per (row, kv head, 512-key block)).  All give bit-identical results. */
 int zn_decode_path_detail(zn_handle h);
 /* Hand-off timeouts are never silent: out[0] = bounded in-kernel hand-off waits that gave up and were reported on this handle (each voids
  * its generation; zn_all_stopped* returns the error), [1] generations begun, [2] batch-1 generations that ran the launches path because
@@ -194,8 +192,7 @@ int zn_debug_prefill_mode(zn_handle h, int32_t mode);
 /* Tuning hook: target workgroup count of a GEMV class (0 in_proj, 1 out_proj, 2 fc1, 3 fc2, 4 heads); 5: longest context of the
  * fused attention launch (at most 512 keys, one block: beyond, every path walks the blocks with the split pass); 6: 1 = single-step
  * graphs only; 8: 2 = per-op launches instead of the persistent kernels (also ZN_CHAIN=0 at zn_create), 1 = back to the default and
- * re-arm a handle demoted by a hand-off timeout; 15: 2 = one chain launch per block instead of the whole-step kernel at batch 1 (4 = the
- * three-role experiment where compiled in); 17: 2 = the whole-step kernel's key-block attention role also for contexts of one block; 16: 2 = the ticketed sampler launch instead of the one-workgroup step tail at batch 1 (the default for greedy decoding), 3 = the one-workgroup tail also with a temperature.  Every path gives bit-identical
+ * re-arm a handle demoted by a hand-off timeout; 15: 2 = one chain launch per block instead of the whole-step kernel at batch 1; 16: 2 = the ticketed sampler launch instead of the one-workgroup step tail at batch 1 (the default for greedy decoding), 3 = the one-workgroup tail also with a temperature.  Every path gives bit-identical
  * results.  14: one-shot test hooks for the next generation (7: hand-off tags about to wrap; 9: the timeout word found set; 11: every
  * whole-step launch stops all its waves for 30 ms in block 2, as a paused device would).  Keys 0 .. 19. */
 int zn_debug_tune(zn_handle h, int32_t key, int32_t value);

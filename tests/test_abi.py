@@ -124,7 +124,7 @@ def test_persistent_kernels_use_no_scratch_and_fit_one_workgroup_per_cu(lib, tmp
                 g = lambda key: int(re.search(r"\.%s:\s+(\d+)" % key, k).group(1))
                 seen[name] = dict(scratch=g("private_segment_fixed_size"), spill=g("vgpr_spill_count"), vgpr=g("vgpr_count"),
                                   lds=g("group_segment_fixed_size"), threads=g("max_flat_workgroup_size"))
-    assert len(seen) == 10, sorted(seen)                 # 6 chain instantiations + 4 whole-step ones (legacy attention role; key-block role for <= 6 / 8 / 12 blocks)
+    assert len(seen) == 9, sorted(seen)                  # 6 chain instantiations + 3 whole-step ones (launches covering <= 6 / 8 / 12 key blocks)
     for name, r in seen.items():
         assert r["scratch"] == 0 and r["spill"] == 0, (name, r)
         waves = r["threads"] // 64
@@ -183,7 +183,7 @@ def _check_ticket_kernel(ins):
 
 
 def test_ticketed_combines_use_write_through_stores_and_sc1_loads(kernels_isa):
-    names = [n for n in kernels_isa if re.match(r"_Z14gemm16s_kernelILi\d+ELi\d+EE", n) or re.match(r"_Z14attn_pv_kernelILi\d+ELi\d+ELi2EE", n)
+    names = [n for n in kernels_isa if re.match(r"_Z14gemm16s_kernelILi\d+ELi\d+EE", n) or re.match(r"_Z17attn_block_kernelILi\d+ELi\d+ELb0EE", n)
              or re.match(r"_Z14gemm64s_kernelILi\d+EE", n)]
     assert len(names) >= 10
     for n in names:
@@ -194,21 +194,19 @@ def test_chain_kernel_handoffs_are_granules_and_sc1_sweeps(kernels_isa):
     """The persistent chain publishes 8-byte {tag, data} granules with ONE write-through store each (the data is the flag:
     Guideline 16 R2) and every load of handed-off bytes is an sc1 buffer load."""
     names = [n for n in kernels_isa if n.startswith("_Z12chain_kernel") or n.startswith("_Z11step_kernel")]
-    assert len(names) == 10                                                           # 6 chain instantiations + 4 whole-step ones
+    assert len(names) == 9                                                            # 6 chain instantiations + 3 whole-step ones
     for n in names:
         ins = kernels_isa[n]
         assert not any(l.startswith("scratch_") for l in ins), n
         sweeps = [l for l in ins if l.startswith("buffer_load_dwordx4")]
         if n.startswith("_Z11step_kernel"):
             # the attention workgroups' K / V prefetch reads cache rows written by EARLIER launches (the newest row comes through
-            # granules): plain buffer loads, two issue sites (kernel start, end of a block); legacy role 16 + 16 + 4 + 4 per site (K of two
-            # blocks, a value slice of each), key-block role 16 + 16 (K and full-width V of one block)
+            # granules): plain buffer loads, 16 (K of the block) + 16 (full-width V) per issue site, two sites (kernel start, end of a block)
             plain = [l for l in sweeps if " sc1" not in l]
-            legacy = re.match(r"_Z11step_kernelILi\d+ELi\d+ELi\d+ELi\d+ELi\d+ELi0EE", n) is not None
-            assert len(plain) == (80 if legacy else 64), (n, len(plain))
-            if not legacy:                                                            # e sums of the partials: one 8-byte granule per block
-                assert any(l.startswith("buffer_load_dwordx2") and " sc1" in l for l in ins), n
-                assert all(" sc1" in l for l in ins if l.startswith("buffer_load_dwordx2")), n
+            assert len(plain) == 64, (n, len(plain))
+            # e sums of the partials: one 8-byte granule per block
+            assert any(l.startswith("buffer_load_dwordx2") and " sc1" in l for l in ins), n
+            assert all(" sc1" in l for l in ins if l.startswith("buffer_load_dwordx2")), n
             sweeps = [l for l in sweeps if " sc1" in l]
             assert len(sweeps) >= 20, n
         assert sweeps and all(" sc1" in l for l in sweeps), n

@@ -63,14 +63,12 @@ def test_chain_generate_vs_oracle():
     assert worst <= 0.06
 
 
-@pytest.mark.parametrize("which", ["chain512", "full-chain", "full-step", "full-step-kb"])
+@pytest.mark.parametrize("which", ["chain512", "full-chain", "full-step"])
 def test_chain_is_bit_identical_to_the_launches_path(which):
     """Free-running greedy generation through the persistent kernels and through the per-op launches (zn_debug_tune(8, 2)).  At the
     Zonos-v0.1-transformer dimensions every path cuts every dot product the same way (fc2's K = 8192 in four quarters): equal
     codes and bit-equal logits at every step (200 steps: 8-step graphs, the fused attention arithmetic, hand-offs replayed
-    26 x 6 x 200 times), for one chain launch per block (zn_debug_tune(15, 2)), for the whole-step kernel (the default: 32 attention
-    workgroups, one per value slice) and for the whole-step kernel with its key-block attention role at one block (zn_debug_tune(17, 2):
-    8 attention workgroups, 248 streaming ones).  At
+    26 x 6 x 200 times), for one chain launch per block (zn_debug_tune(15, 2)) and for the whole-step kernel (the default).  At
     d_model 512 the launches path keeps fc2's K = 2048 in one wave while the chain splits it in quarters - another summation
     order: equal codes, logits within one bf16 ulp of a hidden value."""
     cfg, seed, n = (synth.CHAIN_CFG, 55, 60) if which == "chain512" else (synth.FULL_CFG, 1234, 200)
@@ -78,7 +76,6 @@ def test_chain_is_bit_identical_to_the_launches_path(which):
     eng = model.engine(1)
     cond = synth.conditioning(seed, "cond", 2, 24, cfg["d_model"])
     eng.call("zn_debug_tune", 15, {"full-chain": 2}.get(which, 1))
-    eng.call("zn_debug_tune", 17, 2 if which == "full-step-kb" else 1)
     try:
         a, la, pa = _run(model, cond, n, chain=True)
         b, lb, pb = _run(model, cond, n, chain=False)
@@ -99,16 +96,14 @@ def test_chain_is_bit_identical_to_the_launches_path(which):
         assert eng.counters()["handoff_timeouts"] == 0
     finally:
         eng.call("zn_debug_tune", 15, 1)
-        eng.call("zn_debug_tune", 17, 1)
 
 
 def test_whole_step_kernel_is_bit_identical_to_the_chain_path():
     """The whole-step kernel (csrc/zn_step_kernel.h: every block of the decode step in ONE launch; the default at batch 1) against one
     attention launch (two beyond 512 keys) + one chain launch per block (zn_debug_tune(15, 2)) at the Zonos-v0.1-transformer dimensions:
     free-running greedy codes equal and the logits of every step bit-equal, over single-step launches (trace mode, 40 steps) and over
-    8-step graphs (300 steps: contexts 26 .. 333), with an audio prefix (contexts 426 .. 700, across the 512-key boundary where the
-    attention role changes from one workgroup per value slice to one per key block) and through the second and third block (contexts
-    650 .. 1050, logits of every step).  A hand-off timeout is an error (the bounded waits describe themselves: zn_last_error)."""
+    8-step graphs (300 steps: contexts 26 .. 333), with an audio prefix (contexts 426 .. 700, across the 512-key boundary where a second
+    attention workgroup per (row, kv head) joins) and through the second and third block (contexts 650 .. 1050, logits of every step).  A hand-off timeout is an error (the bounded waits describe themselves: zn_last_error)."""
     cfg, seed = synth.FULL_CFG, 1234
     model, _ = build_model(cfg, seed, "cuda:0")
     eng = model.engine(1)
@@ -153,9 +148,9 @@ def test_whole_step_kernel_is_bit_identical_to_the_chain_path():
 
 def test_whole_step_kernel_at_long_contexts_is_bit_identical_to_the_per_block_path():
     """Contexts beyond 1024 keys (the reference's default call is 30 s = 2.6 k keys, `zonos/model.py:359`; BASELINE config 5 runs at
-    2.6 - 5.2 k): the whole-step kernel's key-block attention role (one workgroup per (row, kv head, 512-key block), K and full-width V of
+    2.6 - 5.2 k): the whole-step kernel's attention role (one workgroup per (row, kv head, 512-key block), K and full-width V of
     the block in registers a block ahead, block maxima and partials exchanged as granules, the in-order combine of the split P.V pass)
-    against the per-block path (attn_scores_kernel + attn_pv_kernel<.., 2> + one chain launch per block, zn_debug_tune(15, 2)) and, for
+    against the per-block path (attn_scores_kernel + attn_block_kernel + one chain launch per block, zn_debug_tune(15, 2)) and, for
     the traced steps, against the launches path (zn_debug_tune(8, 2)): equal codes over the whole run (8-step graphs; contexts 1025 ..
     2725, 2585 .. 5225 = config 5, and across the 3072- and 4096-key changes of instantiation, up to the kernel's 6144-key limit and
     past it, where both runs take the per-block path) and bit-equal logits at every traced step."""

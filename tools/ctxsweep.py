@@ -1,10 +1,9 @@
 """Decode-step time at batch 1 over the context length, per decode path (GPU box): hipGraph-replayed steps on a cache filled with
 random rows, `steps` steps from each starting context.
 
-    python tools/ctxsweep.py [steps=160] [contexts=100,300,450,...] [modes=stack,stack-kb1,chain]
+    python tools/ctxsweep.py [steps=160] [contexts=100,300,450,...] [modes=stack,chain,launches]
 
-modes: stack = the default (whole-step kernel: legacy attention role up to 512 keys, key-block role beyond); stack-kb1 = the key-block role
-also for one block (zn_debug_tune(17, 2)); chain = one chain launch per block (zn_debug_tune(15, 2)); launches = per-op launches.
+modes: stack = the default (whole-step kernel); chain = one chain launch per block (zn_debug_tune(15, 2)); launches = per-op launches.
 Prints ms per decode step and the algorithmic HBM rate (SURVEY.md section 8d bytes at the middle context of the run)."""
 import ctypes as C
 import os
@@ -18,13 +17,13 @@ from zonos_amd.codebook_pattern import apply_delay_pattern  # noqa: E402
 from zonos_amd.model import _sampling_struct  # noqa: E402
 from zonos_amd.testing import build_model  # noqa: E402
 
-MODES = {"stack": {15: 1, 17: 1, 8: 1}, "stack-kb1": {15: 1, 17: 2, 8: 1}, "chain": {15: 2, 17: 1, 8: 1}, "launches": {15: 1, 17: 1, 8: 2}}
+MODES = {"stack": {15: 1, 8: 1}, "chain": {15: 2, 8: 1}, "launches": {15: 1, 8: 2}}
 
 
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 160
     ctxs = [int(c) for c in (sys.argv[2] if len(sys.argv) > 2 else "100,300,450,600,900,1100,1600,2100,2600,3200,3800,4400,5000,5600").split(",")]
-    modes = (sys.argv[3] if len(sys.argv) > 3 else "stack,stack-kb1,chain").split(",")
+    modes = (sys.argv[3] if len(sys.argv) > 3 else "stack,chain").split(",")
     dev = "cuda:0"
     model, _ = build_model(synth.FULL_CFG, 1234, dev)
     eng = model.engine(1)

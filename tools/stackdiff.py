@@ -12,7 +12,6 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 24
 model, _ = build_model(synth.FULL_CFG, 1234, "cuda:0")
 eng = model.engine(1)
 eng.call("zn_debug_eos_bias", float("-inf"))
-eng.call("zn_debug_tune", 5, 1024)
 cond = synth.conditioning(1234, "cond", 2, int(os.environ.get("ZN_LC", "24")), 2048).to("cuda:0")
 res = {}
 for name, t15 in (("chain", 2), ("stack", 1), ("stack2", 1), ("threerole", 4)):

@@ -4,9 +4,6 @@
 #include "zn_decode_kernels.h"
 #include "zn_chain_kernel.h"
 #include "zn_step_kernel.h"
-#ifdef ZN_WITH_STEP3
-#include "zn_step3_kernel.h"     // the three-role whole-step experiment: not in the default library
-#endif
 #include "zn_prefill_kernels.h"
 #include "zn_cond_kernels.h"
 #include "zn_mamba_kernels.h"
@@ -45,11 +42,11 @@ struct zn_handle_s {
   unsigned long long *ch_gy1 = nullptr, *ch_gx1 = nullptr, *ch_gx2 = nullptr, *ch_gm = nullptr;
   unsigned long long *ch_gqkv = nullptr, *ch_ga = nullptr;   // whole-step kernel: q | k | v of the next block, attention output
   unsigned long long *ch_gbmax = nullptr, *ch_gpart = nullptr;   // key-block attention role: per-block score maxima and P.V partials (zn_step_kernel.h)
-  int stack_nbk = 0;                         // attention role of the whole-step launches being enqueued: 0 = legacy (one workgroup per value slice), n >= 1 = one per key block, n blocks
+  int stack_nbk = 1;                         // key blocks (8 attention workgroups each) of the whole-step launches being enqueued
   int graph_nbk[8] = {};                     // ... that a captured graph was built with
-  bool stackv_ok[4] = {};                    // whole-step kernel instantiations that fit this model and device (stack_variant_ok)
+  bool stackv_ok[4] = {};                    // whole-step kernel instantiations 1 .. 3 that fit this model and device (stack_variant_ok)
   StackLayer* stack_layers = nullptr;        // device table [n_layer], rebuilt by zn_gen_begin (it holds the KV cache pointers)
-  bool use_stack = false, stack_ok = false, stack_checked = false, stack3_ok = false;   // stack3: the three-role whole-step kernel (zn_step3_kernel.h)                    // the steps being enqueued run the whole-step kernel
+  bool use_stack = false, stack_ok = false, stack_checked = false;   // use_stack: the steps being enqueued run the whole-step kernel
   unsigned* ch_epoch = nullptr;
   unsigned long long epoch_bound = 1;        // host-side upper bound of the device epoch (tags advance by one per block of every decode step enqueued)
   unsigned* ch_diag = nullptr;               // [8] words: the first hand-off wait that timed out describes itself (sweep_granules)
@@ -77,7 +74,7 @@ struct zn_handle_s {
   float *logits_raw = nullptr, *last_logits = nullptr;
   int* tok_raw = nullptr;
   float *scores = nullptr, *cmax = nullptr;
-  float* pv_part = nullptr;    // split P.V pass: partials per (row, kv head, slice, block)
+  float* pv_part = nullptr;    // split P.V pass: partials per (row, kv head, block)
   int* pv_tickets = nullptr;
   bf16_t *pf_x = nullptr, *pf_n = nullptr, *pf_qkv = nullptr, *pf_a = nullptr, *pf_u = nullptr, *pf_m = nullptr;   // batched-prefill workspace
   // hybrid batched prefill: residual stream (bf16, or fp32 with residual_in_fp32), in_proj output, conv output, scan output, gated-normalised
@@ -488,10 +485,10 @@ static int run_gemv(zn_handle h, GemvArgs a, int rows, int target_blocks, hipStr
 }
 
 // ONE arithmetic for the decode attention on every path (launches, per-block chain, whole-step kernels): scores on the matrix cores in
-// one summation order; contexts of one 512-key block (the reference's block size) are walked in place, longer ones block by block with
-// the blocks' unnormalised partials combined by the reference's recurrence acc = acc * f_j + pv_j in block order (attn_pv_kernel<.., 2>,
-// the key-block attention role of zn_step_kernel.h).  So the fused launch (scores + pass 2 in one launch, in-place accumulation over the
-// blocks) serves contexts up to 512 keys only: tune[5] may lower that limit (tests), never raise it.
+// one summation order, P.V per 512-key block (the reference's block size) on the matrix cores in one order, the blocks' unnormalised partials
+// combined by the reference's recurrence acc = acc * f_j + pv_j in block order (attn_block_probs / attn_block_pv, shared by the launches and
+// by the attention role of zn_step_kernel.h).  The fused launch (scores + pass 2 + normalisation in one launch) serves contexts of one block:
+// tune[5] may lower that limit (tests), never raise it.
 #define ZN_AFUSED_LIMIT 512
 static bool attn_fused_for(zn_handle h, int keys_upper_bound) {
   const int lim = h->tune[5] < ZN_AFUSED_LIMIT ? h->tune[5] : ZN_AFUSED_LIMIT;
@@ -502,9 +499,9 @@ template <int HD>
 static int launch_attn_g(const AttnArgs& a, int G, dim3 grid, bool fused, hipStream_t s) {
   switch (G) {
 #define ZN_ATTN_CASE(GG) case GG: \
-    if (fused) { hipLaunchKernelGGL((attn_pv_kernel<HD, GG, 1>), dim3((HD / 32) * grid.y * grid.z), dim3(512), 0, s, a); return 0; } \
+    if (fused) { hipLaunchKernelGGL((attn_block_kernel<HD, GG, true>), dim3(grid.y * grid.z), dim3(512), 0, s, a); return 0; } \
     hipLaunchKernelGGL((attn_scores_kernel<HD, GG>), grid, dim3(256), 0, s, a); \
-    hipLaunchKernelGGL((attn_pv_kernel<HD, GG, 2>), dim3(HD / 32, grid.y, grid.z * a.nbcap), dim3(512), 0, s, a); return 0;
+    hipLaunchKernelGGL((attn_block_kernel<HD, GG, false>), dim3(grid.y, grid.z * a.nbcap), dim3(512), 0, s, a); return 0;
     ZN_ATTN_CASE(1) ZN_ATTN_CASE(2) ZN_ATTN_CASE(4) ZN_ATTN_CASE(8)
 #undef ZN_ATTN_CASE
   }
@@ -521,8 +518,8 @@ static int ensure_attn_ws(zn_handle h, int max_len) {
   const int nc = lcap / ZN_ACHUNK;
   HIPCHK(h, hipMalloc(&h->scores, RH * lcap * sizeof(float)));
   HIPCHK(h, hipMalloc(&h->cmax, RH * nc * sizeof(float)));
-  { const size_t groups = (size_t)h->max_rows * h->cfg.n_heads_kv * (h->hd / 32);
-    HIPCHK(h, hipMalloc(&h->pv_part, groups * (lcap / 512) * (size_t)(h->G * 32 + h->G) * sizeof(float)));
+  { const size_t groups = (size_t)h->max_rows * h->cfg.n_heads_kv;
+    HIPCHK(h, hipMalloc(&h->pv_part, groups * (lcap / 512) * (size_t)(h->G * h->hd + h->G) * sizeof(float)));
     HIPCHK(h, hipMalloc(&h->pv_tickets, groups * sizeof(int)));
     HIPCHK(h, hipMemset(h->pv_tickets, 0, groups * sizeof(int))); }
   h->lcap = lcap;
@@ -666,16 +663,14 @@ static int launch_chain(zn_handle h, int li, const std::vector<const void*>& kv_
 // Whole-step kernel (zn_step_kernel.h): batch 1 at the Zonos-v0.1 shapes: in_proj(0) + ONE launch per decode step.  The default at batch 1;
 // zn_debug_tune(15, 2) or ZN_STACK=0 in the environment at zn_create selects one chain launch per block.  Instantiations (static tile schedules
 // for the streaming workgroups the attention role leaves):
-//   variant 0  <4, 2, 10, 5, 6, 0>  legacy attention role, 32 workgroups (one per value slice): contexts of one 512-key block
-//   variant 1  <4, 2, 10, 5, 6, 6>  key-block attention role, 1 .. 6 blocks  (8 .. 48 attention workgroups: contexts up to 3072 keys)
-//   variant 2  <4, 2, 11, 6, 7, 8>  7 .. 8 blocks   (up to 4096 keys)
+//   variant 1  <4, 2, 10, 5, 6, 6>   1 .. 6 key blocks  (8 .. 48 attention workgroups: contexts up to 3072 keys)
+//   variant 2  <4, 2, 11, 6, 7, 8>   7 .. 8 blocks   (up to 4096 keys)
 //   variant 3  <4, 2, 13, 7, 8, 12>  9 .. 12 blocks  (up to 6144 keys); longer contexts take the per-block path
-#define ZN_SK_T0 4, 2, 10, 5, 6, 0
 #define ZN_SK_T1 4, 2, 10, 5, 6, 6
 #define ZN_SK_T2 4, 2, 11, 6, 7, 8
 #define ZN_SK_T3 4, 2, 13, 7, 8, 12
-static int stack_variant_of(int mode) { return mode <= 0 ? 0 : mode <= 6 ? 1 : mode <= 8 ? 2 : 3; }
-template <int NCH, int T_OUT, int T_FC1, int T_FC2, int T_IN, int ATT>
+static int stack_variant_of(int mode) { return mode <= 6 ? 1 : mode <= 8 ? 2 : 3; }
+template <int NCH, int T_OUT, int T_FC1, int T_FC2, int T_IN, int NBV>
 static bool stack_variant_ok(zn_handle h, int natt) {
   const zn_config& c = h->cfg;
   const int nsw = ZN_CH_GRID - natt;
@@ -686,11 +681,11 @@ static bool stack_variant_ok(zn_handle h, int natt) {
   if (p_out > ZN_SK_CW * T_OUT || p_out > T_FC2 || p_fc1 > ZN_SK_CW * T_FC1 || p_qkv > ZN_SK_CW * T_IN || p_hd > ZN_SK_CW * T_IN) return false;   // the static schedule
   if (p_out * 2 > 64 || p_out * 4 > 64 || p_fc1 > 64 || p_qkv * 2 > 64 || p_hd * 2 > 64 || nqkv % 2) return false;              // one epilogue lane per (unit, row); s_res slots
   // every workgroup of the grid must be resident at once (the hand-offs wait on all of them): one per CU by its LDS, no scratch
-  const void* fn = (const void*)step_kernel<NCH, T_OUT, T_FC1, T_FC2, T_IN, ATT>;
+  const void* fn = (const void*)step_kernel<NCH, T_OUT, T_FC1, T_FC2, T_IN, NBV>;
   int dev = 0, n_cus = 0, per_cu = 0;
   if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) { (void)hipGetLastError(); return false; }
   if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, ZN_SK_DYN_LDS) != hipSuccess) { (void)hipGetLastError(); return false; }
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, step_kernel<NCH, T_OUT, T_FC1, T_FC2, T_IN, ATT>, ZN_SK_THREADS, ZN_SK_DYN_LDS) != hipSuccess) { (void)hipGetLastError(); return false; }
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, step_kernel<NCH, T_OUT, T_FC1, T_FC2, T_IN, NBV>, ZN_SK_THREADS, ZN_SK_DYN_LDS) != hipSuccess) { (void)hipGetLastError(); return false; }
   hipFuncAttributes fa{};
   if (hipFuncGetAttributes(&fa, fn) != hipSuccess) { (void)hipGetLastError(); return false; }
   return per_cu >= 1 && n_cus >= ZN_CH_GRID && fa.localSizeBytes == 0;
@@ -699,52 +694,18 @@ static bool stack_shapes_ok(zn_handle h) {
   const zn_config& c = h->cfg;
   if (h->ch_variant != 1 || h->hd != 128 || c.n_heads_kv < 1 || c.n_heads != 4 * c.n_heads_kv) return false;
   const int npairs = 2 * c.n_heads_kv;
-  h->stackv_ok[0] = stack_variant_ok<ZN_SK_T0>(h, npairs * (h->hd / 32));
+  h->stackv_ok[0] = false;
   h->stackv_ok[1] = stack_variant_ok<ZN_SK_T1>(h, npairs * 6);
   h->stackv_ok[2] = stack_variant_ok<ZN_SK_T2>(h, npairs * 8);
   h->stackv_ok[3] = stack_variant_ok<ZN_SK_T3>(h, npairs * ZN_SK_KB_MAXNB);
-  return h->stackv_ok[0] || h->stackv_ok[1];
+  return h->stackv_ok[1];
 }
-#ifdef ZN_WITH_STEP3
-// The three-role whole-step kernel (zn_step3_kernel.h: attention / projection / bulk workgroups): a measured experiment (bit-identical, slower),
-// compiled only with -DZN_WITH_STEP3 and then selected by zn_debug_tune(15, 4).
-#define ZN_S3_T 4, 13, 7, 8
-static bool stack3_shapes_ok(zn_handle h) {
-  const zn_config& c = h->cfg;
-  if (!h->stackv_ok[0]) return false;                        // same model family, same attention role
-  const int natt = 2 * c.n_heads_kv * (h->hd / 32), nbw = ZN_CH_GRID - natt - ZN_S3_NPROJ;
-  const int nqkv = (c.n_heads + 2 * c.n_heads_kv) * h->hd;
-  if (nbw < 64 || c.n_layer < 2) return false;
-  if ((c.d_model / 2) != ZN_S3_NPROJ * 8 * ZN_S3_TO || (nqkv / 2) != ZN_S3_NPROJ * 8 * ZN_S3_TI) return false;   // the projection waves' register-resident slices
-  auto most = [&](int units) { return (units + nbw - 1) / nbw; };
-  const int p_fc1 = 2 * most(c.d_ff / 2), p_fc2 = most(c.d_model / 2), p_hd = most((c.n_codebooks * c.vocab_head + 1) / 2);
-  if (p_fc1 > ZN_SK_CW * 13 || p_fc2 > 7 || p_hd > ZN_SK_CW * 8) return false;                                    // the static schedule <4, 13, 7, 8>
-  if (p_fc1 > 64 || p_fc2 * 2 > 64 || p_hd * 2 > 64) return false;
-  int per_cu = 0;
-  if (hipFuncSetAttribute((const void*)step3_kernel<ZN_S3_T>, hipFuncAttributeMaxDynamicSharedMemorySize, ZN_S3_DYN_LDS) != hipSuccess) { (void)hipGetLastError(); return false; }
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, step3_kernel<ZN_S3_T>, ZN_SK_THREADS, ZN_S3_DYN_LDS) != hipSuccess) { (void)hipGetLastError(); return false; }
-  hipFuncAttributes fa{};
-  if (hipFuncGetAttributes(&fa, (const void*)step3_kernel<ZN_S3_T>) != hipSuccess) { (void)hipGetLastError(); return false; }
-  return per_cu >= 1 && fa.localSizeBytes == 0;
-}
-static bool stack3_selected(zn_handle h) { return h->stack3_ok && h->tune[15] == 4; }
-#else
-static bool stack3_shapes_ok(zn_handle) { return false; }
-static bool stack3_selected(zn_handle) { return false; }
-#endif
-// The attention role a whole-step launch covering `keys_upper_bound` keys would run with: -1 = the whole-step kernel does not serve the step
-// (the per-block path does), 0 = legacy role, n >= 1 = key-block role with n blocks.  One 512-key block: the legacy role by default
-// (zn_debug_tune(17, 2): the key-block role there too; both give the same bits).  Longer contexts: the key-block role - its block-by-block
-// combine is the library's definition of the attention beyond one block (attn_fused_for).
+// The key blocks a whole-step launch covering `keys_upper_bound` keys needs: -1 = the whole-step kernel does not serve the step (the
+// per-block path does), n >= 1 = 8 n attention workgroups.
 static int stack_mode_for(zn_handle h, int rows, int keys_upper_bound) {
   if (!chain_active(h, rows) || h->tune[15] == 2 || !h->stack_ok) return -1;
-  const int nb = (keys_upper_bound + 511) / 512;
-  if (nb <= 1) {
-    if (stack3_selected(h)) return 0;
-    if (h->tune[17] == 2 && h->stackv_ok[1]) return 1;
-    return h->stackv_ok[0] ? 0 : h->stackv_ok[1] ? 1 : -1;
-  }
-  if (stack3_selected(h) || nb > ZN_SK_KB_MAXNB) return -1;
+  const int nb = keys_upper_bound <= 512 ? 1 : (keys_upper_bound + 511) / 512;
+  if (nb > ZN_SK_KB_MAXNB) return -1;
   return h->stackv_ok[stack_variant_of(nb)] ? nb : -1;
 }
 static int launch_stack(zn_handle h, hipStream_t s) {
@@ -762,13 +723,9 @@ static int launch_stack(zn_handle h, hipStream_t s) {
   a.layers = h->stack_layers; a.n_layer = c.n_layer; a.q0 = h->q; a.scale = (float)(1.0 / std::sqrt((double)h->hd));
   a.heads_rows = c.n_codebooks * c.vocab_head; a.heads_out = h->logits_raw; a.trace = h->dbg_trace;
   const int mode = h->stack_nbk, npairs = 2 * c.n_heads_kv;
-  a.natt = mode <= 0 ? npairs * (h->hd / 32) : npairs * mode;
+  a.natt = npairs * (mode < 1 ? 1 : mode);
   const dim3 grid(ZN_CH_GRID), block(ZN_SK_THREADS);
-#ifdef ZN_WITH_STEP3
-  if (mode == 0 && stack3_selected(h)) { hipLaunchKernelGGL((step3_kernel<ZN_S3_T>), grid, block, ZN_S3_DYN_LDS, s, a); return ZN_OK; }
-#endif
   switch (stack_variant_of(mode)) {
-    case 0: hipLaunchKernelGGL((step_kernel<ZN_SK_T0>), grid, block, ZN_SK_DYN_LDS, s, a); break;
     case 1: hipLaunchKernelGGL((step_kernel<ZN_SK_T1>), grid, block, ZN_SK_DYN_LDS, s, a); break;
     case 2: hipLaunchKernelGGL((step_kernel<ZN_SK_T2>), grid, block, ZN_SK_DYN_LDS, s, a); break;
     default: hipLaunchKernelGGL((step_kernel<ZN_SK_T3>), grid, block, ZN_SK_DYN_LDS, s, a); break;
@@ -1079,7 +1036,7 @@ extern "C" int zn_gen_begin(zn_handle h, int32_t batch, const void* const* kv_la
   // batch 1 on a model the persistent kernels serve: claim the device for them, or run this generation on the launches path
   h->persist_ok = !(h->cfg.arch == 0 && h->ch_variant != 0 && batch == 1) || zn_tenant_try_claim(h->device, h) != 0;
   if (h->cfg.arch == 0 && h->ch_variant == 1) {
-    if (!h->stack_checked) { h->stack_ok = stack_shapes_ok(h); h->stack3_ok = stack3_shapes_ok(h); h->stack_checked = true; }
+    if (!h->stack_checked) { h->stack_ok = stack_shapes_ok(h); h->stack_checked = true; }
     if (h->stack_ok) { int rc = build_stack_table(h); if (rc) return rc; }
   }
   GenState st{};
@@ -1477,7 +1434,7 @@ extern "C" int zn_get_counters(zn_handle h, int64_t* out, int32_t n) {
 extern "C" int zn_decode_path(zn_handle h) { return (h && h->gen_active && h->cfg.arch == 0 && chain_active(h, h->rows)) ? 1 : 0; }
 extern "C" int zn_decode_path_detail(zn_handle h) {
   if (!h || !h->gen_active || h->cfg.arch != 0 || !chain_active(h, h->rows)) return 0;
-  return h->use_stack ? (stack3_selected(h) ? 3 : 2) : 1;
+  return h->use_stack ? 2 : 1;
 }
 extern "C" int zn_graph_active(zn_handle h) {
   if (!h) return 0;
@@ -1606,7 +1563,7 @@ extern "C" int zn_bench_kernel(zn_handle h, int32_t which, int32_t rows, int32_t
   const int ctx = ctx_arg > 0 ? ctx_arg : 450;
   if (which == 6) {
     if (!chain_active(h, rows)) ZN_FAIL(h, ZN_ERR_UNSUPPORTED, "zn_bench_kernel: the whole-step kernel serves batch 1 (2 rows) of the transformer only");
-    if (!h->stack_checked) { h->stack_ok = stack_shapes_ok(h); h->stack3_ok = stack3_shapes_ok(h); h->stack_checked = true; }
+    if (!h->stack_checked) { h->stack_ok = stack_shapes_ok(h); h->stack_checked = true; }
     h->stack_nbk = stack_mode_for(h, rows, ctx + 1);
     if (h->stack_nbk < 0) ZN_FAIL(h, ZN_ERR_UNSUPPORTED, "zn_bench_kernel: the whole-step kernel does not serve this model / context");
     const int cap = ctx + 8;

@@ -876,8 +876,8 @@ struct AttnArgs {
   int ext_scalar;       // used when ext == NULL and > 0
   int max_len, n_heads, n_heads_kv, lcap;   // lcap = scores row stride (multiple of 512)
   int rows;             // activation rows (fused variant's 1-D grid decode)
-  float* part;          // split variant: per (row, kv head, slice, block) partial [G*32 + G] (P.V sums, e sums)
-  int* tickets;         // split variant: arrival counter per (row, kv head, slice)
+  float* part;          // split variant: per (row, kv head, block) partial [G*HD + G] (P.V sums, e sums)
+  int* tickets;         // split variant: arrival counter per (row, kv head)
   int nbcap;            // split variant: blocks the grid covers (lcap / 512)
   float scale;
   float* scores;        // [rows][Hq][lcap]
@@ -944,88 +944,158 @@ __global__ __launch_bounds__(256) void attn_scores_kernel(AttnArgs a) {
   }
 }
 
-// Pass 2 runs in one of two shapes, both with the reference's rounding (512-key blocks, running max, e / P = bf16(e), P.V in fp32):
-//
-// MODE 1, FUSED (contexts of ONE 512-key block, i.e. up to 512 keys; the host never selects it beyond): one workgroup per (32-wide
-// value slice, kv head, row) first computes the scores of all keys of its kv head into LDS (the arithmetic of attn_scores_kernel; the
-// HD/32 slice workgroups of one (row, kv head) repeat it, and the 1-D grid puts them on one XCD so that K comes from that XCD's L2
-// after the first touch) and then runs pass 2 from LDS: one launch instead of two on the latency-bound chain.  (Its block loop can walk
-// further blocks accumulating in place - acc = acc * f + p.v per key - which rounds differently from the combine below; that is why the
-// host keeps it to one block, where the two coincide.)
-// MODE 2, SPLIT (longer contexts): one workgroup per (slice, kv head, row, 512-key BLOCK): the block's running max comes from the chunk
-// maxima of all earlier chunks, its unnormalised P.V and e sums leave as write-through partials, and the last workgroup of a (row, kv
-// head, slice) to arrive (ticket, no waiting) replays the reference's recurrence acc = acc * f_j + pv_j over the blocks in order and
-// normalises.  This is the library's definition of the decode attention beyond one block: the whole-step kernel's key-block attention
-// role (zn_step_kernel.h) reproduces it bit for bit.
-#define ZN_AFUSED_MAX 2048
-template <int HD, int G, int MODE>
-__global__ __launch_bounds__(512) void attn_pv_kernel(AttnArgs a) {
-  static_assert(MODE == 1 || MODE == 2, "fused (one block) or split (one workgroup per block)");
-  constexpr bool FUSED = MODE == 1, SPLIT = MODE == 2;
-  constexpr int NW = 8;                                   // waves per workgroup; 16 keys per wave-load -> 128 keys per round
-  constexpr int NR = 512 / (NW * 16);                     // rounds per 512-key block
-  constexpr int GL = (G + 3) / 4;                         // heads a lane evaluates: g = vsub + 4*q
-  int slice, kvh, r;
-  if constexpr (FUSED) {
-    // blockIdx.x = pair + npairs * slice with pair = r * Hkv + kvh: with 8 (row, kv head) pairs the slices of a pair
-    // share blockIdx.x % 8, i.e. one XCD under round-robin placement (speed only, never correctness)
-    const int npairs = a.n_heads_kv * a.rows;
-    const int pair = blockIdx.x % npairs;
-    slice = blockIdx.x / npairs; kvh = pair % a.n_heads_kv; r = pair / a.n_heads_kv;
-  } else { slice = blockIdx.x; kvh = blockIdx.y; r = blockIdx.z / a.nbcap; }
-  const int jb = SPLIT ? (int)(blockIdx.z % a.nbcap) : 0;       // SPLIT: the block this workgroup owns
+// ---- Pass 2 of ONE 512-key block of a (row, kv head) pair: the library's definition of the decode attention, shared by the launches below and
+// by the whole-step kernel's attention role (zn_step_kernel.h), so that every path gives the same bits at every context length:
+//   e_t = exp(s_t - m) with m = the running maximum through this block (fexp_u20 for the first 16 * floor(n / 16) keys of the block, libm exp
+//   for the rest: the reference's SIMD / scalar split), row sum of the unrounded e_t, P = bf16(e_t);
+//   P.V on the matrix cores: each of the workgroup's 8 waves contracts its 64 keys as two 16x16x32 steps per 16-column tile (A = P: rows =
+//   the G heads, k = 32 consecutive keys; B = V: k = keys, columns = value dims), fp32 accumulate; the 8 per-wave partials are added in wave
+//   order.  Blocks of one context are combined by the reference's recurrence acc = acc * f_j + pv_j, lsum = lsum * f_j + l_j in block order.
+// (Rounds 1-3 accumulated P.V on the VALU, key by key per lane: 0.8 us per 32-wide value slice and block against 0.2 us for all 128 columns here.)
+template <int HD> struct AttnV { unsigned v[2][8][HD / 32]; };    // lane (kn = l & 15, kg = l >> 4): [32-key step][key 8 kg + j of the step] x dims (HD / 16) kn .. + HD / 16
+
+// e, P and the row sums of a block.  sc: the block's scores [G][512] in LDS; mnew: the running maximum through this block for the heads this
+// lane evaluates (vsub + 4 q, vsub = lane & 3); p: P [G][512] (zero past nkeys); l_out[wave][g]: per-wave sums of e.
+template <int G>
+ZN_DEVINL void attn_block_probs(const float (*sc)[512], const float (&mnew)[(G + 3) / 4], int nkeys, int nvec, bf16_t (*p)[512], float (*l_out)[G], int wave, int lane) {
+  constexpr int GL = (G + 3) / 4, NW = 8, NR = 4;
+  const int vsub = lane & 3, vkey = lane >> 2;           // 16 keys per wave and round, 4 rounds: key = i * 128 + wave * 16 + vkey
+  float lsum[GL];
+#pragma unroll
+  for (int q = 0; q < GL; ++q) lsum[q] = 0.f;
+#pragma unroll
+  for (int i = 0; i < NR; ++i) {
+    const int base = i * (NW * 16), idx = base + wave * 16 + vkey;
+    const bool ok = idx < nkeys;
+#pragma unroll
+    for (int q = 0; q < GL; ++q) {
+      const int g = min(vsub + 4 * q, G - 1);
+      const float x = __fsub_rn(ok ? sc[g][idx] : 0.f, mnew[q]);
+      float ev;
+      if (base + NW * 16 <= nvec) ev = ok ? zn_fexp_u20(x) : 0.f;          // whole round inside the SIMD part: fexp only (uniform branch)
+      else ev = ok ? ((idx < nvec) ? zn_fexp_u20(x) : expf(x)) : 0.f;
+      if (vsub + 4 * q < G) { lsum[q] += ev; p[vsub + 4 * q][idx] = f2bf(ev); }
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < GL; ++q) {
+    // lsum[q] of lane vsub belongs to head vsub + 4q: sum over the 16 lanes with that vsub, per wave
+    float ls = row_stride4_sum(lsum[q]);
+    ls = (readlane_f(ls, 0) + readlane_f(ls, 16)) + (readlane_f(ls, 32) + readlane_f(ls, 48));
+    float l1 = row_stride4_sum(lsum[q]); l1 = (readlane_f(l1, 1) + readlane_f(l1, 17)) + (readlane_f(l1, 33) + readlane_f(l1, 49));
+    float l2 = row_stride4_sum(lsum[q]); l2 = (readlane_f(l2, 2) + readlane_f(l2, 18)) + (readlane_f(l2, 34) + readlane_f(l2, 50));
+    float l3 = row_stride4_sum(lsum[q]); l3 = (readlane_f(l3, 3) + readlane_f(l3, 19)) + (readlane_f(l3, 35) + readlane_f(l3, 51));
+    if (lane == 0) {
+      if (4 * q + 0 < G) l_out[wave][4 * q + 0] = ls;
+      if (4 * q + 1 < G) l_out[wave][4 * q + 1] = l1;
+      if (4 * q + 2 < G) l_out[wave][4 * q + 2] = l2;
+      if (4 * q + 3 < G) l_out[wave][4 * q + 3] = l3;
+    }
+  }
+}
+
+// This wave's 64 keys of P.V on the matrix cores -> accw[wave][head][dim].  Column n of tile t is dim (HD / 16) n + t, so that a lane's row
+// pieces (HD / 16 consecutive dims of 8 keys) transpose in registers (v_perm_b32) into the B operands: no LDS transpose of V.
+template <int HD, int G>
+ZN_DEVINL void attn_block_pv(const bf16_t (*p)[512], const AttnV<HD>& V, float (*accw)[G][HD], int wave, int lane) {
+  static_assert(HD % 32 == 0 && G <= 16, "tile shape");
+  constexpr int DPL = HD / 16;                           // dims per lane and key = tiles
+  const int kn = lane & 15, kg = lane >> 4;
+  f32x4 pacc[DPL];
+#pragma unroll
+  for (int t = 0; t < DPL; ++t) pacc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    u32x4 pa = u32x4{0, 0, 0, 0};
+    if (kn < G) pa = *(const u32x4*)&p[kn][wave * 64 + 32 * ks + 8 * kg];
+#pragma unroll
+    for (int t = 0; t < DPL; ++t) {
+      const unsigned sel = (t & 1) ? 0x07060302u : 0x05040100u;
+      u32x4 bt;
+      bt.x = __builtin_amdgcn_perm(V.v[ks][1][t >> 1], V.v[ks][0][t >> 1], sel);
+      bt.y = __builtin_amdgcn_perm(V.v[ks][3][t >> 1], V.v[ks][2][t >> 1], sel);
+      bt.z = __builtin_amdgcn_perm(V.v[ks][5][t >> 1], V.v[ks][4][t >> 1], sel);
+      bt.w = __builtin_amdgcn_perm(V.v[ks][7][t >> 1], V.v[ks][6][t >> 1], sel);
+      pacc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(zn_bf16x8, pa), __builtin_bit_cast(zn_bf16x8, bt), pacc[t], 0, 0, 0);
+    }
+  }
+  // D: column = dim column kn, row = head 4 kg + reg
+#pragma unroll
+  for (int reg = 0; reg < 4; ++reg) {
+    const int head = 4 * kg + reg;
+    if (head < G) {
+#pragma unroll
+      for (int t = 0; t < DPL; ++t) accw[wave][head][DPL * kn + t] = pacc[t][reg];
+    }
+  }
+}
+
+// The value rows of this wave's 64 keys in AttnV's layout, by plain loads (rows clamped to the cache: the caller masks keys past the context).
+template <int HD>
+ZN_DEVINL void attn_block_load_v(AttnV<HD>& V, const bf16_t* vcol0, size_t kvrow, int key0, int row_max, int lane) {
+  constexpr int DPL = HD / 16;
+  const int kn = lane & 15, kg = lane >> 4;
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const bf16_t* src = vcol0 + (size_t)min(key0 + 32 * ks + 8 * kg + j, row_max) * kvrow + DPL * kn;
+      if constexpr (DPL == 8) { const u32x4 x = ld16(src); V.v[ks][j][0] = x.x; V.v[ks][j][1] = x.y; V.v[ks][j][2] = x.z; V.v[ks][j][3] = x.w; }
+      else if constexpr (DPL == 4) { const u32x2 x = *(const u32x2*)src; V.v[ks][j][0] = x.x; V.v[ks][j][1] = x.y; }
+      else V.v[ks][j][0] = *(const unsigned*)src;
+    }
+}
+// Rows past the context may be uninitialised memory (NaN bit patterns; 0 x NaN = NaN on the matrix cores): zero them.
+template <int HD>
+ZN_DEVINL void attn_block_mask_v(AttnV<HD>& V, int key0, int L, int lane) {
+  const int kg = lane >> 4;
+  if (key0 + 64 <= L) return;                             // wave-uniform
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (key0 + 32 * ks + 8 * kg + j >= L) {
+#pragma unroll
+        for (int q = 0; q < HD / 32; ++q) V.v[ks][j][q] = 0u;
+      }
+}
+
+// One launch per decode step and layer for contexts of ONE block (FUSED; up to 512 keys, host-checked: attn_fused_for), two beyond:
+// FUSED: one workgroup per (row, kv head) computes the block's scores into LDS itself (the arithmetic of attn_scores_kernel; K rows fetched
+//   whole and staged per wave in padded LDS), then pass 2, normalises and stores - one launch on the latency-bound chain.
+// SPLIT (!FUSED): after attn_scores_kernel, one workgroup per (row, kv head, 512-key block): running maximum from the chunk maxima of all
+//   earlier chunks, the block's unnormalised P.V and e sums leave as write-through partials, and the last workgroup of a (row, kv head) to
+//   arrive (ticket, no waiting) replays the recurrence over the blocks in order and normalises.
+template <int HD, int G, bool FUSED>
+__global__ __launch_bounds__(512) void attn_block_kernel(AttnArgs a) {
+  constexpr int NW = 8, GL = (G + 3) / 4;
+  int kvh, r, jb;
+  if constexpr (FUSED) { kvh = blockIdx.x % a.n_heads_kv; r = blockIdx.x / a.n_heads_kv; jb = 0; }
+  else { kvh = blockIdx.x; r = blockIdx.y / a.nbcap; jb = blockIdx.y % a.nbcap; }
   int nst = 0;
   auto stamp = [&]() { if (FUSED && a.stamps && blockIdx.x == 0 && threadIdx.x == 0) a.stamps[nst] = __builtin_amdgcn_s_memrealtime(); ++nst; };
   stamp();
-  // length (and span) first; the first block's requests below do not wait for them (clamped addresses, masked use)
+  // length (and span) first; the requests below do not wait for them (clamped addresses, masked use)
   const int Lraw = a.lengths[r];
   const int Eraw = a.ext ? a.ext[r] : a.ext_scalar;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int vsub = lane & 3, vkey = lane >> 2;           // 4 lanes x 16 B cover the 32-wide slice; 16 keys per wave-load
+  const int vsub = lane & 3;
   const size_t kvrow = (size_t)2 * a.n_heads_kv * HD;
-  const bf16_t* vbase = a.kv + (size_t)r * a.max_len * kvrow + (size_t)(a.n_heads_kv + kvh) * HD + slice * 32 + vsub * 8;
-  const int cstride = a.lcap / ZN_ACHUNK;
-  // this lane evaluates e only for heads vsub, vsub+4, ... and quad-broadcasts them (DPP); P.V needs all G heads
-  const float* srow[GL];
-  const float* crow[GL];
-#pragma unroll
-  for (int q = 0; q < GL; ++q) {
-    const int g = min(vsub + 4 * q, G - 1);
-    srow[q] = a.scores + ((size_t)r * a.n_heads + kvh * G + g) * a.lcap;
-    crow[q] = a.cmax + ((size_t)r * a.n_heads + kvh * G + g) * cstride;
-  }
-  u32x4 vnext[NR], vnextB[FUSED ? NR : 1];                // FUSED: values of even / odd blocks, requested two blocks ahead
-  float scn[FUSED ? 1 : NR][GL], cmn[GL];
-#pragma unroll
-  for (int i = 0; i < NR; ++i) {
-    const int idx = jb * 512 + i * (NW * 16) + wave * 16 + vkey;
-    vnext[i] = ld16(vbase + (size_t)min(idx, a.max_len - 1) * kvrow);
-    if constexpr (!FUSED) {
-#pragma unroll
-      for (int q = 0; q < GL; ++q) scn[i][q] = srow[q][idx];          // idx < 512 * (jb + 1) <= lcap
-    }
-  }
-  if constexpr (!FUSED) {
-#pragma unroll
-    for (int q = 0; q < GL; ++q) cmn[q] = crow[q][8 * jb + (lane >> 3)];   // chunk < 8 * (jb + 1) <= lcap / 64
-  }
-  float acc[G][8], lsum[GL], m_run[GL];
-#pragma unroll
-  for (int g = 0; g < G; ++g)
-#pragma unroll
-    for (int e = 0; e < 8; ++e) acc[g][e] = 0.f;
-#pragma unroll
-  for (int q = 0; q < GL; ++q) { lsum[q] = 0.f; m_run[q] = -INFINITY; }
+  const bf16_t* kvr = a.kv + (size_t)r * a.max_len * kvrow;
+  const int tb = jb * 512;
+  __shared__ float s_sc[G][512];
+  __shared__ __attribute__((aligned(16))) bf16_t s_p[G][512];
+  __shared__ __attribute__((aligned(16))) float s_accw[NW][G][HD];
+  __shared__ float s_l[NW][G];
+  __shared__ float s_bm[NW][G];
+  AttnV<HD> V;
+  attn_block_load_v<HD>(V, kvr + (size_t)(a.n_heads_kv + kvh) * HD, kvrow, tb + wave * 64, a.max_len - 1, lane);
+  float mnew[GL];
   int L, nb;
-  __shared__ float s_sc[FUSED ? G : 1][FUSED ? ZN_AFUSED_MAX : 1];
-  __shared__ float s_bm[FUSED ? ZN_AFUSED_MAX / 512 : 1][NW][FUSED ? G : 1];
   if constexpr (FUSED) {
-    // ---- pass 1 in LDS: scores of all keys on the matrix cores, S[head][key] = Q K^T as 16x16x32 tiles (A = the G
-    // query heads padded to 16 rows, B = 16 keys; lane = (row/col l&15, k-group l>>4); D: col = key l&15, row = head
-    // 4*(l>>4)+reg), fp32 accumulate, then the reference's fp32 scale; per-wave maxima of each 512-key block.
+    // ---- pass 1 in LDS: S[head][key] = Q K^T as 16x16x32 tiles (attn_scores_kernel's operands and order)
     static_assert(HD % 32 == 0 && G <= 16, "fused attention tile shape");
-    constexpr int KST = HD / 32;                                  // MFMA steps over the head dimension
-    constexpr int TPW = 512 / 16 / NW;                            // 16-key tiles per wave per 512-key block
+    constexpr int KST = HD / 32, TPW = 512 / 16 / NW;
     const int kn = lane & 15, kg = lane >> 4;
     zn_bf16x8 qa[KST];
 #pragma unroll
@@ -1034,88 +1104,85 @@ __global__ __launch_bounds__(512) void attn_pv_kernel(AttnArgs a) {
       if (kn < G) v = ld16(a.q + ((size_t)r * a.n_heads + kvh * G + kn) * HD + 32 * st + 8 * kg);
       qa[st] = __builtin_bit_cast(zn_bf16x8, v);
     }
-    // K rows are fetched whole (16 lanes x 16 B = one 256-byte key row per 16-lane phase; a fragment-shaped request would
-    // touch 16 different rows per phase and bound the pass by the vector-memory pipe) and staged per wave in padded LDS,
-    // where the MFMA B fragments (key = lane & 15, k-group = lane >> 4) are read back conflict-free.
+    // K rows are fetched whole (16 lanes x 16 B = one 256-byte key row per 16-lane phase; a fragment-shaped request would touch 16 different
+    // rows per phase and bound the pass by the vector-memory pipe) and staged per wave in padded LDS, where the MFMA B fragments are read back
+    // conflict-free.
     constexpr int KLD = HD + 8, LPK = HD / 8, KPL = 64 / LPK, NLD = 16 / KPL;   // lanes per key row, keys per wave-load, loads per tile
     __shared__ __attribute__((aligned(16))) bf16_t s_k[NW][16 * KLD];
-    const int kq = lane / LPK, kd = lane % LPK;                      // key within a load's group, 16-B piece of its row
-    const bf16_t* kbase = a.kv + (size_t)r * a.max_len * kvrow + (size_t)kvh * HD + kd * 8;
-    typedef __attribute__((ext_vector_type(4))) float f32x4_t;
-    // two register sets: block j+1's keys are requested as soon as the length is known (j = 0) or block j-1's set is
-    // free, one whole block ahead of their use
-    u32x4 kkA[TPW][NLD], kkB[TPW][NLD];
-    auto issue_k = [&](u32x4 (&kk)[TPW][NLD], int tb, int lim) {
+    const int kq = lane / LPK, kd = lane % LPK;
+    const bf16_t* kbase = kvr + (size_t)kvh * HD + kd * 8;
+    u32x4 kk[TPW][NLD];
 #pragma unroll
-      for (int tl = 0; tl < TPW; ++tl)
+    for (int tl = 0; tl < TPW; ++tl)
 #pragma unroll
-        for (int i = 0; i < NLD; ++i)                                  // clamped, not masked: no exec branch between the loads
-          kk[tl][i] = ld16(kbase + (size_t)min(tb + (tl * NW + wave) * 16 + KPL * i + kq, lim) * kvrow);
-    };
-    issue_k(kkA, 0, a.max_len - 1);                                    // block 0, before the length is known
+      for (int i = 0; i < NLD; ++i) kk[tl][i] = ld16(kbase + (size_t)min((tl * NW + wave) * 16 + KPL * i + kq, a.max_len - 1) * kvrow);
     __builtin_amdgcn_sched_barrier(0);
-    L = Lraw + 1; nb = (L + 511) >> 9;
+    L = Lraw + 1; nb = 1;
     stamp();
-    if (nb > 1) {                                                      // wave-uniform
-      issue_k(kkB, 512, L - 1);
-#pragma unroll
-      for (int i = 0; i < NR; ++i) vnextB[i] = ld16(vbase + (size_t)min(512 + i * (NW * 16) + wave * 16 + vkey, L - 1) * kvrow);
-    }
     bf16_t* kw = &s_k[wave][0];
-    auto block_scores = [&](u32x4 (&kk)[TPW][NLD], int j) {
-      float mx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-      const int tb = j * 512, tend = min(L, tb + 512);
+    float mx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    const int tend = min(L, 512);
 #pragma unroll
-      for (int tl = 0; tl < TPW; ++tl) {
-        const int tt = tb + (tl * NW + wave) * 16;
-        if (tt < tend) {                                          // wave-uniform
+    for (int tl = 0; tl < TPW; ++tl) {
+      const int tt = (tl * NW + wave) * 16;
+      if (tt < tend) {                                          // wave-uniform
 #pragma unroll
-          for (int i = 0; i < NLD; ++i) *(u32x4*)(kw + (KPL * i + kq) * KLD + kd * 8) = kk[tl][i];
-          f32x4_t c = {0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < NLD; ++i) *(u32x4*)(kw + (KPL * i + kq) * KLD + kd * 8) = kk[tl][i];
+        f32x4 c = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-          for (int st = 0; st < KST; ++st) {
-            const u32x4 bfrag = *(const u32x4*)(kw + kn * KLD + 32 * st + 8 * kg);
-            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa[st], __builtin_bit_cast(zn_bf16x8, bfrag), c, 0, 0, 0);
-          }
-          const int t = tt + kn;
+        for (int st = 0; st < KST; ++st) {
+          const u32x4 bfrag = *(const u32x4*)(kw + kn * KLD + 32 * st + 8 * kg);
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa[st], __builtin_bit_cast(zn_bf16x8, bfrag), c, 0, 0, 0);
+        }
+        const int t = tt + kn;
 #pragma unroll
-          for (int reg = 0; reg < 4; ++reg) {
-            const int head = 4 * kg + reg;
-            if (head < G && t < tend) {
-              const float sv = __fmul_rn(c[reg], a.scale);
-              mx[reg] = fmaxf(mx[reg], sv);
-              s_sc[head][t] = sv;
-            }
+        for (int reg = 0; reg < 4; ++reg) {
+          const int head = 4 * kg + reg;
+          if (head < G && t < tend) {
+            const float sv = __fmul_rn(c[reg], a.scale);
+            mx[reg] = fmaxf(mx[reg], sv);
+            s_sc[head][t] = sv;
           }
         }
       }
+    }
 #pragma unroll
-      for (int g = 0; g < G; ++g) {
-        const float m = wave_max(kg == g / 4 ? mx[g % 4] : -INFINITY);
-        if (lane == 0) s_bm[j][wave][g] = m;
-      }
-    };
-    for (int j = 0; j < nb; j += 2) {
-      block_scores(kkA, j);
-      if (j + 2 < nb) issue_k(kkA, (j + 2) * 512, L - 1);
-      if (j + 1 < nb) {
-        block_scores(kkB, j + 1);
-        if (j + 3 < nb) issue_k(kkB, (j + 3) * 512, L - 1);
-      }
+    for (int g = 0; g < G; ++g) {
+      const float m = wave_max(kg == g / 4 ? mx[g % 4] : -INFINITY);
+      if (lane == 0) s_bm[wave][g] = m;
     }
     stamp();
     __syncthreads();
     stamp();
+#pragma unroll
+    for (int q = 0; q < GL; ++q) {
+      const int g = min(vsub + 4 * q, G - 1);
+      float bm = -INFINITY;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) bm = fmaxf(bm, s_bm[w][g]);
+      mnew[q] = bm;
+    }
   } else {
+    // the block's scores (attn_scores_kernel) and the chunk maxima: requested before the length is known
+    const int cstride = a.lcap / ZN_ACHUNK;
+    float scv[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) scv[g] = a.scores[((size_t)r * a.n_heads + kvh * G + g) * a.lcap + tb + tid];     // tb + tid < 512 * (jb + 1) <= lcap
+    const float* crow[GL];
+    float cmn[GL];
+#pragma unroll
+    for (int q = 0; q < GL; ++q) {
+      crow[q] = a.cmax + ((size_t)r * a.n_heads + kvh * G + min(vsub + 4 * q, G - 1)) * cstride;
+      cmn[q] = crow[q][8 * jb + (lane >> 3)];              // chunk < 8 * (jb + 1) <= lcap / 64
+    }
     __builtin_amdgcn_sched_barrier(0);
     L = Lraw + 1; nb = (L + 511) >> 9;
-  }
-  int E = Eraw > 0 ? Eraw : L;
-  if (E < L) E = L;
-  const int nchunks = (L + ZN_ACHUNK - 1) / ZN_ACHUNK;
-  if constexpr (SPLIT) {
     if (jb >= nb) return;                                 // the grid covers the capacity; blocks past the context do nothing
-    // running max before this block = max over every earlier chunk maximum (lanes with equal lane & 3 hold one head)
+#pragma unroll
+    for (int g = 0; g < G; ++g) s_sc[g][tid] = scv[g];
+    const int nchunks = (L + ZN_ACHUNK - 1) / ZN_ACHUNK;
+    // running max before this block = max over every earlier chunk maximum (lanes with equal lane & 3 hold one head); the block's own
+    // maximum = max over its <= 8 chunk maxima (lanes 8c .. 8c+7 hold chunk c)
 #pragma unroll
     for (int q = 0; q < GL; ++q) {
       float pm = -INFINITY;
@@ -1126,155 +1193,52 @@ __global__ __launch_bounds__(512) void attn_pv_kernel(AttnArgs a) {
 #pragma unroll
         for (int u = 0; u < 8; ++u) pm = fmaxf(pm, t8[u]);
       }
-      pm = fmaxf(pm, dpp_mov<ZN_DPP_ROR4>(pm));
-      pm = fmaxf(pm, dpp_mov<ZN_DPP_ROR8>(pm));
-      pm = fmaxf(pm, __shfl_xor(pm, 16));
-      pm = fmaxf(pm, __shfl_xor(pm, 32));
-      m_run[q] = pm;
-    }
-  }
-  for (int j = SPLIT ? jb : 0; j < (SPLIT ? jb + 1 : nb); ++j) {
-    const int t0 = j * 512;
-    const int nkeys = min(512, L - t0);
-    // this block's chunk maxima, 4 value pieces and 4*GL scores per lane were requested one block ahead
-    float cm[GL];
-    u32x4 vv[NR];
-    float sc[NR][GL];
-#pragma unroll
-    for (int q = 0; q < GL; ++q) {
-      if constexpr (FUSED) cm[q] = s_bm[j][lane >> 3][min(vsub + 4 * q, G - 1)];
-      else cm[q] = (8 * j + (lane >> 3) < nchunks) ? cmn[q] : -INFINITY;
-    }
-#pragma unroll
-    for (int i = 0; i < NR; ++i) {
-      const int idx = i * (NW * 16) + wave * 16 + vkey;
-      const bool ok = idx < nkeys;
-      if constexpr (FUSED) vv[i] = ok ? ((j & 1) ? vnextB[i] : vnext[i]) : u32x4{0, 0, 0, 0};
-      else vv[i] = ok ? vnext[i] : u32x4{0, 0, 0, 0};
-#pragma unroll
-      for (int q = 0; q < GL; ++q) {
-        if constexpr (FUSED) sc[i][q] = ok ? s_sc[min(vsub + 4 * q, G - 1)][t0 + idx] : 0.f;
-        else sc[i][q] = ok ? scn[i][q] : 0.f;
-      }
-    }
-    if (FUSED) {                                          // block j+2 into the set block j has just left
-      if (j + 2 < nb) {                                   // (uniform branches: each set is loaded in place)
-        if (j & 1) {
-#pragma unroll
-          for (int i = 0; i < NR; ++i) vnextB[i] = ld16(vbase + (size_t)min(t0 + 1024 + i * (NW * 16) + wave * 16 + vkey, L - 1) * kvrow);
-        } else {
-#pragma unroll
-          for (int i = 0; i < NR; ++i) vnext[i] = ld16(vbase + (size_t)min(t0 + 1024 + i * (NW * 16) + wave * 16 + vkey, L - 1) * kvrow);
-        }
-      }
-    }
-    // running max of the block (max over its <= 8 chunk maxima: lanes 8c..8c+7 hold chunk c), rescale factors
-    float f[GL], mnew[GL];
-#pragma unroll
-    for (int q = 0; q < GL; ++q) {
-      // max over the lanes that hold THIS lane's head (equal lane & 3): rotate inside the row, then across the 4 rows
-      float bm = cm[q];
+      float bm = fmaxf(pm, (8 * jb + (lane >> 3) < nchunks) ? cmn[q] : -INFINITY);
       bm = fmaxf(bm, dpp_mov<ZN_DPP_ROR4>(bm));
       bm = fmaxf(bm, dpp_mov<ZN_DPP_ROR8>(bm));
       bm = fmaxf(bm, __shfl_xor(bm, 16));
       bm = fmaxf(bm, __shfl_xor(bm, 32));
-      mnew[q] = fmaxf(m_run[q], bm);
-      f[q] = (SPLIT || j == 0) ? 0.f : expf(m_run[q] - mnew[q]);
-      m_run[q] = mnew[q];
-      lsum[q] = __fmul_rn(lsum[q], f[q]);
+      mnew[q] = bm;
     }
-#pragma unroll
-    for (int g = 0; g < G; ++g) {
-      // factor of head g lives in lane (quad base + g%4), slot g/4
-      float fg = f[g / 4];
-      fg = (g % 4 == 0) ? dpp_mov<0x00>(fg) : (g % 4 == 1) ? dpp_mov<0x55>(fg) : (g % 4 == 2) ? dpp_mov<0xAA>(fg) : dpp_mov<0xFF>(fg);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) acc[g][e] = __fmul_rn(acc[g][e], fg);
-    }
-    const int nblk = min(512, E - t0), nvec = nblk & ~15;
-#pragma unroll
-    for (int i = 0; i < NR; ++i) {
-      const int base = i * (NW * 16);
-      const int idx = base + wave * 16 + vkey;
-      const bool ok = idx < nkeys;
-      float ev[GL];
-      if (base + NW * 16 <= nvec) {                       // whole round inside the SIMD part: fexp only (uniform branch)
-#pragma unroll
-        for (int q = 0; q < GL; ++q) ev[q] = ok ? zn_fexp_u20(__fsub_rn(sc[i][q], mnew[q])) : 0.f;
-      } else {
-#pragma unroll
-        for (int q = 0; q < GL; ++q) {
-          const float x = __fsub_rn(sc[i][q], mnew[q]);
-          ev[q] = ok ? ((idx < nvec) ? zn_fexp_u20(x) : expf(x)) : 0.f;
-        }
-      }
-#pragma unroll
-      for (int q = 0; q < GL; ++q) if (vsub + 4 * q < G) lsum[q] += ev[q];
-      const float v0 = lo_f(vv[i].x), v1 = hi_f(vv[i].x), v2 = lo_f(vv[i].y), v3 = hi_f(vv[i].y);
-      const float v4 = lo_f(vv[i].z), v5 = hi_f(vv[i].z), v6 = lo_f(vv[i].w), v7 = hi_f(vv[i].w);
-#pragma unroll
-      for (int g = 0; g < G; ++g) {
-        float p = bfround(ev[g / 4]);
-        p = (g % 4 == 0) ? dpp_mov<0x00>(p) : (g % 4 == 1) ? dpp_mov<0x55>(p) : (g % 4 == 2) ? dpp_mov<0xAA>(p) : dpp_mov<0xFF>(p);
-        acc[g][0] = fmaf(p, v0, acc[g][0]); acc[g][1] = fmaf(p, v1, acc[g][1]);
-        acc[g][2] = fmaf(p, v2, acc[g][2]); acc[g][3] = fmaf(p, v3, acc[g][3]);
-        acc[g][4] = fmaf(p, v4, acc[g][4]); acc[g][5] = fmaf(p, v5, acc[g][5]);
-        acc[g][6] = fmaf(p, v6, acc[g][6]); acc[g][7] = fmaf(p, v7, acc[g][7]);
-      }
-    }
+    __syncthreads();                                      // the scores are in LDS
   }
-  stamp();
-  // reduce: 4 key lanes per 16-lane row by DPP, then the rows of the workgroup through LDS in a fixed order
-  __shared__ float s_acc[NW * 4][G][32];
-  __shared__ float s_l[NW][G];
-  const int row = lane >> 4;
-#pragma unroll
-  for (int g = 0; g < G; ++g) {
-#pragma unroll
-    for (int e = 0; e < 8; ++e) acc[g][e] = row_stride4_sum(acc[g][e]);
-    if ((lane & 15) < 4) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) s_acc[wave * 4 + row][g][(lane & 3) * 8 + e] = acc[g][e];
-    }
-  }
-  stamp();
-#pragma unroll
-  for (int q = 0; q < GL; ++q) {
-    // lsum[q] of lane vsub belongs to head vsub + 4q: sum over the 16 lanes with that vsub, per wave
-    float ls = row_stride4_sum(lsum[q]);                                   // per row, lanes with equal vsub
-    ls = (readlane_f(ls, 0) + readlane_f(ls, 16)) + (readlane_f(ls, 32) + readlane_f(ls, 48));   // vsub 0 total
-    float l1 = row_stride4_sum(lsum[q]); l1 = (readlane_f(l1, 1) + readlane_f(l1, 17)) + (readlane_f(l1, 33) + readlane_f(l1, 49));
-    float l2 = row_stride4_sum(lsum[q]); l2 = (readlane_f(l2, 2) + readlane_f(l2, 18)) + (readlane_f(l2, 34) + readlane_f(l2, 50));
-    float l3 = row_stride4_sum(lsum[q]); l3 = (readlane_f(l3, 3) + readlane_f(l3, 19)) + (readlane_f(l3, 35) + readlane_f(l3, 51));
-    if (lane == 0) {
-      if (4 * q + 0 < G) s_l[wave][4 * q + 0] = ls;
-      if (4 * q + 1 < G) s_l[wave][4 * q + 1] = l1;
-      if (4 * q + 2 < G) s_l[wave][4 * q + 2] = l2;
-      if (4 * q + 3 < G) s_l[wave][4 * q + 3] = l3;
-    }
-  }
-  stamp();
+  attn_block_mask_v<HD>(V, tb + wave * 64, L, lane);
+  int E = Eraw > 0 ? Eraw : L;
+  if (E < L) E = L;
+  const int nkeys = min(512, L - tb), nvec = min(512, E - tb) & ~15;
+  attn_block_probs<G>(s_sc, mnew, nkeys, nvec, s_p, s_l, wave, lane);
   __syncthreads();
   stamp();
-  float v = 0.f, l = 0.f;
-  const int g = tid >> 5, d = tid & 31;
-  if (tid < G * 32) {
+  attn_block_pv<HD, G>(s_p, V, s_accw, wave, lane);
+  __syncthreads();
+  stamp();
+  if constexpr (FUSED) {
+    for (int o = tid; o < G * HD; o += 512) {
+      const int g = o / HD, d = o % HD;
+      float v = 0.f, l = 0.f;
 #pragma unroll
-    for (int w = 0; w < NW * 4; ++w) v += s_acc[w][g][d];
+      for (int w = 0; w < NW; ++w) v += s_accw[w][g][d];
 #pragma unroll
-    for (int w = 0; w < NW; ++w) l += s_l[w][g];
-  }
-  if constexpr (!SPLIT) {
-    stamp();
-    if (tid < G * 32) a.out[((size_t)r * a.n_heads + kvh * G + g) * HD + slice * 32 + d] = f2bf(__fmul_rn(v, 1.0f / l));
+      for (int w = 0; w < NW; ++w) l += s_l[w][g];
+      a.out[((size_t)r * a.n_heads + kvh * G + g) * HD + d] = f2bf(__fmul_rn(v, 1.0f / l));
+    }
     stamp();
   } else {
-    constexpr int PSZ = G * 32 + G;
-    const int group = (r * a.n_heads_kv + kvh) * (HD / 32) + slice;
+    constexpr int PSZ = G * HD + G;
+    const int group = r * a.n_heads_kv + kvh;
     float* pp = a.part + ((size_t)group * a.nbcap + jb) * PSZ;
-    if (tid < G * 32) {
-      st_wt(pp + g * 32 + d, v);
-      if (d == 0) st_wt(pp + G * 32 + g, l);
+    for (int o = tid; o < G * HD; o += 512) {
+      const int g = o / HD, d = o % HD;
+      float v = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) v += s_accw[w][g][d];
+      st_wt(pp + o, v);
+      if (d == 0) {
+        float l = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) l += s_l[w][g];
+        st_wt(pp + G * HD + g, l);
+      }
     }
     __builtin_amdgcn_s_waitcnt(0);                        // stores acknowledged before the ticket
     __syncthreads();
@@ -1288,8 +1252,10 @@ __global__ __launch_bounds__(512) void attn_pv_kernel(AttnArgs a) {
     if (!s_last) return;
     // the reference's recurrence over the blocks, in order: acc = acc * f_j + pv_j, lsum = lsum * f_j + sum_j,
     // f_j = exp(m_{j-1} - m_j) with m_j the running maximum through block j (from the chunk maxima of pass 1)
+    const int cstride = a.lcap / ZN_ACHUNK, nchunks = (L + ZN_ACHUNK - 1) / ZN_ACHUNK;
     __shared__ float s_bmax[G][32];                       // block maxima per head (nbcap <= 32: 16384 keys)
-    if (tid < G * 32 && d < nb) {
+    if (tid < G * 32 && (tid & 31) < nb) {
+      const int g = tid >> 5, d = tid & 31;
       const float* crq = a.cmax + ((size_t)r * a.n_heads + kvh * G + g) * cstride;
       float t8[8];
 #pragma unroll
@@ -1300,31 +1266,33 @@ __global__ __launch_bounds__(512) void attn_pv_kernel(AttnArgs a) {
       s_bmax[g][d] = bm;
     }
     __syncthreads();
-    if (tid >= G * 32) return;
     const float* pb = a.part + (size_t)group * a.nbcap * PSZ;
-    float tot = 0.f, lt = 0.f, mprev = -INFINITY;
-    for (int j0 = 0; j0 < nb; j0 += 8) {
-      // eight blocks' partials requested at once (one memory round trip per eight blocks, not per block)
-      float pv[8], pl[8];
+    for (int o = tid; o < G * HD; o += 512) {
+      const int g = o / HD;
+      float tot = 0.f, lt = 0.f, mprev = -INFINITY;
+      for (int j0 = 0; j0 < nb; j0 += 8) {
+        // eight blocks' partials requested at once (one memory round trip per eight blocks, not per block)
+        float pv[8], pl[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int j = min(j0 + u, nb - 1);
-        pv[u] = ld_wt(pb + (size_t)j * PSZ + g * 32 + d);
-        pl[u] = ld_wt(pb + (size_t)j * PSZ + G * 32 + g);
-      }
+        for (int u = 0; u < 8; ++u) {
+          const int j = min(j0 + u, nb - 1);
+          pv[u] = ld_wt(pb + (size_t)j * PSZ + o);
+          pl[u] = ld_wt(pb + (size_t)j * PSZ + G * HD + g);
+        }
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int j = j0 + u;
-        if (j < nb) {
-          const float mj = fmaxf(mprev, s_bmax[g][j]);
-          const float fj = (j == 0) ? 0.f : expf(mprev - mj);
-          mprev = mj;
-          tot = __fadd_rn(__fmul_rn(tot, fj), pv[u]);
-          lt = __fadd_rn(__fmul_rn(lt, fj), pl[u]);
+        for (int u = 0; u < 8; ++u) {
+          const int j = j0 + u;
+          if (j < nb) {
+            const float mj = fmaxf(mprev, s_bmax[g][j]);
+            const float fj = (j == 0) ? 0.f : expf(mprev - mj);
+            mprev = mj;
+            tot = __fadd_rn(__fmul_rn(tot, fj), pv[u]);
+            lt = __fadd_rn(__fmul_rn(lt, fj), pl[u]);
+          }
         }
       }
+      a.out[((size_t)r * a.n_heads + kvh * G + g) * HD + (o % HD)] = f2bf(__fmul_rn(tot, 1.0f / lt));
     }
-    a.out[((size_t)r * a.n_heads + kvh * G + g) * HD + slice * 32 + d] = f2bf(__fmul_rn(tot, 1.0f / lt));
   }
 }
 

@@ -1,18 +1,16 @@
-// Whole decode step of the transformer stack at batch 1 (R = 2 rows) in ONE persistent launch, second design (round 3).
+// Whole decode step of the transformer stack at batch 1 (R = 2 rows) in ONE persistent launch (round 3; attention role rebuilt in round 4).
 //
 // 256 workgroups of 8 waves, one per CU, in two fixed roles:
 //
-//  * 32 ATTENTION workgroups (one per (row, kv head, 32-wide value slice), as attn_pv_kernel<128, 4, 1>'s fused grid) carry NO weight
-//    tiles.  All eight waves run the fused launch's arithmetic (MFMA scores into LDS, block maxima, e / P / P.V per key in the same
-//    per-lane order, the same DPP + LDS reduction tree: results bit-identical to that launch).  Their whole register budget holds
-//    K (both 512-key blocks: 128 VGPRs) and V (32 VGPRs) of the NEXT block's cache, requested as soon as the block's result is
-//    published — a whole block (~20 us) before q arrives, so the attention of a block is two
-//    hand-offs plus ~3.5 us of arithmetic, and nothing in it waits for memory.  (_torch.py:376-420)
-//  * 224 STREAMING workgroups split every weight matrix of the block (out_proj, fc1, fc2, next in_proj / heads) with chain_kernel's
-//    static tile schedule: 4 compute waves, 2 communication waves (one per activation row), 2 idle waves (the launch's shape is
-//    the attention's).  While the attention runs they have nothing to wait for but weights: each compute wave streams the first
+//  * 8 * NBK ATTENTION workgroups, one per (row, kv head, 512-key block) of the launch's context bound (NBK = 1 .. 12: contexts up to 6144
+//    keys), carry NO weight tiles.  Their register budget holds K and full-width V of the NEXT block's cache, requested as soon as the
+//    block's result is published - a whole block (~20 us) before q arrives -, so the attention of a block is hand-offs plus ~3 us of
+//    arithmetic on the matrix cores (scores and P.V), and nothing in it waits for memory.  (step_attention_kb_role; _torch.py:376-420)
+//  * the other 248 - 160 STREAMING workgroups split every weight matrix of the block (out_proj, fc1, fc2, next in_proj / heads) with
+//    chain_kernel's static tile schedule: 4 compute waves, 2 communication waves (one per activation row), 2 idle waves (the launch's shape
+//    is the attention's).  While the attention runs they have nothing to wait for but weights: each compute wave streams the first
 //    ZN_SK_PARK tiles of the block through its register buffers into LDS ("parked" tiles, 128 KB per CU) and leaves ZN_SK_NBUF more
-//    in flight in registers — 7 of its ~17 tiles (~50 MB chip-wide, ~40 % of the block's weights) are on chip before op 0's input
+//    in flight in registers - 7 of its ~17 tiles (~50 MB chip-wide, ~40 % of the block's weights) are on chip before op 0's input
 //    exists.  (_torch.py:307-328)
 //
 // Hand-offs are chain_kernel's tagged granules (tag = epoch + block).  Reuse of a granule buffer block after block is safe
@@ -20,10 +18,12 @@
 // stage s of block b + 1 only after EVERY streaming workgroup has published stage s' > s of block b, i.e. after each of them has
 // finished sweeping stage s of block b; the attention workgroups' stages (q|k|v in, attention output out) sit inside that
 // chain: an attention workgroup publishes g_a(b + 1) only after its own sweep of g_qkv(b), and no workgroup writes g_qkv(b + 1)
-// before it has swept all of g_a(b + 1).  A consumer therefore never sees a tag newer than the one it waits for, and the sweeps
-// compare for equality.  Every wait is bounded and describes itself when it gives up (sweep_granules, SweepWho).
+// before it has swept all of g_a(b + 1); the attention workgroups' own exchanges (block maxima, partials) sit between their sweep of
+// g_qkv(b) and the publication of g_a(b + 1): a pair's maxima and partials of block b have all been swept before its combiner publishes,
+// i.e. before q of the next block exists.  A consumer therefore never sees a tag newer than the one it waits for, and the sweeps
+// compare for equality.  Every wait is bounded and describes itself when it gives up (sweep_granules, SpinBound, SweepWho).
 //
-// Results (codes, logits) are bit-identical to the per-block path with the fused attention launch.
+// Results (codes, logits) are bit-identical to the per-block path and to the launches path at every context length.
 #pragma once
 #include "zn_chain_kernel.h"
 #include "zn_step_sched.h"
@@ -53,25 +53,13 @@
 #ifndef ZN_SK_SWEEP_DELAY
 #define ZN_SK_SWEEP_DELAY 40                                // s_sleep units (64 cycles) between an op's publish and the first sweep pass for its output
 #endif                                                      // (two sweep passes in flight per wave, a new one every half round trip: 0.891 vs 0.869 ms per step - more polling loads the fabric)
-#define ZN_SK_MAXKEYS 1024                                  // two 512-key blocks: longer contexts go down the per-block path
-#define ZN_SK_DYN_LDS (ZN_SK_CW * ZN_SK_PARK * 8192)        // parked tiles (streaming role) / StepAttnLds (attention role)
+#define ZN_SK_DYN_LDS (ZN_SK_CW * ZN_SK_PARK * 8192)        // parked tiles (streaming role) / StepKbLds (attention role)
 #ifndef ZN_SK_PACE_MARGIN
 #define ZN_SK_PACE_MARGIN 0                                 // > 0: sleep until this many 10 ns ticks before the previous wait's length instead of a fraction of it
 #endif
 #ifndef ZN_SK_PACE_SHIFT
 #define ZN_SK_PACE_SHIFT 2                                  // a waiting wave sleeps through the first (1 - 2^-SHIFT) of the wait it measured one block earlier
 #endif
-
-struct StepAttnLds {
-  float sc[4][ZN_SK_MAXKEYS];                               // scores [head][key]
-  float bm[ZN_SK_MAXKEYS / 512][8][4];                      // per (block, wave, head) maxima
-  float acc[32][4][32];                                     // per (wave, 16-lane row) partial P.V
-  float l[8][4];
-  __attribute__((aligned(16))) bf16_t q[4][128];            // the kv head's 4 query heads
-  __attribute__((aligned(16))) bf16_t knew[128], vnew[128]; // newest key / value row of the kv head
-  __attribute__((aligned(16))) bf16_t out[4][32];           // result slice
-};
-static_assert(sizeof(StepAttnLds) <= ZN_SK_DYN_LDS, "the attention role's LDS fits the launch's dynamic LDS");
 
 // A wave that waits for a hand-off far in the future (the attention workgroups for q|k|v, the streaming ones for the attention
 // output) sleeps through most of the wait it measured one block earlier instead of polling through it (polls sit in the CU's
@@ -101,275 +89,27 @@ ZN_DEVINL void step_debug_pause(unsigned ticks) {
   while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(127);
 }
 
-// ------------------------------------------------------------------------------------------------ attention role
-ZN_DEVINL void step_attention_role(const ChainArgs& a, StepAttnLds& S, const unsigned tag0, const int c, const int wave, const int lane) {
-  constexpr int HD = 128, G = 4, NW = 8, NR = 4, KST = HD / 32, TPW = 4, R = 2;
-  constexpr int NLD = KST;                                    // K registers per 16-key tile: one B fragment per MFMA step
-  typedef __attribute__((ext_vector_type(4))) float f32x4_t;
-  const int npairs = a.n_heads_kv * R;
-  const int pair = c % npairs, slice = c / npairs, kvh = pair % a.n_heads_kv, ar = pair / a.n_heads_kv;
-  const int nq = a.n_heads * HD, nk = a.n_heads_kv * HD, D = nq;
-  const int L = a.lengths[ar] + 1, nb = (L + 511) >> 9;     // keys including this step's; 1 or 2 blocks (host-checked)
-  const int hi = L >= 2 ? L - 2 : 0;                         // rows 0 .. L-2 are in the cache from earlier launches; row L-1 comes from LDS
-  const size_t kvrow = (size_t)2 * nk;
-  const int kn = lane & 15, kg = lane >> 4;
-  const int vsub = lane & 3, vkey = lane >> 2, row = lane >> 4;
-  const bool stamped = a.stamps && c == 0 && wave == 0 && lane == 0;
-  u32x4 kkA[TPW][NLD], kkB[TPW][NLD], vA[NR], vB[NR];
-  // Buffer loads with a 32-bit byte offset per request, recomputed at every issue from a value the optimiser cannot see through
-  // (`opq` = 0): hoisted out of the block loop, the 40 loop-invariant addresses stayed live beside the 160 K / V registers and spilled.
-  const int rowbytes = (int)kvrow * 2;
-  // K is requested straight in the MFMA B-fragment layout (lane = (key kn, k-group kg): 16 B of dims 32 st + 8 kg .. + 8 of key row
-  // tt + kn): 16 rows x 64 B per wave-load, a shape that runs at ~30 GB/s per CU — which is what kept the fused LAUNCH on whole rows
-  // + an LDS transpose, its K requests being on the critical path.  Here they are a block (~25 us) ahead of their use, so the
-  // scores need no LDS staging at all: same operands in the same MFMA slots, bit-identical scores.
-  auto issue_k = [&](const bf16_t* kv, u32x4 (&kk)[TPW][NLD], int tb, int opq) {
-    const __amdgpu_buffer_rsrc_t rs = zn_rsrc(kv);
-    const int base = ar * a.max_len * rowbytes + (kvh * HD + 8 * kg) * 2, r0 = opq + wave * 16 + kn;
-#pragma unroll
-    for (int tl = 0; tl < TPW; ++tl)
-#pragma unroll
-      for (int st = 0; st < KST; ++st) kk[tl][st] = __builtin_amdgcn_raw_buffer_load_b128(rs, base + min(r0 + tb + tl * NW * 16, hi) * rowbytes + 64 * st, 0, 0);
-  };
-  auto issue_v = [&](const bf16_t* kv, u32x4 (&vv)[NR], int tb, int opq) {
-    const __amdgpu_buffer_rsrc_t rs = zn_rsrc(kv);
-    const int base = ar * a.max_len * rowbytes + ((a.n_heads_kv + kvh) * HD + slice * 32 + vsub * 8) * 2, r0 = opq + wave * 16 + vkey;
-#pragma unroll
-    for (int i = 0; i < NR; ++i) vv[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, base + min(r0 + tb + i * (NW * 16), hi) * rowbytes, 0, 0);
-  };
-  {
-    const bf16_t* kv0 = a.layers[0].kv;
-    issue_k(kv0, kkA, 0, 0);
-    if (nb > 1) issue_k(kv0, kkB, 512, 0);
-    issue_v(kv0, vA, 0, 0);
-    if (nb > 1) issue_v(kv0, vB, 512, 0);
-  }
-  StepPacer pace{0ull, 0u};
-#pragma unroll 1
-  for (int li = 0; li < a.n_layer; ++li) {
-    const unsigned tag = tag0 + (unsigned)li;
-    if (a.dbg_pause && li == 3) step_debug_pause(a.dbg_pause);     // (inside the measured wait for block 3's q | k | v)
-    const bool st_on = stamped && li == a.stamp_layer;
-    auto stamp = [&](int i) { if (st_on) a.stamps[32 + i] = __builtin_amdgcn_s_memrealtime(); };
-    stamp(0);
-    // ---- q (4 heads), newest key and value row of this kv head -> LDS
-    if (wave == ZN_SK_CW || wave == ZN_SK_CW + 1) {
-      const bool first = wave == ZN_SK_CW;
-      if (li == 0) {                                         // from the in_proj launch before this one: plain loads
-        if (first) *(u32x4*)&S.q[lane >> 4][(lane & 15) * 8] = ld16(a.q0 + ((size_t)ar * a.n_heads + kvh * G + (lane >> 4)) * HD + (lane & 15) * 8);
-        else if (lane < 32) {
-          const bf16_t* rowp = a.layers[0].kv + ((size_t)ar * a.max_len + (L - 1)) * kvrow + (size_t)(lane < 16 ? 0 : nk) + (size_t)kvh * HD + (lane & 15) * 8;
-          const u32x4 v = ld16(rowp);
-          if (lane < 16) *(u32x4*)&S.knew[lane * 8] = v; else *(u32x4*)&S.vnew[(lane - 16) * 8] = v;
-        }
-      } else {                                               // granules of the block before (tag - 1)
-        const int qoff = (ar * (a.nqkv / 2) + ((kvh * G) * HD) / 2 + lane * 4) * 8;
-        const int kvsel = lane < 16 ? nq + kvh * HD : nq + nk + kvh * HD;
-        const int koff = (ar * (a.nqkv / 2) + kvsel / 2 + (lane & 15) * 4) * 8;
-        int off1[1] = {first ? qoff : koff};
-        u32x4 d1[1];
-        pace.sleep();
-        sweep_granules<1>(zn_rsrc(a.g_qkv), off1, tag - 1u, d1, a.tmo, lane, SweepWho{(5u << 8) | (unsigned)li, a.diag});   // (one pass at a time: 253 VGPRs here)
-        pace.done();
-        if (first) *(u32x4*)&S.q[lane >> 4][(lane & 15) * 8] = d1[0];
-        else if (lane < 16) *(u32x4*)&S.knew[lane * 8] = d1[0];
-        else if (lane < 32) *(u32x4*)&S.vnew[(lane - 16) * 8] = d1[0];
-      }
-    }
-    __syncthreads();                                         // A1: q, newest key and value rows are in LDS
-    stamp(1);
-    // ---- scores of all keys on the matrix cores (attn_pv_kernel<128, 4, 1>, FUSED): S[head][key] as 16x16x32 tiles
-    {
-      zn_bf16x8 qa[KST];
-#pragma unroll
-      for (int st = 0; st < KST; ++st) {
-        u32x4 v = u32x4{0, 0, 0, 0};
-        if (kn < G) v = *(const u32x4*)&S.q[kn][32 * st + 8 * kg];
-        qa[st] = __builtin_bit_cast(zn_bf16x8, v);
-      }
-      u32x4 knew_frag[KST];                                  // the newest key row is not in the cache for this launch's readers: from LDS
-#pragma unroll
-      for (int st = 0; st < KST; ++st) knew_frag[st] = *(const u32x4*)&S.knew[32 * st + 8 * kg];
-      auto block_scores = [&](u32x4 (&kk)[TPW][NLD], int j) {
-        float mx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-        const int tb = j * 512, tend = min(L, tb + 512);
-#pragma unroll
-        for (int tl = 0; tl < TPW; ++tl) {
-          const int tt = tb + (tl * NW + wave) * 16;
-          if (tt < tend) {                                    // wave-uniform
-            const bool newest = tt + kn >= L - 1;
-            f32x4_t cc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int st = 0; st < KST; ++st) {
-              const u32x4 bfrag = newest ? knew_frag[st] : kk[tl][st];
-              cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa[st], __builtin_bit_cast(zn_bf16x8, bfrag), cc, 0, 0, 0);
-            }
-            const int t = tt + kn;
-#pragma unroll
-            for (int reg = 0; reg < 4; ++reg) {
-              const int head = 4 * kg + reg;
-              if (head < G && t < tend) {
-                const float sv = __fmul_rn(cc[reg], a.scale);
-                mx[reg] = fmaxf(mx[reg], sv);
-                S.sc[head][t] = sv;
-              }
-            }
-          }
-        }
-#pragma unroll
-        for (int g = 0; g < G; ++g) {
-          const float m = wave_max(kg == g / 4 ? mx[g % 4] : -INFINITY);
-          if (lane == 0) S.bm[j][wave][g] = m;
-        }
-      };
-      block_scores(kkA, 0);
-      if (nb > 1) block_scores(kkB, 1);
-    }
-    __syncthreads();                                         // A2: every score and block maximum is in LDS
-    stamp(2);
-    // ---- pass 2: the reference's recurrence over the 512-key blocks
-    {
-      const u32x4 vnew_piece = *(const u32x4*)&S.vnew[slice * 32 + vsub * 8];
-      float acc[G][8], lsum = 0.f, m_run = -INFINITY;
-#pragma unroll
-      for (int g = 0; g < G; ++g)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) acc[g][e] = 0.f;
-#pragma unroll
-      for (int j = 0; j < ZN_SK_MAXKEYS / 512; ++j) {
-        if (j < nb) {                                          // wave-uniform
-          const int t0 = j * 512, nkeys = min(512, L - t0);
-          u32x4 vv[NR];
-          float sc[NR];
-#pragma unroll
-          for (int i = 0; i < NR; ++i) {
-            const int idx = i * (NW * 16) + wave * 16 + vkey;
-            const bool ok = idx < nkeys;
-            u32x4 v = j ? vB[i] : vA[i];
-            if (t0 + idx >= L - 1) v = vnew_piece;
-            vv[i] = ok ? v : u32x4{0, 0, 0, 0};
-            sc[i] = ok ? S.sc[vsub][t0 + idx] : 0.f;
-          }
-          float bm = S.bm[j][lane >> 3][vsub];
-          bm = fmaxf(bm, dpp_mov<ZN_DPP_ROR4>(bm));
-          bm = fmaxf(bm, dpp_mov<ZN_DPP_ROR8>(bm));
-          bm = fmaxf(bm, __shfl_xor(bm, 16));
-          bm = fmaxf(bm, __shfl_xor(bm, 32));
-          const float mnew = fmaxf(m_run, bm);
-          const float f = (j == 0) ? 0.f : expf(m_run - mnew);
-          m_run = mnew;
-          lsum = __fmul_rn(lsum, f);
-#pragma unroll
-          for (int g = 0; g < G; ++g) {
-            float fg = f;
-            fg = (g % 4 == 0) ? dpp_mov<0x00>(fg) : (g % 4 == 1) ? dpp_mov<0x55>(fg) : (g % 4 == 2) ? dpp_mov<0xAA>(fg) : dpp_mov<0xFF>(fg);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) acc[g][e] = __fmul_rn(acc[g][e], fg);
-          }
-          const int nblk = min(512, L - t0), nvec = nblk & ~15;  // decode steps: the reference's block loop spans exactly the context
-#pragma unroll
-          for (int i = 0; i < NR; ++i) {
-            const int base = i * (NW * 16);
-            const int idx = base + wave * 16 + vkey;
-            const bool ok = idx < nkeys;
-            float ev;
-            if (base + NW * 16 <= nvec) ev = ok ? zn_fexp_u20(__fsub_rn(sc[i], mnew)) : 0.f;
-            else {
-              const float x = __fsub_rn(sc[i], mnew);
-              ev = ok ? ((idx < nvec) ? zn_fexp_u20(x) : expf(x)) : 0.f;
-            }
-            lsum += ev;
-            const float v0 = lo_f(vv[i].x), v1 = hi_f(vv[i].x), v2f = lo_f(vv[i].y), v3 = hi_f(vv[i].y);
-            const float v4 = lo_f(vv[i].z), v5 = hi_f(vv[i].z), v6 = lo_f(vv[i].w), v7 = hi_f(vv[i].w);
-#pragma unroll
-            for (int g = 0; g < G; ++g) {
-              float pr = bfround(ev);
-              pr = (g % 4 == 0) ? dpp_mov<0x00>(pr) : (g % 4 == 1) ? dpp_mov<0x55>(pr) : (g % 4 == 2) ? dpp_mov<0xAA>(pr) : dpp_mov<0xFF>(pr);
-              acc[g][0] = fmaf(pr, v0, acc[g][0]); acc[g][1] = fmaf(pr, v1, acc[g][1]);
-              acc[g][2] = fmaf(pr, v2f, acc[g][2]); acc[g][3] = fmaf(pr, v3, acc[g][3]);
-              acc[g][4] = fmaf(pr, v4, acc[g][4]); acc[g][5] = fmaf(pr, v5, acc[g][5]);
-              acc[g][6] = fmaf(pr, v6, acc[g][6]); acc[g][7] = fmaf(pr, v7, acc[g][7]);
-            }
-          }
-        }
-      }
-      stamp(3);
-      // reduce: 4 key lanes per 16-lane row by DPP, the rows of the workgroup through LDS in the fused kernel's order
-#pragma unroll
-      for (int g = 0; g < G; ++g) {
-        float red[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) red[e] = row_stride4_sum(acc[g][e]);
-        if ((lane & 15) < 4) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) S.acc[wave * 4 + row][g][(lane & 3) * 8 + e] = red[e];
-        }
-      }
-      float ls = row_stride4_sum(lsum);
-      ls = (readlane_f(ls, 0) + readlane_f(ls, 16)) + (readlane_f(ls, 32) + readlane_f(ls, 48));
-      float l1 = row_stride4_sum(lsum); l1 = (readlane_f(l1, 1) + readlane_f(l1, 17)) + (readlane_f(l1, 33) + readlane_f(l1, 49));
-      float l2 = row_stride4_sum(lsum); l2 = (readlane_f(l2, 2) + readlane_f(l2, 18)) + (readlane_f(l2, 34) + readlane_f(l2, 50));
-      float l3 = row_stride4_sum(lsum); l3 = (readlane_f(l3, 3) + readlane_f(l3, 19)) + (readlane_f(l3, 35) + readlane_f(l3, 51));
-      if (lane == 0) { S.l[wave][0] = ls; S.l[wave][1] = l1; S.l[wave][2] = l2; S.l[wave][3] = l3; }
-    }
-    __syncthreads();                                         // A3: partial sums of all 8 waves
-    stamp(4);
-    {
-      const int tid = wave * 64 + lane;
-      if (tid < G * 32) {
-        const int g = tid >> 5, d = tid & 31;
-        float v = 0.f, l = 0.f;
-#pragma unroll
-        for (int w = 0; w < NW * 4; ++w) v += S.acc[w][g][d];
-#pragma unroll
-        for (int w = 0; w < NW; ++w) l += S.l[w][g];
-        S.out[g][d] = f2bf(__fmul_rn(v, 1.0f / l));
-      }
-    }
-    __syncthreads();                                         // A4: the result slice is in LDS
-    if (wave == ZN_SK_CW) {
-      const int gq = lane >> 4, dp = lane & 15;
-      const unsigned v = *(const unsigned*)&S.out[gq][2 * dp];
-      st_granule(a.g_a + (size_t)ar * (D / 2) + ((kvh * G + gq) * HD + slice * 32) / 2 + dp, tag, v);
-      if (a.trace) {
-        *(unsigned*)(a.trace + ((size_t)(8 * li + 1) * R + ar) * D + (kvh * G + gq) * HD + slice * 32 + 2 * dp) = v;
-        if (slice == 0) *(u32x4*)(a.trace + ((size_t)(8 * li + 2) * R + ar) * D + (kvh * G + (lane >> 4)) * HD + (lane & 15) * 8) = *(const u32x4*)&S.q[lane >> 4][(lane & 15) * 8];
-      }
-    }
-    stamp(5);
-    // the key and value registers are free: the next block's rows are requested now, a whole block (~20 us) ahead of their use
-    if (li + 1 < a.n_layer) {
-      const bf16_t* kvn = a.layers[li + 1].kv;
-      int opq = 0;
-      asm volatile("" : "+v"(opq));
-      issue_k(kvn, kkA, 0, opq);
-      if (nb > 1) issue_k(kvn, kkB, 512, opq);
-      issue_v(kvn, vA, 0, opq);
-      if (nb > 1) issue_v(kvn, vB, 512, opq);
-    }
-    pace.start();                                            // the wait for the next block's q | k | v starts here
-  }
-}
-
-// ------------------------------------------------------------------------------------------------ attention role, one workgroup per KEY BLOCK
-// Contexts beyond one 512-key block (the legacy role above holds two blocks and makes its four value-slice workgroups repeat every score).
-// Here the first natt = 8 * NBK workgroups of the grid are one per (row, kv head, 512-key block): a workgroup holds K of its block in the
-// MFMA B-fragment layout (64 VGPRs) and V at full width (64 VGPRs), both requested a block ahead, computes its 512 x 4 scores once,
-// exchanges the block maxima with the other blocks of its (row, kv head) pair (the running max m_j of the reference's recurrence is the
-// max over blocks 0 .. j), runs pass 2 on its keys for the four 32-wide value slices in turn (attn_pv_kernel<128, 4, 2>'s per-lane order and
-// reduction tree per slice: the same partials bit for bit) and publishes the unnormalised P.V and e sums as granules; the workgroup of
-// block 0 sweeps the partials of all blocks, replays acc = acc * f_j + pv_j in block order (that kernel's combine), normalises and
-// publishes the attention output.  One block (contexts up to 512 keys): no exchange, no partials - the workgroup normalises and
-// publishes itself, 8 attention workgroups instead of 32, i.e. 248 streaming workgroups.  Workgroups of blocks past the context
-// (the grid is sized for the launch's upper bound) leave at once.  (_torch.py:413-417)
+// ------------------------------------------------------------------------------------------------ attention role: one workgroup per KEY BLOCK
+// The first natt = 8 * NBK workgroups of the grid are one per (row, kv head, 512-key block) and carry NO weight tiles.  A workgroup holds K of
+// its block in the MFMA B-fragment layout (64 VGPRs) and V at full width in AttnV's layout (64 VGPRs), both requested the moment the previous
+// block's result is published - a whole block (~20 us) before q arrives, so nothing in the attention waits for memory.  Per block: q (and, in
+// the newest block's workgroup, this step's key and value row) from the hand-off granules; the block's 512 x 4 scores on the matrix cores into
+// LDS; block maxima exchanged with the other blocks of the (row, kv head) pair as granules (the running max m_j of the reference's recurrence is
+// the max over blocks 0 .. j); pass 2 = attn_block_probs / attn_block_pv (zn_decode_kernels.h: the launches' arithmetic, bit for bit); the
+// unnormalised P.V and e sums leave as granules; the workgroup of block 0 sweeps the partials of all blocks, replays acc = acc * f_j + pv_j in
+// block order (attn_block_kernel's combine), normalises and publishes the attention output.  One block (contexts up to 512 keys): no exchange,
+// no partials - the workgroup normalises and publishes itself, and 248 workgroups stream.  Workgroups of blocks past the context (the grid is
+// sized for the launch's upper bound) leave at once.  (Rounds 2-3: one workgroup per 32-wide value slice over one or two blocks, P.V on the
+// VALU, limited to 1024 keys; the same time at one block, 2.7 us per block slower at two.)  (_torch.py:413-417)
 #define ZN_SK_KB_MAXNB 12                                   // key blocks covered: 6144 keys
 #define ZN_SK_KB_PSZ 520                                    // granules per (pair, block): P.V [4][128], e sums [4] (as two 16-byte pairs), padding to 64 B
 struct StepKbLds {
   float sc[4][512];                                         // scores [head][key of the block]
   float bm[8][4];                                           // per (wave, head) maxima of the block
   float bmall[ZN_SK_KB_MAXNB][4];                           // maxima of every block of the pair
-  float acc[32][4][128];                                    // per (wave, 16-lane row) partial P.V, the four value slices side by side
+  float accw[8][4][128];                                    // per-wave partial P.V [head][dim]
   float l[8][4];
+  __attribute__((aligned(16))) bf16_t p[4][512];            // P = bf16(e) [head][key of the block]
   __attribute__((aligned(16))) bf16_t q[4][128];            // the kv head's 4 query heads
   __attribute__((aligned(16))) bf16_t knew[128], vnew[128]; // newest key / value row of the kv head
   __attribute__((aligned(16))) bf16_t out[4][128];          // normalised result (one-block contexts)
@@ -379,7 +119,7 @@ static_assert(sizeof(StepKbLds) <= ZN_SK_DYN_LDS, "the key-block attention role'
 template <int NBV>          // blocks this instantiation's launches can be asked to cover (<= ZN_SK_KB_MAXNB): the unroll bound of the combine
 ZN_DEVINL void step_attention_kb_role(const ChainArgs& a, StepKbLds& S, const unsigned tag0, const int c, const int wave, const int lane_in) {
   static_assert(NBV >= 1 && NBV <= ZN_SK_KB_MAXNB, "blocks covered");
-  constexpr int HD = 128, G = 4, NW = 8, NR = 4, KST = HD / 32, TPW = 4, R = 2, NSL = HD / 32, MAXNB = ZN_SK_KB_MAXNB, PSZ = ZN_SK_KB_PSZ;
+  constexpr int HD = 128, G = 4, NW = 8, KST = HD / 32, TPW = 4, R = 2, MAXNB = ZN_SK_KB_MAXNB, PSZ = ZN_SK_KB_PSZ;
   typedef __attribute__((ext_vector_type(4))) float f32x4_t;
   const int npairs = a.n_heads_kv * R;
   const int pair = c % npairs, jb = c / npairs, kvh = pair % a.n_heads_kv, ar = pair / a.n_heads_kv;
@@ -391,24 +131,30 @@ ZN_DEVINL void step_attention_kb_role(const ChainArgs& a, StepKbLds& S, const un
   const int hi = L >= 2 ? L - 2 : 0;                         // rows 0 .. L-2 are in the cache from earlier launches
   const size_t kvrow = (size_t)2 * nk;
   const bool stamped = a.stamps && c == 0 && wave == 0 && lane_in == 0;
-  u32x4 kk[TPW][KST], vv[NSL][NR];
+  u32x4 kk[TPW][KST];
+  AttnV<HD> V;                                               // [32-key step of the wave's 64 keys][key 8 kg + j of the step] x dims 8 kn .. + 8
   const int rowbytes = (int)kvrow * 2;
   // (offsets formed at every issue from a value the optimiser cannot see through, as in the legacy role: hoisted they spill)
   // Everything derived from the lane index is formed anew in every block from a copy of it the optimiser cannot see through: hoisted out
   // of the block loop, the per-lane LDS addresses and granule offsets (~80 VGPRs) stayed live beside the 128 K / V registers and spilled.
   auto issue_kv = [&](const bf16_t* kv, int opq, int ln) {
-    const int kn = ln & 15, kg = ln >> 4, vsub = ln & 3, vkey = ln >> 2;
+    const int kn = ln & 15, kg = ln >> 4;
     const __amdgpu_buffer_rsrc_t rs = zn_rsrc(kv);
     const int kbase = ar * a.max_len * rowbytes + (kvh * HD + 8 * kg) * 2, kr0 = opq + tb + wave * 16 + kn;
 #pragma unroll
     for (int tl = 0; tl < TPW; ++tl)
 #pragma unroll
       for (int st = 0; st < KST; ++st) kk[tl][st] = __builtin_amdgcn_raw_buffer_load_b128(rs, kbase + min(kr0 + tl * NW * 16, hi) * rowbytes + 64 * st, 0, 0);
-    const int vbase = ar * a.max_len * rowbytes + ((a.n_heads_kv + kvh) * HD + vsub * 8) * 2, vr0 = opq + tb + wave * 16 + vkey;
+    // V in the layout the P.V contraction on the matrix cores wants (k = keys): lane (kn, kg) holds keys 8 kg .. + 8 of each 32-key step x dims
+    // 8 kn .. + 8, transposed in registers into the B operands; a load instruction covers four whole 256-byte rows
+    const int vbase = ar * a.max_len * rowbytes + ((a.n_heads_kv + kvh) * HD + kn * 8) * 2, vr0 = opq + tb + wave * 64 + 8 * kg;
 #pragma unroll
-    for (int sl = 0; sl < NSL; ++sl)
+    for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-      for (int i = 0; i < NR; ++i) vv[sl][i] = __builtin_amdgcn_raw_buffer_load_b128(rs, vbase + min(vr0 + i * (NW * 16), hi) * rowbytes + 64 * sl, 0, 0);
+      for (int j = 0; j < 8; ++j) {
+        const u32x4 x = __builtin_amdgcn_raw_buffer_load_b128(rs, vbase + min(vr0 + 32 * ks + j, hi) * rowbytes, 0, 0);
+        V.v[ks][j][0] = x.x; V.v[ks][j][1] = x.y; V.v[ks][j][2] = x.z; V.v[ks][j][3] = x.w;
+      }
   };
   issue_kv(a.layers[0].kv, 0, lane_in);
   const __amdgpu_buffer_rsrc_t rs_bmax = zn_rsrc(a.g_bmax), rs_part = zn_rsrc(a.g_part);
@@ -422,8 +168,7 @@ ZN_DEVINL void step_attention_kb_role(const ChainArgs& a, StepKbLds& S, const un
     stamp(0);
     int lane = lane_in;
     asm volatile("" : "+v"(lane));
-    const int kn = lane & 15, kg = lane >> 4;
-    const int vsub = lane & 3, vkey = lane >> 2, row = lane >> 4;
+    const int kn = lane & 15, kg = lane >> 4, vsub = lane & 3;
     const int tid = wave * 64 + lane;
     // ---- q (4 heads) and, in the newest block's workgroup, this step's key and value row of the kv head -> LDS
     if (wave == ZN_SK_CW || (wave == ZN_SK_CW + 1 && has_newest)) {
@@ -522,74 +267,30 @@ ZN_DEVINL void step_attention_kb_role(const ChainArgs& a, StepKbLds& S, const un
     }
     __syncthreads();                                         // K3: the running maxima are known
     stamp(3);
-    // ---- pass 2 on this block's keys (attn_pv_kernel<128, 4, 2>: lane = (key vkey, head / 8-wide value piece vsub)), slice by slice
+    // ---- pass 2 on this block's keys: the launches' arithmetic (zn_decode_kernels.h)
     {
       float m_run = -INFINITY;
       for (int j = 0; j < jb; ++j) m_run = fmaxf(m_run, S.bmall[j][vsub]);
-      const float mnew = fmaxf(m_run, S.bmall[jb][vsub]);
-      const int nvec = nkeys & ~15;                          // decode steps: the reference's block loop spans exactly the context
-      float ev[NR], lsum = 0.f;
-#pragma unroll
-      for (int i = 0; i < NR; ++i) {
-        const int base = i * (NW * 16), idx = base + wave * 16 + vkey;
-        const bool ok = idx < nkeys;
-        const float x = __fsub_rn(ok ? S.sc[vsub][idx] : 0.f, mnew);
-        if (base + NW * 16 <= nvec) ev[i] = ok ? zn_fexp_u20(x) : 0.f;
-        else ev[i] = ok ? ((idx < nvec) ? zn_fexp_u20(x) : expf(x)) : 0.f;
-        lsum += ev[i];
-      }
-#pragma unroll
-      for (int sl = 0; sl < NSL; ++sl) {
-        const u32x4 vnew_piece = *(const u32x4*)&S.vnew[sl * 32 + vsub * 8];
-        float acc[G][8];
-#pragma unroll
-        for (int g = 0; g < G; ++g)
-#pragma unroll
-          for (int e = 0; e < 8; ++e) acc[g][e] = 0.f;
-#pragma unroll
-        for (int i = 0; i < NR; ++i) {
-          const int idx = i * (NW * 16) + wave * 16 + vkey;
-          u32x4 v = vv[sl][i];
-          if (tb + idx >= L - 1) v = vnew_piece;
-          if (!(idx < nkeys)) v = u32x4{0, 0, 0, 0};
-          const float v0 = lo_f(v.x), v1 = hi_f(v.x), v2f = lo_f(v.y), v3 = hi_f(v.y);
-          const float v4 = lo_f(v.z), v5 = hi_f(v.z), v6 = lo_f(v.w), v7 = hi_f(v.w);
-#pragma unroll
-          for (int g = 0; g < G; ++g) {
-            float pr = bfround(ev[i]);
-            pr = (g % 4 == 0) ? dpp_mov<0x00>(pr) : (g % 4 == 1) ? dpp_mov<0x55>(pr) : (g % 4 == 2) ? dpp_mov<0xAA>(pr) : dpp_mov<0xFF>(pr);
-            acc[g][0] = fmaf(pr, v0, acc[g][0]); acc[g][1] = fmaf(pr, v1, acc[g][1]);
-            acc[g][2] = fmaf(pr, v2f, acc[g][2]); acc[g][3] = fmaf(pr, v3, acc[g][3]);
-            acc[g][4] = fmaf(pr, v4, acc[g][4]); acc[g][5] = fmaf(pr, v5, acc[g][5]);
-            acc[g][6] = fmaf(pr, v6, acc[g][6]); acc[g][7] = fmaf(pr, v7, acc[g][7]);
-          }
-        }
-        // reduce: 4 key lanes per 16-lane row by DPP, the rows of the workgroup through LDS in the split kernel's order
-#pragma unroll
-        for (int g = 0; g < G; ++g) {
-          float red[8];
-#pragma unroll
-          for (int e = 0; e < 8; ++e) red[e] = row_stride4_sum(acc[g][e]);
-          if ((lane & 15) < 4) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) S.acc[wave * 4 + row][g][sl * 32 + (lane & 3) * 8 + e] = red[e];
-          }
-        }
-      }
-      float ls = row_stride4_sum(lsum);
-      ls = (readlane_f(ls, 0) + readlane_f(ls, 16)) + (readlane_f(ls, 32) + readlane_f(ls, 48));
-      float l1 = row_stride4_sum(lsum); l1 = (readlane_f(l1, 1) + readlane_f(l1, 17)) + (readlane_f(l1, 33) + readlane_f(l1, 49));
-      float l2 = row_stride4_sum(lsum); l2 = (readlane_f(l2, 2) + readlane_f(l2, 18)) + (readlane_f(l2, 34) + readlane_f(l2, 50));
-      float l3 = row_stride4_sum(lsum); l3 = (readlane_f(l3, 3) + readlane_f(l3, 19)) + (readlane_f(l3, 35) + readlane_f(l3, 51));
-      if (lane == 0) { S.l[wave][0] = ls; S.l[wave][1] = l1; S.l[wave][2] = l2; S.l[wave][3] = l3; }
+      const float mnew[1] = {fmaxf(m_run, S.bmall[jb][vsub])};
+      attn_block_probs<G>(S.sc, mnew, nkeys, nkeys & ~15, S.p, S.l, wave, lane);      // decode steps: the reference's block loop spans exactly the context
     }
+    __syncthreads();                                         // K3b: P of the whole block is in LDS
+    if (has_newest && ((L - 1 - tb) >> 6) == wave) {          // wave-uniform: this step's value row comes from the hand-off, not from the cache
+      const u32x4 vnew_piece = *(const u32x4*)&S.vnew[8 * kn];
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          if (tb + wave * 64 + 32 * ks + 8 * kg + j == L - 1) { V.v[ks][j][0] = vnew_piece.x; V.v[ks][j][1] = vnew_piece.y; V.v[ks][j][2] = vnew_piece.z; V.v[ks][j][3] = vnew_piece.w; }
+    }
+    attn_block_pv<HD, G>(S.p, V, S.accw, wave, lane);
     __syncthreads();                                         // K4: partial sums of all 8 waves
     stamp(4);
     {
       const int g = tid >> 7, d = tid & 127;                 // 512 threads = 4 heads x 128 value columns
       float v = 0.f, l = 0.f;
 #pragma unroll
-      for (int w = 0; w < NW * 4; ++w) v += S.acc[w][g][d];
+      for (int w = 0; w < NW; ++w) v += S.accw[w][g][d];
 #pragma unroll
       for (int w = 0; w < NW; ++w) l += S.l[w][g];
       if (nb == 1) S.out[g][d] = f2bf(__fmul_rn(v, 1.0f / l));
@@ -606,7 +307,7 @@ ZN_DEVINL void step_attention_kb_role(const ChainArgs& a, StepKbLds& S, const un
       unsigned o;
       if (nb == 1) o = *(const unsigned*)&S.out[g][2 * dp];
       else {
-        // the combine of attn_pv_kernel<.., 2>: the reference's recurrence over the blocks, in order
+        // attn_block_kernel's combine: the reference's recurrence over the blocks, in order
         const int voff = ((pair * MAXNB) * PSZ + g * 128 + 2 * dp) * 8, loff = ((pair * MAXNB) * PSZ + G * 128 + g) * 8;
         // in chunks of CH blocks (every pass requests all CH entries of its chunk, blocks past the context repeating the last one: an
         // entry that kept its value from the pass before would be carried around the retry loop in a second set of registers)
@@ -677,9 +378,8 @@ ZN_DEVINL void step_attention_kb_role(const ChainArgs& a, StepKbLds& S, const un
 // ------------------------------------------------------------------------------------------------ the launch
 // T_* = tiles per compute wave per op (upper bounds: the matrices do not divide evenly over 224 workgroups; a wave skips the tiles
 // its workgroup does not have).  d_model = 512 * NCH, d_ff = 4 * d_model (host-checked, as are the bounds).
-// ATT: 0 = the legacy attention role (32 workgroups per value slice, contexts up to ZN_SK_MAXKEYS); n >= 1 = one attention workgroup per key block,
-// launches covering up to n blocks (a.natt = 8 * blocks of the launch's context bound).
-template <int NCH, int T_OUT, int T_FC1, int T_FC2, int T_IN, int ATT = 0>
+// NBV: key blocks a launch of this instantiation may be asked to cover (a.natt = 8 * blocks of the launch's context bound <= 8 * NBV).
+template <int NCH, int T_OUT, int T_FC1, int T_FC2, int T_IN, int NBV>
 __global__ __launch_bounds__(ZN_SK_THREADS) void step_kernel(ChainArgs a_in) {
   // Integer arguments that the whole kernel keeps using are detached from the kernarg segment's wide scalar loads: read as parts of an
   // s_load_dwordx8 they made the register allocator spill the 256-bit tuple, rematerialise it instead, and leave its 32-byte stack slot
@@ -702,8 +402,7 @@ __global__ __launch_bounds__(ZN_SK_THREADS) void step_kernel(ChainArgs a_in) {
   extern __shared__ __attribute__((aligned(16))) unsigned char zn_dyn_lds[];
   const int natt = a.natt;
   if (c < natt) {
-    if constexpr (ATT == 0) step_attention_role(a, *reinterpret_cast<StepAttnLds*>(zn_dyn_lds), tag0, c, wave, lane);
-    else step_attention_kb_role<ATT>(a, *reinterpret_cast<StepKbLds*>(zn_dyn_lds), tag0, c, wave, lane);
+    step_attention_kb_role<NBV>(a, *reinterpret_cast<StepKbLds*>(zn_dyn_lds), tag0, c, wave, lane);
     return;
   }
   // ------------------------------------------------------------------------------------------------ streaming role
