@@ -88,7 +88,7 @@ def _teacher_forced_tokens(model, cond, g, dec_margin=0.5):
     return float(agree.mean()), bool(agree[decisive].all())
 
 
-def _compare_logits(got, ref, margin, name, tol):
+def _compare_logits(got, ref, margin, name, tol, dec=None):
     fin = np.isfinite(ref)
     assert np.array_equal(np.isfinite(got), fin)
     diff = np.abs(np.where(fin, got - ref, 0.0))
@@ -97,8 +97,9 @@ def _compare_logits(got, ref, margin, name, tol):
     assert diff.max() <= tol, (name, diff.max())
     # greedy index equality wherever the reference margin is decisive
     ga, ra = np.where(fin, got, -np.inf).argmax(-1), np.where(fin, ref, -np.inf).argmax(-1)
-    decisive = margin > 2 * tol
-    print(f"[{name}] decisive (margin>{2 * tol}) {decisive.mean():.3f} of (step,codebook) pairs; argmax equal on all pairs: {(ga == ra).mean():.4f}")
+    dec = 2 * tol if dec is None else dec
+    decisive = margin > dec
+    print(f"[{name}] decisive (margin>{dec}) {decisive.mean():.3f} of (step,codebook) pairs; argmax equal on all pairs: {(ga == ra).mean():.4f}")
     assert np.array_equal(ga[decisive], ra[decisive])
     return exact
 
@@ -420,7 +421,7 @@ def test_full_dims_teacher_forced_vs_reference(golden_dir, full):
     steps = g["logit_steps"]
     spread, flip = _ref_variation("gaussian")
     print(f"\n[full] the reference's own variation across host thread counts: max |dlogit| {spread}, largest margin of an argmax flip {flip}")
-    _compare_logits(got[steps], g["logits"], g["margin"][steps], "full", tol=spread)       # |dlogit| <= the reference's own spread; argmax equal beyond 2 x it
+    _compare_logits(got[steps], g["logits"], g["margin"][steps], "full", tol=spread, dec=spread)       # |dlogit| <= the reference's own spread; argmax equal beyond it
     # greedy tokens of every step vs the reference's tokens, on decisive margins
     ref_tok = g["tokens"].astype(np.int64)              # [calls, 1, 9]
     bias_free = got.copy()
@@ -433,10 +434,10 @@ def test_full_dims_teacher_forced_vs_reference(golden_dir, full):
             lg = zo.repetition_penalty(lg, hist, 3.0, 2)
         ga.append(lg.argmax(-1).numpy())
     ga = np.stack(ga)
-    decisive = g["margin"] > 2 * spread
+    decisive = g["margin"] > spread
     agree = (ga == ref_tok)
     worst = float(g["margin"][~agree].max()) if (~agree).any() else 0.0
-    print(f"\n[full] greedy tokens equal on {agree.mean():.4f} of all (step,codebook); decisive (margin > {2 * spread}) pairs {decisive.mean():.3f}; "
+    print(f"\n[full] greedy tokens equal on {agree.mean():.4f} of all (step,codebook); decisive (margin > {spread}) pairs {decisive.mean():.3f}; "
           f"largest reference margin of a HIP-vs-reference flip {worst} (the reference against itself: {flip})")
     assert agree[decisive].all()
 
@@ -455,10 +456,10 @@ def test_full_dims_free_running(golden_dir, full):
         model.fused_heads.weight.data.copy_(heads.to("cuda:0"))
         _free_run(model, cond, gp, "full peaky")
         # peaky logits reach |l| ~ 100-200 where one bf16 ulp is 0.5-1.0; the reference itself, run with another thread count, moves them by
-        # up to `spread` and flips argmaxes at margins up to `flip`: "decisive" = margin > 2 x spread
+        # up to `spread` and flips argmaxes at margins up to `flip`: "decisive" = margin > spread
         spread, flip = _ref_variation("peaky")
         print(f"\n[full peaky] the reference's own variation: max |dlogit| {spread}, largest margin of an argmax flip {flip}")
-        agree, dec = _teacher_forced_tokens(model, cond, gp, dec_margin=2 * spread)
+        agree, dec = _teacher_forced_tokens(model, cond, gp, dec_margin=spread)
     finally:
         model.fused_heads.weight.data.copy_(keep)
     assert agree > 0.95 and dec, (agree, dec)
@@ -509,7 +510,8 @@ def test_config5_long_prefix_prefill_vs_reference(golden_dir, full):
     pre = torch.from_numpy(synth.randint(1234, "longprefix", (1, 9, P), 1024)).to("cuda:0")
     got = _teacher_forced(model, cond, int(g["max_new"]), g["inputs"], prefix=pre)
     steps = g["logit_steps"]
-    _compare_logits(got[steps], g["logits"], g["margin"][steps], f"config5 prefix {P}", tol=0.1)
+    spread, _ = _ref_variation("gaussian")                 # the reference's own |dlogit| across host thread counts (64-step run at short contexts)
+    _compare_logits(got[steps], g["logits"], g["margin"][steps], f"config5 prefix {P}", tol=spread, dec=spread)
 
 
 def test_config5_longform_generation_properties(full):
