@@ -287,7 +287,7 @@ def run_rank(args) -> int:
             eng.call("zn_bench_kernel", which, 2 * B, 260, C.byref(ms), C.byref(by), _lib.stream_ptr())
         ach = by.value / (ms.value * 1e-3)
         traffic, traffic_note = pmc_traffic(which) if which in PMC_FILES else (None, "PMC summaries cover the batch-1 persistent kernels only")
-        kname = {6: "step_kernel<NCH=4,T_OUT=2,T_FC1=10,T_FC2=5,T_IN=6> (whole decode step in one persistent launch: per block attention, out_proj x2, LayerNorm+fc1+SiLU-gate, fc2, "
+        kname = {6: "step_kernel<NCH=4,T_OUT=2,T_FC1=10,T_FC2=5,T_IN=6,NBV=6> (whole decode step in one persistent launch: per block attention, out_proj x2, LayerNorm+fc1+SiLU-gate, fc2, "
                     f"next block's LayerNorm+in_proj+RoPE+KV append; norm_f + heads; context {STEP_KERNEL_CTX} keys)",
                  5: "chain_kernel<NCH=4,T_OUT=1,T_FC1=8,T_FC2=4,T_IN=2> (out_proj x2 + LayerNorm+fc1+SiLU-gate + fc2 + next block's LayerNorm+in_proj+RoPE+KV append, one persistent launch)",
                  0: "gemm16s/gemv LayerNorm+fc1+SiLU-gate"}[which]

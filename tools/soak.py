@@ -1,6 +1,8 @@
 """Soak of the default batch-1 decode path (whole-step kernel): N full-length generations (10 s each: prefill + 868 decode steps = 26 x 6
-in-kernel hand-offs per step), every one compared with the first (the kernels are deterministic) - codes must be identical, no hand-off
-wait may give up, the handle must still be on the whole-step kernel at the end.
+in-kernel hand-offs per step, 26 x 8 beyond 512 keys of context), every one compared with the first (the kernels are deterministic) - codes
+must be identical, no hand-off wait may give up, the handle must still be on the whole-step kernel at the end.  Every 10th generation is
+followed by a long one (the reference's default 30 s call, or 10 s behind a 2584-frame audio prefix = contexts 2.6 - 3.5 k: the key-block
+attention role with 6 - 7 blocks and the change of instantiation at 3072 keys), each compared with its own first run.
     python tools/soak.py [generations] [sampled]      # "sampled": temperature 1.0 + min_p 0.1 with a fixed seed instead of greedy decoding"""
 import os
 import sys
@@ -21,6 +23,21 @@ cond = synth.conditioning(1234, "cond", 2, 24, 2048).to("cuda:0")
 ref = None
 t0 = time.perf_counter()
 worst = 0.0
+long_ref = {}
+prefix = torch.from_numpy(synth.randint(1234, "longprefix", (1, 9, 2584), 1024)).to("cuda:0")
+
+
+def long_one(kind):
+    o = (model.generate(cond, max_new_tokens=2580, sampling_params=SP, seed=4242) if kind == "30s" else
+         model.generate(cond, audio_prefix_codes=prefix, max_new_tokens=861, sampling_params=SP, seed=4242))
+    torch.cuda.synchronize()
+    p = eng.lib.zn_decode_path_detail(eng.h)
+    same_ = kind not in long_ref or torch.equal(o, long_ref[kind])
+    long_ref.setdefault(kind, o.clone())
+    print(f"  long generation ({kind}): path {p}, identical to its first run: {same_}", flush=True)
+    assert same_ and p == 2, "soak failed (long generation)"
+
+
 for i in range(n):
     torch.cuda.synchronize()
     ta = time.perf_counter()
@@ -35,5 +52,9 @@ for i in range(n):
     if not same or path != 2 or i % 10 == 0:
         print(f"generation {i}: {dt * 1e3:.1f} ms, path {path}, identical to the first: {same}", flush=True)
     assert same and path == 2, "soak failed"
+    if i % 10 == 9:
+        long_one("30s" if (i // 10) % 2 == 0 else "prefix")
 hand_offs = n * 869 * 26 * 6
-print(f"{n} generations ({hand_offs / 1e6:.1f} M in-kernel hand-offs) in {time.perf_counter() - t0:.1f} s, slowest {worst * 1e3:.1f} ms: all identical, no wait gave up")
+print(f"counters: {eng.counters()}")
+assert eng.counters()["handoff_timeouts"] == 0
+print(f"{n} generations ({hand_offs / 1e6:.1f} M in-kernel hand-offs, the long ones not counted) in {time.perf_counter() - t0:.1f} s, slowest {worst * 1e3:.1f} ms: all identical, no wait gave up")
