@@ -39,6 +39,14 @@
 #ifndef ZN_SWEEP_BACKOFF
 #define ZN_SWEEP_BACKOFF 0                                 // s_sleep units (64 cycles) between a failed sweep pass and the next
 #endif
+// Timing-only builds (tools/build_variants.py; outputs WRONG, never shipped): -DZN_TIMING_STREAM_ONLY makes every hand-off wait succeed on its
+// first pass whatever it read (the weight stream and the arithmetic alone: what a block costs without its dependency chain);
+// -DZN_TIMING_HANDOFFS_ONLY replaces the whole-step kernel's weight tiles by zeros without loading them (the dependency chain alone).
+#ifdef ZN_TIMING_STREAM_ONLY
+#define ZN_TIMING_PASS(bad) (bad) = 0ull
+#else
+#define ZN_TIMING_PASS(bad) (void)0
+#endif
 #define ZN_CH_TIMEOUT_TICKS 2000000ull                     // 20 ms of s_memrealtime (100 MHz) ...
 #define ZN_CH_TIMEOUT_PASSES 4096u                         // ... AND this many sweep passes (~1 us each when the wave runs): see sweep_granules
 
@@ -126,7 +134,8 @@ ZN_DEVINL bool sweep_granules_at(__amdgpu_buffer_rsrc_t rs, OffFn off, unsigned 
       ok &= (l0.y == tag) & (l0.w == tag) & (l1.y == tag) & (l1.w == tag);
       data[i] = u32x4{l0.x, l0.z, l1.x, l1.z};
     }
-    const unsigned long long bad = __builtin_amdgcn_ballot_w64(!ok);
+    unsigned long long bad = __builtin_amdgcn_ballot_w64(!ok);
+    ZN_TIMING_PASS(bad);
     if (bad == 0ull) { if (passes_out) *passes_out = np; return true; }
     if constexpr (ZN_SWEEP_BACKOFF > 0) __builtin_amdgcn_s_sleep(ZN_SWEEP_BACKOFF);      // a failed pass: let the publishers' stores through before asking again
     if ((np >= ZN_CH_TIMEOUT_PASSES && __builtin_amdgcn_s_memrealtime() - t0 > ZN_CH_TIMEOUT_TICKS) || __hip_atomic_load(tmo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
@@ -151,6 +160,41 @@ ZN_DEVINL bool sweep_granules_at(__amdgpu_buffer_rsrc_t rs, OffFn off, unsigned 
 template <int N>
 ZN_DEVINL bool sweep_granules(__amdgpu_buffer_rsrc_t rs, const int (&off)[N], unsigned tag, u32x4 (&data)[N], int* tmo, int lane, SweepWho who, unsigned* passes_out = nullptr) {
   return sweep_granules_at<N>(rs, [&](int i) { return off[i]; }, tag, data, tmo, lane, who, passes_out);
+}
+
+// One 32-byte piece per lane (four granules), DEPTH passes in flight: a new pass goes out every time the oldest returns, so that the wait ends
+// within a fraction of a memory round trip of the granules becoming visible instead of within a whole one.  For the attention workgroups of
+// the whole-step kernel only: their CUs stream no weights and they are few (polling from the 448 communication waves of the streaming
+// workgroups this way loads the fabric their publishers' stores travel on: measured slower).
+template <int DEPTH>
+ZN_DEVINL bool sweep_granules_piped(__amdgpu_buffer_rsrc_t rs, int off, unsigned tag, u32x4& data, int* tmo, int lane, SweepWho who) {
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+  unsigned np = 0;
+  u32x4 l0[DEPTH], l1[DEPTH];
+#pragma unroll
+  for (int d = 0; d < DEPTH; ++d) { l0[d] = ld_sc1_16(rs, off); l1[d] = ld_sc1_16(rs, off + 16); }
+  for (;;) {
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) {
+      ++np;
+      const u32x4 a0 = l0[d], a1 = l1[d];                    // (waits for this pass only: the later ones stay in flight)
+      const bool ok = (a0.y == tag) & (a0.w == tag) & (a1.y == tag) & (a1.w == tag);
+      unsigned long long bad = __builtin_amdgcn_ballot_w64(!ok);
+      ZN_TIMING_PASS(bad);
+      if (bad == 0ull) { data = u32x4{a0.x, a0.z, a1.x, a1.z}; return true; }
+      if ((np >= ZN_CH_TIMEOUT_PASSES && __builtin_amdgcn_s_memrealtime() - t0 > ZN_CH_TIMEOUT_TICKS) || __hip_atomic_load(tmo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+        if (lane == (int)__builtin_ctzll(bad) && atomicAdd(tmo, 1) == 0 && who.diag) {
+          const unsigned badoff = a0.y != tag ? off : a0.w != tag ? off + 8 : a1.y != tag ? off + 16 : off + 24;
+          const unsigned badtag = a0.y != tag ? a0.y : a0.w != tag ? a0.w : a1.y != tag ? a1.y : a1.w;
+          who.diag[0] = who.code; who.diag[1] = blockIdx.x; who.diag[2] = threadIdx.x >> 6; who.diag[3] = tag;
+          who.diag[4] = badoff; who.diag[5] = badtag; who.diag[6] = (unsigned)lane; who.diag[7] = np;
+        }
+        data = u32x4{a0.x, a0.z, a1.x, a1.z};
+        return false;
+      }
+      l0[d] = ld_sc1_16(rs, off); l1[d] = ld_sc1_16(rs, off + 16);
+    }
+  }
 }
 
 // The same bounded, self-describing wait for sweeps whose requests do not have sweep_granules' shape (the key-block attention role's

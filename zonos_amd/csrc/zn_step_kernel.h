@@ -54,6 +54,15 @@
 #define ZN_SK_SWEEP_DELAY 40                                // s_sleep units (64 cycles) between an op's publish and the first sweep pass for its output
 #endif                                                      // (two sweep passes in flight per wave, a new one every half round trip: 0.891 vs 0.869 ms per step - more polling loads the fabric)
 #define ZN_SK_DYN_LDS (ZN_SK_CW * ZN_SK_PARK * 8192)        // parked tiles (streaming role) / StepKbLds (attention role)
+#ifndef ZN_SK_APOLL
+#define ZN_SK_APOLL 1                                       // sweep passes an attention workgroup keeps in flight while it waits for a hand-off.  Its CU streams nothing, and
+#endif                                                      // still: 2 / 3 passes in flight cost 0.914 / 0.940 ms per step at 600 keys against 0.861 with one (polling loads the fabric)
+#ifndef ZN_SK_XDELAY
+#define ZN_SK_XDELAY 16                                     // s_sleep units (64 cycles) between an attention workgroup's publish (block maxima, partials) and its first sweep pass for the
+#endif                                                      // others', from ZN_SK_XDELAY_NB blocks on: 0 / 16 / 32 / 48 units: 0.857 / 0.870 / 0.884 / 0.900 ms per step at 2 blocks, 0.878 / 0.896 /
+#ifndef ZN_SK_XDELAY_NB                                     // 0.906 / 0.919 at 4, 0.939 / 0.913 / 0.929 / 0.944 at 6, 1.030 / 1.004 / 1.018 / 1.034 at 8, 1.084 / 1.052 / 1.069 / 1.085 at 10
+#define ZN_SK_XDELAY_NB 5
+#endif
 #ifndef ZN_SK_PACE_MARGIN
 #define ZN_SK_PACE_MARGIN 0                                 // > 0: sleep until this many 10 ns ticks before the previous wait's length instead of a fraction of it
 #endif
@@ -71,6 +80,9 @@ struct StepPacer {
   unsigned long long t_ref; unsigned prev;
   ZN_DEVINL void start() { t_ref = __builtin_amdgcn_s_memrealtime(); }
   ZN_DEVINL void sleep() const {
+#ifdef ZN_TIMING_STREAM_ONLY
+    return;
+#endif
     const unsigned long long until = t_ref + (ZN_SK_PACE_MARGIN > 0 ? (prev > ZN_SK_PACE_MARGIN ? prev - ZN_SK_PACE_MARGIN : 0u) : (prev - (prev >> ZN_SK_PACE_SHIFT)));
     while (__builtin_amdgcn_s_memrealtime() < until) __builtin_amdgcn_s_sleep(8);
   }
@@ -115,6 +127,70 @@ struct StepKbLds {
   __attribute__((aligned(16))) bf16_t out[4][128];          // normalised result (one-block contexts)
 };
 static_assert(sizeof(StepKbLds) <= ZN_SK_DYN_LDS, "the key-block attention role's LDS fits the launch's dynamic LDS");
+
+// The combine of a (row, kv head) pair's blocks j0 .. j0 + CH - 1 (attn_block_kernel's recurrence): sweeps the blocks' partials of one output
+// pair (P.V of columns 2 dp, 2 dp + 1 of head g as two granules = one 16-byte load; the e sum of head g as one granule), DEPTH passes in flight,
+// and folds them into (tot0, tot1, lt, mprev) in block order.  Every pass requests all CH entries, blocks past the context repeating the last
+// one (an entry that kept its value from the pass before would be carried around the retry loop in a second set of registers).
+template <int CH, int DEPTH>
+ZN_DEVINL void kb_combine_chunk(__amdgpu_buffer_rsrc_t rs_part, int voff, int loff, int j0, int nb, unsigned tag, const float (*bmall)[4], int g,
+                                float& tot0, float& tot1, float& lt, float& mprev, int* tmo, int lane, SweepWho who) {
+  constexpr int PSZ8 = ZN_SK_KB_PSZ * 8;
+  u32x4 pv[DEPTH][CH];
+  u32x2 pl[DEPTH][CH];                                       // {e sum, tag} of head g: one granule
+  auto issue = [&](auto DC) {
+    constexpr int d = decltype(DC)::value;
+#pragma unroll
+    for (int j = 0; j < CH; ++j) {
+      const int jo = min(j0 + j, nb - 1) * PSZ8;
+      pv[d][j] = ld_sc1_16(rs_part, voff + jo);
+      pl[d][j] = ld_sc1_8(rs_part, loff + jo);
+    }
+  };
+  zn_static_for<0, DEPTH>([&](auto DC) { issue(DC); });
+  SpinBound sb; sb.begin();
+  int got = -1;
+  while (got < 0) {
+    zn_static_for<0, DEPTH>([&](auto DC) {
+      constexpr int d = decltype(DC)::value;
+      if (got >= 0) return;
+      ++sb.np;
+      bool ok = true;
+#pragma unroll
+      for (int j = 0; j < CH; ++j) ok &= (pv[d][j].y == tag) & (pv[d][j].w == tag) & (pl[d][j].y == tag);
+      unsigned long long bad = __builtin_amdgcn_ballot_w64(!ok);
+      ZN_TIMING_PASS(bad);
+      if (bad == 0ull) { got = d; return; }
+      if (sb.give_up(tmo)) {
+        unsigned badoff = 0, badtag = 0;
+#pragma unroll
+        for (int j = CH - 1; j >= 0; --j) {
+          const bool okj = (pv[d][j].y == tag) & (pv[d][j].w == tag) & (pl[d][j].y == tag);
+          if (!okj) { badoff = (unsigned)(voff + min(j0 + j, nb - 1) * PSZ8); badtag = pv[d][j].y != tag ? pv[d][j].y : pv[d][j].w != tag ? pv[d][j].w : pl[d][j].y; }
+        }
+        sb.report(tmo, who, bad, lane, tag, badoff, badtag);
+        got = d;
+        return;
+      }
+      issue(DC);
+    });
+  }
+  zn_static_for<0, DEPTH>([&](auto DC) {
+    constexpr int d = decltype(DC)::value;
+    if (got != d) return;                                    // uniform
+#pragma unroll
+    for (int j = 0; j < CH; ++j) {
+      if (j0 + j < nb) {
+        const float mj = fmaxf(mprev, bmall[j0 + j][g]);
+        const float fj = (j0 + j == 0) ? 0.f : expf(mprev - mj);
+        mprev = mj;
+        tot0 = __fadd_rn(__fmul_rn(tot0, fj), __uint_as_float(pv[d][j].x));
+        tot1 = __fadd_rn(__fmul_rn(tot1, fj), __uint_as_float(pv[d][j].z));
+        lt = __fadd_rn(__fmul_rn(lt, fj), __uint_as_float(pl[d][j].x));
+      }
+    }
+  });
+}
 
 template <int NBV>          // blocks this instantiation's launches can be asked to cover (<= ZN_SK_KB_MAXNB): the unroll bound of the combine
 ZN_DEVINL void step_attention_kb_role(const ChainArgs& a, StepKbLds& S, const unsigned tag0, const int c, const int wave, const int lane_in) {
@@ -184,10 +260,9 @@ ZN_DEVINL void step_attention_kb_role(const ChainArgs& a, StepKbLds& S, const un
         const int qoff = (ar * (a.nqkv / 2) + ((kvh * G) * HD) / 2 + lane * 4) * 8;
         const int kvsel = lane < 16 ? nq + kvh * HD : nq + nk + kvh * HD;
         const int koff = (ar * (a.nqkv / 2) + kvsel / 2 + (lane & 15) * 4) * 8;
-        int off1[1] = {first ? qoff : koff};
         u32x4 d1[1];
         pace.sleep();
-        sweep_granules<1>(zn_rsrc(a.g_qkv), off1, tag - 1u, d1, a.tmo, lane, SweepWho{(5u << 8) | (unsigned)li, a.diag});
+        sweep_granules_piped<ZN_SK_APOLL>(zn_rsrc(a.g_qkv), first ? qoff : koff, tag - 1u, d1[0], a.tmo, lane, SweepWho{(5u << 8) | (unsigned)li, a.diag});
         pace.done();
         if (first) *(u32x4*)&S.q[lane >> 4][(lane & 15) * 8] = d1[0];
         else if (lane < 16) *(u32x4*)&S.knew[lane * 8] = d1[0];
@@ -251,17 +326,28 @@ ZN_DEVINL void step_attention_kb_role(const ChainArgs& a, StepKbLds& S, const un
         if (lane < G) st_granule(a.g_bmax + ((size_t)pair * MAXNB + jb) * G + lane, tag, __float_as_uint(bmx));
         const bool act = lane < 2 * nb;                      // lane = (block lane >> 1, head pair lane & 1): one 16-byte load = two granules
         const int off = ((pair * MAXNB) * G + 2 * (act ? lane : 0)) * 8;
+        if (ZN_SK_XDELAY > 0 && nb >= ZN_SK_XDELAY_NB) __builtin_amdgcn_s_sleep(ZN_SK_XDELAY);
         SpinBound sb; sb.begin();
-        for (;;) {
-          ++sb.np;
-          const u32x4 v = ld_sc1_16(rs_bmax, off);
-          const bool ok = !act || ((v.y == tag) & (v.w == tag));
-          const unsigned long long bad = __builtin_amdgcn_ballot_w64(!ok);
-          if (bad == 0ull) {
-            if (act) { S.bmall[lane >> 1][2 * (lane & 1)] = __uint_as_float(v.x); S.bmall[lane >> 1][2 * (lane & 1) + 1] = __uint_as_float(v.z); }
-            break;
+        u32x4 pv_[ZN_SK_APOLL];
+#pragma unroll
+        for (int d = 0; d < ZN_SK_APOLL; ++d) pv_[d] = ld_sc1_16(rs_bmax, off);
+        for (bool done = false; !done;) {
+#pragma unroll
+          for (int d = 0; d < ZN_SK_APOLL; ++d) {
+            if (done) break;
+            ++sb.np;
+            const u32x4 v = pv_[d];
+            const bool ok = !act || ((v.y == tag) & (v.w == tag));
+            unsigned long long bad = __builtin_amdgcn_ballot_w64(!ok);
+            ZN_TIMING_PASS(bad);
+            if (bad == 0ull) {
+              if (act) { S.bmall[lane >> 1][2 * (lane & 1)] = __uint_as_float(v.x); S.bmall[lane >> 1][2 * (lane & 1) + 1] = __uint_as_float(v.z); }
+              done = true;
+            } else if (sb.give_up(a.tmo)) {
+              sb.report(a.tmo, SweepWho{(7u << 8) | (unsigned)li, a.diag}, bad, lane, tag, (unsigned)off + (v.y != tag ? 0u : 8u), v.y != tag ? v.y : v.w);
+              done = true;
+            } else pv_[d] = ld_sc1_16(rs_bmax, off);
           }
-          if (sb.give_up(a.tmo)) { sb.report(a.tmo, SweepWho{(7u << 8) | (unsigned)li, a.diag}, bad, lane, tag, (unsigned)off + (v.y != tag ? 0u : 8u), v.y != tag ? v.y : v.w); break; }
         }
       } else if (lane < G) S.bmall[0][lane] = bmx;
     }
@@ -309,52 +395,16 @@ ZN_DEVINL void step_attention_kb_role(const ChainArgs& a, StepKbLds& S, const un
       else {
         // attn_block_kernel's combine: the reference's recurrence over the blocks, in order
         const int voff = ((pair * MAXNB) * PSZ + g * 128 + 2 * dp) * 8, loff = ((pair * MAXNB) * PSZ + G * 128 + g) * 8;
-        // in chunks of CH blocks (every pass requests all CH entries of its chunk, blocks past the context repeating the last one: an
-        // entry that kept its value from the pass before would be carried around the retry loop in a second set of registers)
-        constexpr int CH = 6;
+        // in chunks of up to 6 blocks, sized to the context (kb_combine_chunk)
         float tot0 = 0.f, tot1 = 0.f, lt = 0.f, mprev = -INFINITY;
+        const SweepWho who{(8u << 8) | (unsigned)li, a.diag};
+        if (ZN_SK_XDELAY > 0 && nb >= ZN_SK_XDELAY_NB) __builtin_amdgcn_s_sleep(ZN_SK_XDELAY);
+        if (nb <= 2) kb_combine_chunk<2, ZN_SK_APOLL>(rs_part, voff, loff, 0, nb, tag, S.bmall, g, tot0, tot1, lt, mprev, a.tmo, lane, who);
+        else if (nb <= 4) kb_combine_chunk<4, 2>(rs_part, voff, loff, 0, nb, tag, S.bmall, g, tot0, tot1, lt, mprev, a.tmo, lane, who);
+        else {
 #pragma unroll
-        for (int j0 = 0; j0 < NBV; j0 += CH) {
-          if (j0 < nb) {                                      // uniform
-            u32x4 pv[CH];
-            u32x2 pl[CH];                                     // {e sum, tag} of head g: one granule
-            SpinBound sb; sb.begin();
-            for (;;) {
-              ++sb.np;
-#pragma unroll
-              for (int j = 0; j < CH; ++j) {
-                const int jo = min(j0 + j, nb - 1) * (PSZ * 8);
-                pv[j] = ld_sc1_16(rs_part, voff + jo);
-                pl[j] = ld_sc1_8(rs_part, loff + jo);
-              }
-              bool ok = true;
-#pragma unroll
-              for (int j = 0; j < CH; ++j) ok &= (pv[j].y == tag) & (pv[j].w == tag) & (pl[j].y == tag);
-              const unsigned long long bad = __builtin_amdgcn_ballot_w64(!ok);
-              if (bad == 0ull) break;
-              if (sb.give_up(a.tmo)) {
-                unsigned badoff = 0, badtag = 0;
-#pragma unroll
-                for (int j = CH - 1; j >= 0; --j) {
-                  const bool okj = (pv[j].y == tag) & (pv[j].w == tag) & (pl[j].y == tag);
-                  if (!okj) { badoff = (unsigned)(voff + min(j0 + j, nb - 1) * (PSZ * 8)); badtag = pv[j].y != tag ? pv[j].y : pv[j].w != tag ? pv[j].w : pl[j].y; }
-                }
-                sb.report(a.tmo, SweepWho{(8u << 8) | (unsigned)li, a.diag}, bad, lane, tag, badoff, badtag);
-                break;
-              }
-            }
-#pragma unroll
-            for (int j = 0; j < CH; ++j) {
-              if (j0 + j < nb) {
-                const float mj = fmaxf(mprev, S.bmall[j0 + j][g]);
-                const float fj = (j0 + j == 0) ? 0.f : expf(mprev - mj);
-                mprev = mj;
-                tot0 = __fadd_rn(__fmul_rn(tot0, fj), __uint_as_float(pv[j].x));
-                tot1 = __fadd_rn(__fmul_rn(tot1, fj), __uint_as_float(pv[j].z));
-                lt = __fadd_rn(__fmul_rn(lt, fj), __uint_as_float(pl[j].x));
-              }
-            }
-          }
+          for (int j0 = 0; j0 < NBV; j0 += 6)
+            if (j0 < nb) kb_combine_chunk<6, 1>(rs_part, voff, loff, j0, nb, tag, S.bmall, g, tot0, tot1, lt, mprev, a.tmo, lane, who);      // uniform
         }
         const float inv = 1.0f / lt;
         o = pack2(__fmul_rn(tot0, inv), __fmul_rn(tot1, inv));
@@ -539,8 +589,13 @@ __global__ __launch_bounds__(ZN_SK_THREADS) void step_kernel(ChainArgs a_in) {
           tile(slot_of_load(l), ok, pa, pb, ridx);
           if (ok) {                                         // wave-uniform
             WT& w = bufs[b];
+#ifdef ZN_TIMING_HANDOFFS_ONLY
+#pragma unroll
+            for (int c2 = 0; c2 < NCH; ++c2) { w.a[c2] = u32x4{0, 0, 0, 0}; w.b[c2] = u32x4{0, 0, 0, 0}; }
+#else
 #pragma unroll
             for (int c2 = 0; c2 < NCH; ++c2) { w.a[c2] = ld_nt16g(pa + c2 * 512); w.b[c2] = ld_nt16g(pb + c2 * 512); }
+#endif
           }
         }
       };
