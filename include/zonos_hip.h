@@ -154,7 +154,9 @@ int zn_decode_path_detail(zn_handle h);
 /* Hand-off timeouts are never silent: out[0] = bounded in-kernel hand-off waits that gave up and were reported on this handle (each voids
  * its generation; zn_all_stopped* returns the error), [1] generations begun, [2] batch-1 generations that ran the launches path because
  * an earlier timeout had demoted the handle, [3] 1 while the handle is demoted, [4] times it was re-armed (automatically after 4 clean
- * generations on the launches path, or by zn_debug_tune(8, 1)), [5] clean generations since the demotion.  n <= 6 values are written. */
+ * generations on the launches path, or by zn_debug_tune(8, 1)), [5] clean generations since the demotion, [6] the longest in-kernel hand-off
+ * wait any whole-step launch of this handle measured, in microseconds (0: none beyond 0.1 ms; a pause of the device shows up here with its
+ * length), [7] waits beyond 0.2 ms.  n <= 8 values are written; asking for [6], [7] synchronises with the device. */
 int zn_get_counters(zn_handle h, int64_t* out, int32_t n);
 /* Ends the generation begun by zn_gen_begin: releases the device's persistent-kernel tenancy (below) so that another handle's next
  * generation may take it.  The handle's state stays readable (zn_decode_path, zn_get_step_outputs); further steps need a new

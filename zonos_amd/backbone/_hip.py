@@ -225,9 +225,9 @@ class HipEngine:
 
     def counters(self) -> dict:
         """zn_get_counters: hand-off timeouts reported, generations, generations that ran the launches path because of a demotion, ..."""
-        buf = (C.c_int64 * 6)()
-        self.call("zn_get_counters", buf, 6)
-        keys = ("handoff_timeouts", "generations", "fallback_generations", "demoted", "rearms", "clean_since_demotion")
+        buf = (C.c_int64 * 8)()
+        self.call("zn_get_counters", buf, 8)
+        keys = ("handoff_timeouts", "generations", "fallback_generations", "demoted", "rearms", "clean_since_demotion", "longest_wait_us", "waits_over_200us")
         return dict(zip(keys, (int(v) for v in buf)))
 
     def stream(self) -> int:

@@ -49,7 +49,7 @@ struct zn_handle_s {
   bool use_stack = false, stack_ok = false, stack_checked = false;   // use_stack: the steps being enqueued run the whole-step kernel
   unsigned* ch_epoch = nullptr;
   unsigned long long epoch_bound = 1;        // host-side upper bound of the device epoch (tags advance by one per block of every decode step enqueued)
-  unsigned* ch_diag = nullptr;               // [8] words: the first hand-off wait that timed out describes itself (sweep_granules)
+  unsigned* ch_diag = nullptr;               // [16] words: [0..7] the first hand-off wait that timed out describes itself (sweep_granules); [8] the longest hand-off wait a whole-step launch measured (10 ns ticks), [9] waits beyond 0.2 ms (StepPacer::report)
   unsigned diag_host[8] = {};
   bf16_t* ch_x2 = nullptr;
   bf16_t* dbg_trace = nullptr;               // diagnostic: [n_layer][2][rows * d] copies of (x after the block, attention output) per decode step
@@ -1423,11 +1423,15 @@ extern "C" int zn_gen_end(zn_handle h) {
 }
 
 // [0] hand-off timeouts reported on this handle, [1] generations begun, [2] of those, batch-1 generations that ran the launches path because an
-// earlier timeout had demoted the handle, [3] 1 while demoted, [4] times the handle was re-armed, [5] clean generations since the demotion
+// earlier timeout had demoted the handle, [3] 1 while demoted, [4] times the handle was re-armed, [5] clean generations since the demotion,
+// [6] the longest in-kernel hand-off wait any whole-step launch of this handle measured, in microseconds (0: none beyond 0.1 ms), [7] waits
+// beyond 0.2 ms (a pause of the device shows up as one such wait per waiting wave).  Reading [6], [7] synchronises with the device.
 extern "C" int zn_get_counters(zn_handle h, int64_t* out, int32_t n) {
   if (!h || !out || n < 0) return ZN_ERR_ARG;
-  const long long v[6] = {h->n_timeouts, h->n_generations, h->n_fallback_generations, h->demoted ? 1 : 0, h->n_rearms, h->clean_since_demotion};
-  for (int i = 0; i < n && i < 6; ++i) out[i] = v[i];
+  unsigned w[2] = {0, 0};
+  if (n > 6 && h->ch_diag) HIPCHK(h, hipMemcpy(w, h->ch_diag + 8, sizeof w, hipMemcpyDeviceToHost));
+  const long long v[8] = {h->n_timeouts, h->n_generations, h->n_fallback_generations, h->demoted ? 1 : 0, h->n_rearms, h->clean_since_demotion, (long long)(w[0] / 100u), (long long)w[1]};
+  for (int i = 0; i < n && i < 8; ++i) out[i] = v[i];
   return ZN_OK;
 }
 
@@ -1452,7 +1456,7 @@ static int handoff_timeout(zn_handle h, int count) {
   // destroyed (on a non-blocking stream the null-stream copies below would not wait for them).
   if (h->gen_stream) (void)hipStreamSynchronize(h->gen_stream);
   (void)hipMemcpy(h->diag_host, h->ch_diag, sizeof h->diag_host, hipMemcpyDeviceToHost);
-  (void)hipMemset(h->ch_diag, 0, 64);
+  (void)hipMemset(h->ch_diag, 0, 32);                   // (the wait statistics in words 8, 9 stay)
   (void)hipMemset(&h->st->pad[0], 0, sizeof(int));
   h->demoted = true; h->clean_since_demotion = 0; h->n_timeouts++; h->gen_timed_out = true;
   free_graph(h);

@@ -76,8 +76,10 @@
 #ifndef ZN_SK_PACE_CAP
 #define ZN_SK_PACE_CAP 8192u            // 82 us in the 100 MHz ticks of s_memrealtime
 #endif
+#define ZN_SK_LONG_WAIT 20000u          // 0.2 ms in the 100 MHz ticks of s_memrealtime: six block times
 struct StepPacer {
   unsigned long long t_ref; unsigned prev;
+  unsigned worst = 0, n_long = 0;         // observation only (zn_get_counters): the longest wait of this wave in the launch, waits longer than ZN_SK_LONG_WAIT
   ZN_DEVINL void start() { t_ref = __builtin_amdgcn_s_memrealtime(); }
   ZN_DEVINL void sleep() const {
 #ifdef ZN_TIMING_STREAM_ONLY
@@ -92,6 +94,14 @@ struct StepPacer {
   ZN_DEVINL void done() {
     const unsigned long long d = __builtin_amdgcn_s_memrealtime() - t_ref;
     prev = d < ZN_SK_PACE_CAP ? (unsigned)d : ZN_SK_PACE_CAP;
+    const unsigned du = d < 0xffffffffull ? (unsigned)d : 0xffffffffu;
+    worst = du > worst ? du : worst;
+    n_long += du > ZN_SK_LONG_WAIT ? 1u : 0u;
+  }
+  // A pause of the device (section "Pauses of the device") shows up here as one wait of its length in every waiting wave: the launch leaves the
+  // longest wait any wave measured in diag[8] and the number of waits beyond 0.2 ms in diag[9] - observed, never provoked.
+  ZN_DEVINL void report(unsigned* diag, int lane) const {
+    if (lane == 0 && diag) { if (worst > ZN_SK_LONG_WAIT / 2) atomicMax(diag + 8, worst); if (n_long) atomicAdd(diag + 9, n_long); }
   }
 };
 // Test hook (ChainArgs::dbg_pause, zn_debug_tune(14, 11)): what a pause of the device looks like from inside - every wave stops at about the
@@ -423,6 +433,7 @@ ZN_DEVINL void step_attention_kb_role(const ChainArgs& a, StepKbLds& S, const un
     }
     pace.start();                                            // the wait for the next block's q | k | v starts here
   }
+  if (wave == ZN_SK_CW) pace.report(a.diag, lane_in);
 }
 
 // ------------------------------------------------------------------------------------------------ the launch
@@ -832,5 +843,6 @@ __global__ __launch_bounds__(ZN_SK_THREADS) void step_kernel(ChainArgs a_in) {
     if (a.dbg_pause && li == 2) step_debug_pause(a.dbg_pause);     // (outside the measured wait)
     pace.start();                                          // the wait for the next block's attention output starts here
   }
+  pace.report(a.diag, lane);
   if (epi && sc == 0 && lane == 0) st_sc1_u32(a.epoch, tag0 + (unsigned)a.n_layer);   // every workgroup read the epoch before its first publish, which this one has seen
 }
