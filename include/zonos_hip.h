@@ -196,7 +196,8 @@ int zn_debug_prefill_mode(zn_handle h, int32_t mode);
  * graphs only; 8: 2 = per-op launches instead of the persistent kernels (also ZN_CHAIN=0 at zn_create), 1 = back to the default and
  * re-arm a handle demoted by a hand-off timeout; 15: 2 = one chain launch per block instead of the whole-step kernel at batch 1; 16: 2 = the ticketed sampler launch instead of the one-workgroup step tail at batch 1 (the default for greedy decoding), 3 = the one-workgroup tail also with a temperature.  Every path gives bit-identical
  * results.  14: one-shot test hooks for the next generation (7: hand-off tags about to wrap; 9: the timeout word found set; 11: every
- * whole-step launch stops all its waves for 30 ms in block 2, as a paused device would).  Keys 0 .. 19. */
+ * whole-step launch stops all its waves for 30 ms in block 2, as a paused device would; 13: forget the wait statistics of zn_get_counters
+ * [6], [7] now).  Keys 0 .. 19. */
 int zn_debug_tune(zn_handle h, int32_t key, int32_t value);
 /* Diagnostic: workgroup 0 of every persistent chain launch records s_memrealtime (100 MHz) stamps of its phases into
  * stamps_dev [2 * n_layer][32] (NULL = off); rows n_layer.. hold the fused attention launch's (start, length known, scores

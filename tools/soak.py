@@ -38,6 +38,7 @@ def long_one(kind):
     assert same_ and p == 2, "soak failed (long generation)"
 
 
+pauses = []
 for i in range(n):
     torch.cuda.synchronize()
     ta = time.perf_counter()
@@ -45,6 +46,12 @@ for i in range(n):
     torch.cuda.synchronize()
     dt = time.perf_counter() - ta
     worst = max(worst, dt)
+    c = eng.counters()
+    if c["longest_wait_us"] > 0:                # a wait beyond 0.1 ms inside this generation: a pause of the device, observed from inside the kernel
+        pauses.append((round(ta - t0, 2), i, c["longest_wait_us"], c["waits_over_200us"], round(dt * 1e3, 1)))
+        print(f"  generation {i} at t = {ta - t0:.2f} s: longest in-kernel hand-off wait {c['longest_wait_us']} us ({c['waits_over_200us']} waits beyond 0.2 ms), "
+              f"the generation took {dt * 1e3:.1f} ms", flush=True)
+        eng.call("zn_debug_tune", 14, 13)
     path = eng.lib.zn_decode_path_detail(eng.h)
     if ref is None:
         ref = out.clone()
@@ -56,5 +63,8 @@ for i in range(n):
         long_one("30s" if (i // 10) % 2 == 0 else "prefix")
 hand_offs = n * 869 * 26 * 6
 print(f"counters: {eng.counters()}")
+print(f"pauses observed (t [s], generation, longest wait [us], long waits, generation [ms]): {pauses}")
+if len(pauses) > 1:
+    print("  intervals between them [s]:", [round(b[0] - a[0], 2) for a, b in zip(pauses[:-1], pauses[1:])])
 assert eng.counters()["handoff_timeouts"] == 0
 print(f"{n} generations ({hand_offs / 1e6:.1f} M in-kernel hand-offs, the long ones not counted) in {time.perf_counter() - t0:.1f} s, slowest {worst * 1e3:.1f} ms: all identical, no wait gave up")

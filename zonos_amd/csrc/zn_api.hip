@@ -1516,6 +1516,10 @@ extern "C" int zn_debug_token_override(zn_handle h, const int32_t* tokens_dev, i
 }
 extern "C" int zn_debug_tune(zn_handle h, int32_t key, int32_t value) {
   if (!h || key < 0 || key >= 20 || value < 1) return ZN_ERR_ARG;
+  if (key == 14 && value == 13) {                        // observation hook: forget the wait statistics (zn_get_counters [6], [7]) gathered so far
+    if (h->ch_diag) { (void)hipDeviceSynchronize(); (void)hipMemset(h->ch_diag + 8, 0, 2 * sizeof(unsigned)); }
+    return ZN_OK;
+  }
   h->tune[key] = value; free_graph(h); h->emb_valid = false;
   if (key == 8 && value == 1 && h->demoted) { h->demoted = false; h->clean_since_demotion = 0; h->n_rearms++; }
   return ZN_OK;
