@@ -60,7 +60,15 @@ def test_transformer_backbone_forward_like_the_reference_loop(S0):
 def test_hybrid_backbone_forward_like_the_reference_loop(form):
     """The hybrid stack through the seam, for every attention / norm form the configuration can ask for: round 1's
     (interleaved rotary, no bias), the Zonos-v0.1-hybrid checkpoint's (half-split rotary, no bias), mamba_ssm's defaults (no
-    rotary, biases), interleaved rotary with biases, and rms_norm + residual_in_fp32."""
+    rotary, biases), interleaved rotary with biases, and rms_norm + residual_in_fp32.
+
+    What the bit-equal fraction of an S = 1 call means here: the stack's 512 outputs are either ALL bit-equal to the restatement's
+    (no bf16 value anywhere upstream fell on the other side of a rounding boundary: forms round1, rms+fp32-residual, most calls
+    of interleaved+bias) or 4 - 18 % of them differ by one bf16 ulp (ONE flipped value - a GEMV output, 2e-4 per output by summation
+    order - perturbs every output of the next contraction): 0.82 - 0.96 for library-defaults and checkpoint since the prefill's SSM
+    state is carried in fp32 (round 3: other intermediate values, other near-ties; before that change these seeds happened to have
+    none).  The error bound is the assertion that matters (measured <= 0.0157 = one ulp at |x| in [2, 4)); the floor on the fraction
+    is the smallest measured value minus 0.05."""
     hd = 32
     extra = {"round1": {}, "checkpoint": {"attn_cfg": dict(synth.HYBRID_CKPT_ATTN)}, "library-defaults": {"attn_cfg": {"causal": True}},
              "interleaved+bias": {"attn_cfg": {"causal": True, "rotary_emb_dim": hd, "rotary_emb_interleaved": True}},
@@ -72,7 +80,7 @@ def test_hybrid_backbone_forward_like_the_reference_loop(form):
         eq = float((_bits(got) == _bits(ref)).float().mean())
         err = float((got.float() - ref.float()).abs().max())
         print(f"\n[seam hybrid {form} S={S}] bit-equal {eq:.4f}, max |d| {err:.4g}")
-        assert eq > 0.8 and err <= 0.13
+        assert eq > 0.77 and err <= 0.032
 
 
 def test_hybrid_prefill_scan_carries_the_state_in_fp32_like_the_reference_prefill():
