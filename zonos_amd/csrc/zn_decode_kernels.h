@@ -594,6 +594,19 @@ __global__ __launch_bounds__(NWV * 64) void gemm16s_kernel(GemvArgs a) {
   for (int j = 0; j < XP; ++j) xr[j] = ld16(xp[j]);
 #pragma unroll
   for (int j = 0; j < 8; ++j) wr[j] = ld_nt16(wp[j]);
+  // the residual operands of this thread's two epilogue items are requested with the first chunk: with K split over workgroups only the
+  // last arriver uses them, but there they would be one more dependent round trip behind the ticket and the read-back of the slices
+  unsigned resid_pre[2] = {0u, 0u};
+  if constexpr (EPI == EPI_RESID) {
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int item = it * NT + tid, m = item & 15, pj = item >> 4, rowA = grp * TN + 2 * pj;
+      if (m < a.nrows && rowA < a.N) {
+        const size_t o = (size_t)m * a.N + rowA;
+        resid_pre[it] = (rowA + 1 < a.N) ? *(const unsigned*)(a.resid + o) : (unsigned)a.resid[o];
+      }
+    }
+  }
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
   // one chunk in flight per thread: two or four (register sets requested further ahead) measured 1-3 % slower per step
   for (int c = 0; c < nchunks; ++c) {
@@ -672,10 +685,7 @@ __global__ __launch_bounds__(NWV * 64) void gemm16s_kernel(GemvArgs a) {
       if (rowA >= a.N) continue;
       const bool b_ok = rowB < a.N;
       unsigned resid = 0; float cs = 1.f, sn = 0.f; int pos = 0;
-      if constexpr (EPI == EPI_RESID) {
-        const size_t o = (size_t)m * a.N + rowA;
-        resid = b_ok ? *(const unsigned*)(a.resid + o) : (unsigned)a.resid[o];
-      }
+      if constexpr (EPI == EPI_RESID) resid = resid_pre[it];
       if constexpr (EPI == EPI_ROPE_KV) {
         pos = a.lengths[m];
         if (rowA < (a.n_heads + a.n_heads_kv) * a.hd) {

@@ -118,6 +118,21 @@ __global__ __launch_bounds__(256) void gemm64s_kernel(GemvArgs a) {
   for (int j = 0; j < 8; ++j) xr[j] = ld16(xp[j]);
 #pragma unroll
   for (int j = 0; j < 8; ++j) wr[j] = ld_nt16(wp[j]);
+  // (the residual operands of this thread's epilogue items travel with the first chunk, as in gemm16s_kernel: one dependent round trip
+  // less behind the split-K combine)
+  constexpr int NIT = (TN / 2) * MR / NT;
+  unsigned resid_pre[NIT];
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    resid_pre[it] = 0u;
+    if constexpr (EPI == EPI_RESID) {
+      const int item = it * NT + tid, m = item % MR, pj = item / MR, rowA = grp * TN + 2 * pj;
+      if (m < a.nrows && rowA < a.N) {
+        const size_t o = (size_t)m * a.N + rowA;
+        resid_pre[it] = (rowA + 1 < a.N) ? *(const unsigned*)(a.resid + o) : (unsigned)a.resid[o];
+      }
+    }
+  }
   f32x4 acc[RB];
 #pragma unroll
   for (int rb = 0; rb < RB; ++rb) acc[rb] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -223,11 +238,7 @@ __global__ __launch_bounds__(256) void gemm64s_kernel(GemvArgs a) {
       const int rowA = grp * TN + 2 * pj, rowB = rowA + 1;
       if (rowA >= a.N) continue;
       const bool b_ok = rowB < a.N;
-      unsigned resid = 0;
-      if constexpr (EPI == EPI_RESID) {
-        const size_t o = (size_t)m * a.N + rowA;
-        resid = b_ok ? *(const unsigned*)(a.resid + o) : (unsigned)a.resid[o];
-      }
+      const unsigned resid = resid_pre[it];
       gemv_epilogue<EPI>(a, m, rowA, rowB, b_ok, rowA >> 1, Ct[2 * pj][m], b_ok ? Ct[2 * pj + 1][m] : 0.f, resid, 1.f, 0.f, 0);
     }
   }
