@@ -90,7 +90,9 @@ static void replay(const char* name) {
 }
 
 int main() {
-  replay<2, 10, 5, 6, 3, 4, 0, 0xF, 0>("step_kernel<4,2,10,5,6> (shipped)");
+  replay<2, 10, 5, 6, 3, 4, 0, 0xF, 0>("step_kernel<4,2,10,5,6,6> (shipped: 1 - 6 key blocks)");
+  replay<2, 11, 6, 7, 3, 4, 0, 0xF, 0>("step_kernel<4,2,11,6,7,8> (shipped: 7 - 8 key blocks)");
+  replay<2, 13, 7, 8, 3, 4, 0, 0xF, 0>("step_kernel<4,2,13,7,8,12> (shipped: 9 - 12 key blocks)");
   replay<2, 10, 5, 6, 3, 4, 2, 0xF, 0>("helper waves (ZN_SK_HELP 2)");
   replay<2, 10, 5, 6, 4, 4, 0, 0xF, 0>("4 register buffers");
   replay<2, 10, 5, 6, 3, 3, 0, 0xF, 0>("3 parked tiles");
@@ -100,6 +102,6 @@ int main() {
   replay<2, 10, 5, 6, 3, 4, 0, 0xB, 0>("deferral off for fc1");
   replay<2, 10, 5, 6, 3, 4, 0, 0x0, 0>("no deferral");
   replay<2, 10, 5, 6, 2, 4, 0, 0xF, 0>("2 register buffers");
-  replay<0, 13, 7, 8, 3, 4, 0, 0xF, 0>("step3_kernel<4,13,7,8> bulk role");
+  replay<0, 13, 7, 8, 3, 4, 0, 0xF, 0>("no out_proj slots (round 3's three-role experiment, bulk role; retired)");
   return fails ? 1 : 0;
 }

@@ -5,6 +5,9 @@ Model of zonos_amd/csrc/zn_step_kernel.h: A attention workgroups and S streaming
     streaming:  sweep a(b) -> publish y1(b) -> sweep y1(b) -> publish x1(b) -> sweep x1(b) -> publish m(b) -> sweep m(b) -> publish x2(b)
                 -> sweep x2(b) -> publish q|k|v(b)
     attention:  sweep its slice of q|k|v(b - 1) (a subset of the streaming workgroups' parts) -> publish its part of a(b)
+    attention, one workgroup per key block (round 4; `kb` = (pairs, blocks per pair)):
+                sweep q|k|v(b - 1) -> publish its block maximum(b) -> sweep the maxima(b) of the pair's blocks -> publish its partial(b)
+                -> (the pair's block-0 workgroup only) sweep the partials(b) of the pair's blocks -> publish the pair's part of a(b)
 as independent sequential processes; a scheduler picks the next process at random and lets it do ONE memory action (publish its part, or
 read ONE part of the vector it is sweeping - a sweep pass is not atomic).  The hazard the kernel must never meet: a sweep that waits for
 tag t reading a part that already carries a tag NEWER than t (the data of block b overwritten by block b + 1 before it was read: a
@@ -23,9 +26,14 @@ class Hazard(Exception):
     pass
 
 
-def run(n_att, n_str, n_blocks, seed, slow=(), partial_sweep=None, att_publishes_early=False, max_actions=2_000_000):
+def run(n_att, n_str, n_blocks, seed, slow=(), partial_sweep=None, att_publishes_early=False, max_actions=2_000_000, kb=None, combiner_publishes_early=False):
     rng = random.Random(seed)
-    tags = {st: [0] * (n_att if st == "a" else n_str) for st in STAGES}          # tag of each producer's part; 0 = never written
+    n_pairs, nb = kb if kb else (n_att, 1)
+    if kb:
+        n_att = n_pairs * nb
+    tags = {st: [0] * (n_pairs if st == "a" else n_str) for st in STAGES}        # tag of each producer's part; 0 = never written
+    tags["bmax"] = [0] * n_att
+    tags["part"] = [0] * n_att
     qkv_subset = {i: [j for j in range(n_str) if j % max(1, n_att // 2) == i % max(1, n_att // 2)] or [0] for i in range(n_att)}
 
     def sweep(vec, tag, parts):
@@ -65,7 +73,27 @@ def run(n_att, n_str, n_blocks, seed, slow=(), partial_sweep=None, att_publishes
                 tags["a"][i] = b
                 yield
 
-    procs = [streaming(w) for w in range(n_str)] + [attention(i) for i in range(n_att)]
+    def attention_kb(i):
+        pair, jb = i // nb, i % nb
+        mine = [pair * nb + j for j in range(nb)]
+        for b in range(1, n_blocks + 1):
+            if b > 1:
+                yield from sweep("qkv", b - 1, qkv_subset[i])
+            tags["bmax"][i] = b
+            yield
+            yield from sweep("bmax", b, mine)
+            tags["part"][i] = b
+            yield
+            if jb == 0:
+                if combiner_publishes_early:
+                    tags["a"][pair] = b                                           # negative control: the pair's output before the partials are in
+                    yield
+                yield from sweep("part", b, mine)
+                if not combiner_publishes_early:
+                    tags["a"][pair] = b
+                    yield
+
+    procs = [streaming(w) for w in range(n_str)] + [(attention_kb(i) if kb else attention(i)) for i in range(n_att)]
     weight = [0.02 if k in slow else 1.0 for k in range(len(procs))]
     alive = list(range(len(procs)))
     actions = 0
@@ -109,6 +137,29 @@ def test_attention_publishing_before_its_sweep_would_break_it():
     for seed in range(60):
         try:
             run(4, 9, n_blocks=6, seed=seed, slow=(9, 10), att_publishes_early=True, max_actions=300_000)
+        except (Hazard, AssertionError):
+            hits += 1
+    assert hits > 0
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_key_block_attention_exchanges_are_safe_under_random_schedules(seed):
+    """Round 4's attention role: the block maxima and partials of a (row, kv head) pair travel through two more granule buffers, reused block
+    after block like the others.  They sit between a workgroup's sweep of q|k|v(b - 1) and the pair's publication of a(b): when q|k|v(b)
+    exists every streaming workgroup has swept a(b) of every pair, i.e. every pair's combiner has swept its partials(b), each of which was
+    published after its workgroup's sweep of the maxima(b) - so no workgroup can publish maxima or partials of block b + 1 over unread ones."""
+    rng = random.Random(2000 + seed)
+    pairs, nb, n_str = rng.choice([(2, 2, 3), (2, 3, 5), (4, 2, 6), (3, 4, 7)])
+    procs = pairs * nb + n_str
+    slow = tuple(rng.sample(range(procs), k=rng.choice([0, 1, 2, procs // 3])))
+    run(0, n_str, n_blocks=6, seed=seed, slow=slow, kb=(pairs, nb))
+
+
+def test_a_combiner_publishing_before_its_sweep_would_break_it():
+    hits = 0
+    for seed in range(60):
+        try:
+            run(0, 6, n_blocks=6, seed=seed, slow=(7, 9), kb=(3, 3), combiner_publishes_early=True, max_actions=300_000)
         except (Hazard, AssertionError):
             hits += 1
     assert hits > 0

@@ -23,4 +23,4 @@ def test_static_schedule_replays_without_hazards(tmp_path):
     r = subprocess.run([str(exe)], capture_output=True, text=True)
     print(r.stdout)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert "FAIL" not in r.stdout and r.stdout.count("\n") >= 11
+    assert "FAIL" not in r.stdout and r.stdout.count("\n") >= 13

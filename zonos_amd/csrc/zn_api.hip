@@ -43,7 +43,6 @@ struct zn_handle_s {
   unsigned long long *ch_gqkv = nullptr, *ch_ga = nullptr;   // whole-step kernel: q | k | v of the next block, attention output
   unsigned long long *ch_gbmax = nullptr, *ch_gpart = nullptr;   // key-block attention role: per-block score maxima and P.V partials (zn_step_kernel.h)
   int stack_nbk = 1;                         // key blocks (8 attention workgroups each) of the whole-step launches being enqueued
-  int graph_nbk[8] = {};                     // ... that a captured graph was built with
   bool stackv_ok[4] = {};                    // whole-step kernel instantiations 1 .. 3 that fit this model and device (stack_variant_ok)
   StackLayer* stack_layers = nullptr;        // device table [n_layer], rebuilt by zn_gen_begin (it holds the KV cache pointers)
   bool use_stack = false, stack_ok = false, stack_checked = false;   // use_stack: the steps being enqueued run the whole-step kernel
@@ -106,9 +105,12 @@ struct zn_handle_s {
   hipStream_t cap_stream = nullptr;
   // captured decode steps per attention launch shape (k & 1: 1 = fused single launch, 0 = two passes) and per length
   // (k >> 1: 0 = one step, 1 = ZN_GRAPH_STEPS consecutive steps: fewer graph launches on the chain)
-  hipGraphExec_t graph_exec[8] = {};
-  hipGraph_t graph[8] = {};
-  bool graph_tried[8] = {};
+  // ... and, for the whole-step kernel, per key-block count of the attention role: slots 8 + nb (one step) and 8 + 13 + nb (ZN_GRAPH_STEPS steps).
+  // A count's graph is captured once per generation and kept to its end: no graph is destroyed while launches of it may still be queued.
+#define ZN_NGRAPHS (8 + 2 * (ZN_SK_KB_MAXNB + 1))
+  hipGraphExec_t graph_exec[ZN_NGRAPHS] = {};
+  hipGraph_t graph[ZN_NGRAPHS] = {};
+  bool graph_tried[ZN_NGRAPHS] = {};
   int len_hi = 0;            // host-side upper bound of the rows' KV lengths (keys already cached)
   bool attn_fused = false;   // launch shape of the next run_attention
   std::string err;
@@ -146,7 +148,7 @@ extern "C" size_t zn_mamba_state_bytes_per_layer(const zn_config* c, int32_t row
 }
 
 static void free_graph(zn_handle h) {
-  for (int k = 0; k < 8; ++k) {
+  for (int k = 0; k < ZN_NGRAPHS; ++k) {
     if (h->graph_exec[k]) { (void)hipGraphExecDestroy(h->graph_exec[k]); h->graph_exec[k] = nullptr; }
     if (h->graph[k]) { (void)hipGraphDestroy(h->graph[k]); h->graph[k] = nullptr; }
     h->graph_tried[k] = false;
@@ -1381,16 +1383,9 @@ extern "C" int zn_decode_steps(zn_handle h, int32_t n, zn_stream stream) {
     const bool stack_run = mode_run >= 0, stack = stack_run || mode_one >= 0;
     const int mode = stack_run ? mode_run : mode_one;
     const int run = stack ? (stack_run ? ZN_GRAPH_STEPS : 1) : ((want_run && attn_fused_for(h, h->len_hi + ZN_GRAPH_STEPS) == fused) ? ZN_GRAPH_STEPS : 1);
-    const int k = stack ? (4 | (run > 1 ? 2 : 0)) : ((fused ? 1 : 0) | (run > 1 ? 2 : 0));
+    const int k = stack ? (8 + (run > 1 ? ZN_SK_KB_MAXNB + 1 : 0) + mode) : ((fused ? 1 : 0) | (run > 1 ? 2 : 0));
     h->attn_fused = fused; h->use_stack = stack;
-    if (stack) {
-      if (h->graph_nbk[k] != mode && (h->graph_exec[k] || h->graph_tried[k])) {       // the attention role changed (another 512-key block): capture anew
-        if (h->graph_exec[k]) { (void)hipGraphExecDestroy(h->graph_exec[k]); h->graph_exec[k] = nullptr; }
-        if (h->graph[k]) { (void)hipGraphDestroy(h->graph[k]); h->graph[k] = nullptr; }
-        h->graph_tried[k] = false;
-      }
-      h->stack_nbk = h->graph_nbk[k] = mode;
-    }
+    if (stack) h->stack_nbk = mode;
     if (!h->graph_exec[k] && !h->graph_tried[k] && n > 1) {
       // capture; every step-varying quantity (column, positions) is read from device memory
       h->graph_tried[k] = true;
@@ -1442,7 +1437,7 @@ extern "C" int zn_decode_path_detail(zn_handle h) {
 }
 extern "C" int zn_graph_active(zn_handle h) {
   if (!h) return 0;
-  for (int k = 0; k < 8; ++k) if (h->graph_exec[k]) return 1;
+  for (int k = 0; k < ZN_NGRAPHS; ++k) if (h->graph_exec[k]) return 1;
   return 0;
 }
 
