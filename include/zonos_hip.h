@@ -126,6 +126,8 @@ size_t zn_mamba_state_bytes_per_layer(const zn_config* cfg, int32_t rows, size_t
  * [2B, max_len, 2, Hkv, hd] bf16 = TorchZonosBackbone.allocate_inference_cache), lengths_per_sample int32[2B]
  * (device, zeroed by the caller), the delay-patterned code buffer int32 [B, n_codebooks, t_total] with -1 for
  * unknown (model.py:414-420), the first column to write `offset0` = prefix_len + 1, cfg_scale and sampling. */
+/* (zn_gen_begin discards the hipGraphs captured for the previous generation: call it only when that generation's steps have drained from
+ * their stream - `Zonos.generate` synchronises before it returns.) */
 int zn_gen_begin(zn_handle h, int32_t batch, const void* const* kv_layers_dev, int32_t max_len,
                  int32_t* lengths_dev, int32_t* delayed_codes_dev, int32_t t_total, int32_t offset0,
                  int32_t max_new_tokens, float cfg_scale, const zn_sampling* sp, zn_stream stream);

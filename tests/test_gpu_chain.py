@@ -372,3 +372,9 @@ def test_a_device_pause_inside_the_attention_wait_is_survived(capfd):
     assert "hand-off" not in err, err
     assert dt > 19 * 0.030, f"the pause hook did not run ({dt:.3f} s)"
     assert torch.equal(out, ref) and torch.equal(again, ref)
+    # ... and the pause was OBSERVED: the attention workgroups' waits contained it, the launch left the longest one in the handle's
+    # diagnostic words (zn_get_counters [6], [7]; tools/soak.py logs real pauses of the device this way)
+    c = eng.counters()
+    assert c["handoff_timeouts"] == 0 and c["longest_wait_us"] >= 29000 and c["waits_over_200us"] >= 8, c
+    eng.call("zn_debug_tune", 14, 13)
+    assert eng.counters()["longest_wait_us"] == 0
