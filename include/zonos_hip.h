@@ -196,7 +196,8 @@ int zn_debug_prefill_mode(zn_handle h, int32_t mode);
 /* Tuning hook: target workgroup count of a GEMV class (0 in_proj, 1 out_proj, 2 fc1, 3 fc2, 4 heads); 5: longest context of the
  * fused attention launch (at most 512 keys, one block: beyond, every path walks the blocks with the split pass); 6: 1 = single-step
  * graphs only; 8: 2 = per-op launches instead of the persistent kernels (also ZN_CHAIN=0 at zn_create), 1 = back to the default and
- * re-arm a handle demoted by a hand-off timeout; 15: 2 = one chain launch per block instead of the whole-step kernel at batch 1; 16: 2 = the ticketed sampler launch instead of the one-workgroup step tail at batch 1 (the default for greedy decoding), 3 = the one-workgroup tail also with a temperature.  Every path gives bit-identical
+ * re-arm a handle demoted by a hand-off timeout; 15: 2 = one chain launch per block instead of the whole-step kernel at batch 1; 18: 2 = block 0's in_proj as a launch before the
+ * whole-step kernel instead of inside it; 16: 2 = the ticketed sampler launch instead of the one-workgroup step tail at batch 1 (the default for greedy decoding), 3 = the one-workgroup tail also with a temperature.  Every path gives bit-identical
  * results.  14: one-shot test hooks for the next generation (7: hand-off tags about to wrap; 9: the timeout word found set; 11: every
  * whole-step launch stops all its waves for 30 ms in block 2, as a paused device would; 13: forget the wait statistics of zn_get_counters
  * [6], [7] now).  Keys 0 .. 19. */
@@ -231,7 +232,8 @@ int zn_op_backbone_forward(zn_handle h, const void* hidden_dev, void* out_dev, c
  * (out_proj twice, LayerNorm+fc1+SiLU-gate, fc2, next block's LayerNorm+in_proj+RoPE+KV-append in ONE launch: batch 1 only;
  * bytes = those four weight matrices, out_proj counted once), 6 = the whole-step kernel (every block of a decode step and the heads in
  * ONE launch, batch 1 only) on scratch KV caches of its own holding `ctx` keys per row; bytes = every weight the step reads once
- * (in_proj of block 0 excluded: it is a launch of its own) + K/V of ctx keys read and one row written per layer.
+ * (in_proj of block 0 included: the launch's pre-block; excluded under zn_debug_tune(18, 2), where it is a launch of its own) + K/V of
+ * ctx keys read and one row written per layer.
  * rows: bits 0-7 = activation rows; bit 8 = keep streaming layer 0's weights (cache-hot variant); bits 16-30 = ctx for which == 6
  * (0 = 450, the mean context of a 10 s utterance). */
 int zn_bench_kernel(zn_handle h, int32_t which, int32_t rows, int32_t iters, float* ms_per_launch,

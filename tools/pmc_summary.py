@@ -38,7 +38,7 @@ def kernel_summary(fetch_dir, write_dir, out, which=5):
     if which == 6:
         want, drop = "step_kernel<4, 2, 10, 5, 6, 6>", 8
         d, F, nqkv, nl, kvpos = 2048, 8192, 3072, 26, 2 * 512 * 2
-        alg = int(nl * (d * d + 3 * F * d) * 2 + (nl - 1) * nqkv * d * 2 + 9 * 1025 * d * 2 + 2 * nl * kvpos * STEP_KERNEL_CTX + 2 * (nl - 1) * kvpos)
+        alg = int(nl * (d * d + 3 * F * d) * 2 + nl * nqkv * d * 2 + 9 * 1025 * d * 2 + 2 * nl * kvpos * STEP_KERNEL_CTX + 2 * nl * kvpos)      # (in_proj of block 0 inside the launch since the pre-block)
         what = f"whole decode step at {STEP_KERNEL_CTX} keys of context: 26 x (attention, out_proj x2, LayerNorm+fc1+SiLU-gate, fc2, next LayerNorm+in_proj+RoPE+KV append), norm_f + heads"
     else:
         want, drop = "chain_kernel<4, 1, 8, 4, 2>", 8

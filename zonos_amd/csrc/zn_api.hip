@@ -681,6 +681,7 @@ static bool stack_variant_ok(zn_handle h, int natt) {
   const int nqkv = (c.n_heads + 2 * c.n_heads_kv) * h->hd;
   const int p_out = most(c.d_model / 2), p_fc1 = 2 * most(c.d_ff / 2), p_qkv = most((nqkv + 1) / 2), p_hd = most((c.n_codebooks * c.vocab_head + 1) / 2);
   if (p_out > ZN_SK_CW * T_OUT || p_out > T_FC2 || p_fc1 > ZN_SK_CW * T_FC1 || p_qkv > ZN_SK_CW * T_IN || p_hd > ZN_SK_CW * T_IN) return false;   // the static schedule
+  if (p_qkv > 10) return false;                                                                                                   // the pre-block: five row pairs per helper wave
   if (p_out * 2 > 64 || p_out * 4 > 64 || p_fc1 > 64 || p_qkv * 2 > 64 || p_hd * 2 > 64 || nqkv % 2) return false;              // one epilogue lane per (unit, row); s_res slots
   // every workgroup of the grid must be resident at once (the hand-offs wait on all of them): one per CU by its LDS, no scratch
   const void* fn = (const void*)step_kernel<NCH, T_OUT, T_FC1, T_FC2, T_IN, NBV>;
@@ -710,6 +711,7 @@ static int stack_mode_for(zn_handle h, int rows, int keys_upper_bound) {
   if (nb > ZN_SK_KB_MAXNB) return -1;
   return h->stackv_ok[stack_variant_of(nb)] ? nb : -1;
 }
+static bool stack_pre(zn_handle h) { return h->tune[18] != 2; }
 static int launch_stack(zn_handle h, hipStream_t s) {
   const zn_config& c = h->cfg;
   ChainArgs a{};
@@ -726,6 +728,10 @@ static int launch_stack(zn_handle h, hipStream_t s) {
   a.heads_rows = c.n_codebooks * c.vocab_head; a.heads_out = h->logits_raw; a.trace = h->dbg_trace;
   const int mode = h->stack_nbk, npairs = 2 * c.n_heads_kv;
   a.natt = npairs * (mode < 1 ? 1 : mode);
+  if (stack_pre(h)) {       // block 0's LayerNorm + in_proj + RoPE + KV append inside the launch (zn_debug_tune(18, 2): as a launch before it)
+    a.pre_W = (const bf16_t*)h->layers[0].in_proj; a.pre_ln_w = (const bf16_t*)h->layers[0].norm_w; a.pre_ln_b = (const bf16_t*)h->layers[0].norm_b;
+    a.pre_kv = (bf16_t*)h->kv_layers[0];
+  }
   const dim3 grid(ZN_CH_GRID), block(ZN_SK_THREADS);
   switch (stack_variant_of(mode)) {
     case 1: hipLaunchKernelGGL((step_kernel<ZN_SK_T1>), grid, block, ZN_SK_DYN_LDS, s, a); break;
@@ -964,8 +970,8 @@ static int enqueue_step(zn_handle h, hipStream_t s) {
     if ((rc = hybrid_token(h, true, s))) return rc;
   } else {
     bool heads_done = false;
-    if (h->use_stack) {                                    // in_proj of block 0, then every block + the heads in one launch
-      if ((rc = layer_in_proj(h, 0, h->x_emb, (bf16_t*)h->kv_layers[0], h->max_len, h->lengths, h->rows, s))) return rc;
+    if (h->use_stack) {                                    // every block + the heads in one launch (in_proj of block 0 inside it, or as a launch before it)
+      if (!stack_pre(h) && (rc = layer_in_proj(h, 0, h->x_emb, (bf16_t*)h->kv_layers[0], h->max_len, h->lengths, h->rows, s))) return rc;
       if ((rc = launch_stack(h, s))) return rc;
       heads_done = true;
     } else if ((rc = decode_blocks(h, nullptr, 0, s, fused ? h->x_emb : nullptr, &heads_done))) return rc;
@@ -1644,10 +1650,11 @@ extern "C" int zn_bench_kernel(zn_handle h, int32_t which, int32_t rows, int32_t
   const double wbytes = which == 5 ? ((double)d * nq + 3.0 * c.d_ff * d + (double)(nq + 2 * nkv) * d) * 2 : which == 0 ? 2.0 * c.d_ff * d * 2 : which == 1 ? (double)d * c.d_ff * 2 : which == 2 ? (double)d * c.n_heads * h->hd * 2
                         : which == 4 ? (double)(nq + 2 * nkv) * d * 2 : (double)c.n_codebooks * c.vocab_head * d * 2;
   *bytes_per_launch = wbytes;   // algorithmic bytes = the weight matrix, read once (activations are KBs)
-  if (which == 6) {             // every block's out_proj (once), fc1, fc2; the in_proj of blocks 1 .. n-1; the heads; K and V of `ctx` keys read, one row written
+  if (which == 6) {             // every block's out_proj (once), fc1, fc2, in_proj; the heads; K and V of `ctx` keys read, one row written
     const double per_block = ((double)d * nq + 3.0 * c.d_ff * d) * 2, inp = (double)(nq + 2 * nkv) * d * 2, kvpos = 2.0 * nkv * 2;
-    *bytes_per_launch = c.n_layer * per_block + (c.n_layer - 1) * inp + (double)c.n_codebooks * c.vocab_head * d * 2 +
-                        (double)rows * c.n_layer * kvpos * ctx + (double)rows * (c.n_layer - 1) * kvpos;
+    const int nin = stack_pre(h) ? c.n_layer : c.n_layer - 1;      // in_proj of block 0 inside the launch (the pre-block) or before it
+    *bytes_per_launch = c.n_layer * per_block + nin * inp + (double)c.n_codebooks * c.vocab_head * d * 2 +
+                        (double)rows * c.n_layer * kvpos * ctx + (double)rows * nin * kvpos;
   }
   return ZN_OK;
 }

@@ -84,6 +84,10 @@ struct ChainArgs {
   int natt;                                                // attention workgroups at the front of the grid (legacy role: rows * kv heads * hd / 32)
   unsigned long long* g_bmax;                              // granules {tag, fp32 bits} [rows * kv heads][ZN_SK_KB_MAXNB][4]: per-block score maxima of the pair's 4 heads
   unsigned long long* g_part;                              // granules [rows * kv heads][ZN_SK_KB_MAXNB][ZN_SK_KB_PSZ]: per-block unnormalised P.V [4][128] and e sums [4]
+  // ---- whole-step kernel, pre-block: LayerNorm + in_proj + RoPE + KV append of block 0 inside the launch (pre_W == NULL: a launch before it
+  // has left q in q0 and the new row in block 0's cache)
+  const bf16_t *pre_W, *pre_ln_w, *pre_ln_b;               // block 0's in_proj and norm
+  bf16_t* pre_kv;                                          // block 0's KV cache
 };
 struct StackLayer {
   const bf16_t *W_out, *W_fc1, *W_fc2, *W_in;              // W_in = NEXT block's in_proj, or the heads matrix (last block)

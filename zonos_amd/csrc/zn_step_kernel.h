@@ -247,7 +247,7 @@ ZN_DEVINL void step_attention_kb_role(const ChainArgs& a, StepKbLds& S, const un
   StepPacer pace{0ull, 0u};
 #pragma unroll 1
   for (int li = 0; li < a.n_layer; ++li) {
-    const unsigned tag = tag0 + (unsigned)li;
+    const unsigned tag = tag0 + 1u + (unsigned)li;           // (tag0 itself: the pre-block's q | k | v)
     if (a.dbg_pause && li == 3) step_debug_pause(a.dbg_pause);     // (inside the measured wait for block 3's q | k | v)
     const bool st_on = stamped && li == a.stamp_layer;
     auto stamp = [&](int i) { if (st_on) a.stamps[32 + i] = __builtin_amdgcn_s_memrealtime(); };
@@ -259,7 +259,7 @@ ZN_DEVINL void step_attention_kb_role(const ChainArgs& a, StepKbLds& S, const un
     // ---- q (4 heads) and, in the newest block's workgroup, this step's key and value row of the kv head -> LDS
     if (wave == ZN_SK_CW || (wave == ZN_SK_CW + 1 && has_newest)) {
       const bool first = wave == ZN_SK_CW;
-      if (li == 0) {                                         // from the in_proj launch before this one: plain loads
+      if (li == 0 && !a.pre_W) {                             // from the in_proj launch before this one: plain loads
         if (first) *(u32x4*)&S.q[lane >> 4][(lane & 15) * 8] = ld16(a.q0 + ((size_t)ar * a.n_heads + kvh * G + (lane >> 4)) * HD + (lane & 15) * 8);
         else if (lane < 32) {
           const bf16_t* rowp = a.layers[0].kv + ((size_t)ar * a.max_len + (L - 1)) * kvrow + (size_t)(lane < 16 ? 0 : nk) + (size_t)kvh * HD + (lane & 15) * 8;
@@ -480,6 +480,16 @@ __global__ __launch_bounds__(ZN_SK_THREADS) void step_kernel(ChainArgs a_in) {
   split((a.nqkv + 1) / 2, n_qkv, s_qkv);
   split((a.heads_rows + 1) / 2, n_hd, s_hd);
   constexpr int NBAR = 14;                                    // workgroup barriers per block (every wave of a streaming workgroup runs them all)
+  // ---- pre-block (a.pre_W): LayerNorm + in_proj + RoPE + KV append of block 0 from the step's embedding, by the waves that have nothing to
+  // do at the start of a launch - the two communication waves normalise a row each, the two helper waves hold the workgroup's <= 10 weight
+  // row pairs (requested at kernel entry) and contract them, communication wave 0 runs the epilogue and publishes q | k | v under tag0 - while
+  // the compute waves park block 0's tiles as in every block.  The four waves meet through two counters in LDS, not through workgroup
+  // barriers (the compute waves would have to join those).  Same arithmetic as gemv_kernel<PRO_LN, EPI_ROPE_KV> / the op-4 path of a block.
+  __shared__ int s_pf[2];                                                   // [0] rows normalised (2), [1] helper waves done (2)
+  constexpr int NPT = 5;                                                    // pre-block row pairs per helper wave (host-checked: <= 10 per workgroup)
+  const bool pre = a.pre_W != nullptr;
+  if (tid < 2) s_pf[tid] = 0;
+  __syncthreads();
 
   using SC = StepSched<T_OUT, T_FC1, T_FC2, T_IN, NB, P, ZN_SK_HELP, MASK, ZN_SK_EARLY>;
   auto op_of = [](int s) constexpr { return SC::op_of(s); };
@@ -524,6 +534,45 @@ __global__ __launch_bounds__(ZN_SK_THREADS) void step_kernel(ChainArgs a_in) {
     // ------------------------------------------------------------------------------------ helper waves
     const int hw = wave - (CW + 2);                           // serves compute waves 2 hw and 2 hw + 1
     WT hb[2 * (NH > 0 ? NH : 1)];
+    if (pre) {
+      WT pt[NPT];
+#pragma unroll
+      for (int t = 0; t < NPT; ++t) {
+        const int j = hw + 2 * t;
+        if (j < n_qkv) {                                      // wave-uniform
+          const int u = s_qkv + j;
+          const bf16_t* pa = a.pre_W + (size_t)(2 * u) * D + lane * 8;
+          const bf16_t* pb = (2 * u + 1 < a.nqkv) ? pa + D : pa;
+#pragma unroll
+          for (int c2 = 0; c2 < NCH; ++c2) { pt[t].a[c2] = ld_nt16(pa + c2 * 512); pt[t].b[c2] = ld_nt16(pb + c2 * 512); }
+        }
+      }
+      while (__hip_atomic_load(&s_pf[0], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < R) __builtin_amdgcn_s_sleep(1);
+      u32x4 xr[NCH][R];
+#pragma unroll
+      for (int c2 = 0; c2 < NCH; ++c2)
+#pragma unroll
+        for (int r = 0; r < R; ++r) xr[c2][r] = *(const u32x4*)&s_act[r * D + (c2 * 64 + lane) * 8];
+#pragma unroll
+      for (int t = 0; t < NPT; ++t) {
+        const int j = hw + 2 * t;
+        if (j < n_qkv) {
+          float accA[R] = {0.f, 0.f}, accB[R] = {0.f, 0.f};
+#pragma unroll
+          for (int c2 = 0; c2 < NCH; ++c2) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) { accA[r] = dot8(pt[t].a[c2], xr[c2][r], accA[r]); accB[r] = dot8(pt[t].b[c2], xr[c2][r], accB[r]); }
+          }
+#pragma unroll
+          for (int r = 0; r < R; ++r) { accA[r] = wave_sum(accA[r]); accB[r] = wave_sum(accB[r]); }
+          if (lane == 0) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) { s_res[0][j][0][r] = accA[r]; s_res[0][j][1][r] = accB[r]; }
+          }
+        }
+      }
+      if (lane == 0) __hip_atomic_fetch_add(&s_pf[1], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
 #pragma unroll 1
     for (int li = 0; li < a.n_layer; ++li) {
       const LW Lr{a.layers[li].W_out, a.layers[li].W_fc1, a.layers[li].W_fc2, a.layers[li].W_in};
@@ -588,7 +637,7 @@ __global__ __launch_bounds__(ZN_SK_THREADS) void step_kernel(ChainArgs a_in) {
       const bool last = li + 1 == a.n_layer;
       const int rows_in = last ? a.heads_rows : a.nqkv;
       const int n_in = last ? n_hd : n_qkv, s_in = last ? s_hd : s_qkv;
-      const unsigned tag = tag0 + (unsigned)li;
+      const unsigned tag = tag0 + 1u + (unsigned)li;
       const bool stamped = st_on && li == a.stamp_layer;
       auto cstamp = [&](int i) { if (stamped) a.stamps[40 + i] = __builtin_amdgcn_s_memrealtime(); };
       auto tile = [&](int s, bool& ok, const bf16_t*& pa, const bf16_t*& pb, int& ridx) { tile_of(Lr, rows_in, n_in, s_in, s, wave, ok, pa, pb, ridx); };
@@ -739,13 +788,44 @@ __global__ __launch_bounds__(ZN_SK_THREADS) void step_kernel(ChainArgs a_in) {
 #pragma unroll
   for (int c2 = 0; c2 < NCH; ++c2) goff[c2] = (myr * (D / 2) + (c2 * 64 + lane) * 4) * 8;
   unsigned x1own = 0;
+  if (pre) {
+    // row myr of the step's embedding (written by the previous step's tail: plain loads) -> LayerNorm of block 0 -> s_act
+    u32x4 lw[NCH], lb[NCH];
+#pragma unroll
+    for (int c2 = 0; c2 < NCH; ++c2) {
+      g[c2] = ld16(a.xin + (size_t)myr * D + (c2 * 64 + lane) * 8);
+      lw[c2] = ld16(a.pre_ln_w + (c2 * 64 + lane) * 8);
+      lb[c2] = ld16(a.pre_ln_b + (c2 * 64 + lane) * 8);
+    }
+    chain_layernorm_row<NCH>(g, lw, lb, a.eps);
+#pragma unroll
+    for (int c2 = 0; c2 < NCH; ++c2) *(u32x4*)&s_act[myr * D + (c2 * 64 + lane) * 8] = g[c2];
+    if (lane == 0) __hip_atomic_fetch_add(&s_pf[0], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    // both communication waves wait for the helper waves: s_act and s_res are theirs again only then
+    while (__hip_atomic_load(&s_pf[1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < 2) __builtin_amdgcn_s_sleep(1);
+    if (it_qkv) {                                            // EPI_ROPE_KV (gemv_epilogue) of block 0, q | k | v also as granules under tag0
+      const int rowA = 2 * u_qkv;
+      const float x0 = bfround(s_res[0][ij][0][ir]), x1 = bfround(s_res[0][ij][1][ir]);
+      unsigned packed;
+      if (rowA < nq + nk) {
+        float re, im;
+        zn_rope_pair(x0, x1, cs, sn, re, im);
+        packed = pack2(re, im);
+      } else packed = pack2(x0, x1);
+      st_granule(a.g_qkv + (size_t)ir * (a.nqkv / 2) + u_qkv, tag0, packed);
+      if (rowA >= nq && pos < a.max_len) {
+        const int which = rowA < nq + nk ? 0 : 1, colk = rowA - nq - which * nk;
+        *(unsigned*)(a.pre_kv + (((size_t)ir * a.max_len + pos) * 2 + which) * nk + colk) = packed;
+      }
+    }
+  }
   StepPacer pace{0ull, 0u};
   pace.start();
 #pragma unroll 1
   for (int li = 0; li < a.n_layer; ++li) {
     const StackLayer& Lr = a.layers[li];
     const bool last = li + 1 == a.n_layer;
-    const unsigned tag = tag0 + (unsigned)li;
+    const unsigned tag = tag0 + 1u + (unsigned)li;
     const bool stamped = a.stamps && li == a.stamp_layer && epi && sc == 0 && lane == 0;
     int nst = 0;
     auto stamp = [&]() { if (stamped) a.stamps[nst] = __builtin_amdgcn_s_memrealtime(); ++nst; };
@@ -844,5 +924,5 @@ __global__ __launch_bounds__(ZN_SK_THREADS) void step_kernel(ChainArgs a_in) {
     pace.start();                                          // the wait for the next block's attention output starts here
   }
   pace.report(a.diag, lane);
-  if (epi && sc == 0 && lane == 0) st_sc1_u32(a.epoch, tag0 + (unsigned)a.n_layer);   // every workgroup read the epoch before its first publish, which this one has seen
+  if (epi && sc == 0 && lane == 0) st_sc1_u32(a.epoch, tag0 + 1u + (unsigned)a.n_layer);   // every workgroup read the epoch before its first publish, which this one has seen
 }
