@@ -3,7 +3,8 @@ random rows, `steps` steps from each starting context.
 
     python tools/ctxsweep.py [steps=160] [contexts=100,300,450,...] [modes=stack,chain,launches]
 
-modes: stack = the default (whole-step kernel); chain = one chain launch per block (zn_debug_tune(15, 2)); launches = per-op launches.
+modes: stack = the default (whole-step kernel); stack-nopre = the same with block 0's in_proj as a launch before it (zn_debug_tune(18, 2));
+chain = one chain launch per block (zn_debug_tune(15, 2)); launches = per-op launches.
 Prints ms per decode step and the algorithmic HBM rate (SURVEY.md section 8d bytes at the middle context of the run)."""
 import ctypes as C
 import os
@@ -17,7 +18,7 @@ from zonos_amd.codebook_pattern import apply_delay_pattern  # noqa: E402
 from zonos_amd.model import _sampling_struct  # noqa: E402
 from zonos_amd.testing import build_model  # noqa: E402
 
-MODES = {"stack": {15: 1, 8: 1}, "chain": {15: 2, 8: 1}, "launches": {15: 1, 8: 2}}
+MODES = {"stack": {15: 1, 8: 1, 18: 1}, "stack-nopre": {15: 1, 8: 1, 18: 2}, "chain": {15: 2, 8: 1, 18: 1}, "launches": {15: 1, 8: 2, 18: 1}}
 
 
 def main():

@@ -245,6 +245,7 @@ ZN_DEVINL void step_attention_kb_role(const ChainArgs& a, StepKbLds& S, const un
   issue_kv(a.layers[0].kv, 0, lane_in);
   const __amdgpu_buffer_rsrc_t rs_bmax = zn_rsrc(a.g_bmax), rs_part = zn_rsrc(a.g_part);
   StepPacer pace{0ull, 0u};
+  pace.start();                                              // (with the pre-block the first block's q | k | v is waited for like every other's)
 #pragma unroll 1
   for (int li = 0; li < a.n_layer; ++li) {
     const unsigned tag = tag0 + 1u + (unsigned)li;           // (tag0 itself: the pre-block's q | k | v)
