@@ -63,12 +63,13 @@ def test_chain_generate_vs_oracle():
     assert worst <= 0.06
 
 
-@pytest.mark.parametrize("which", ["chain512", "full-chain", "full-step"])
+@pytest.mark.parametrize("which", ["chain512", "full-chain", "full-step", "full-step-nopre"])
 def test_chain_is_bit_identical_to_the_launches_path(which):
     """Free-running greedy generation through the persistent kernels and through the per-op launches (zn_debug_tune(8, 2)).  At the
     Zonos-v0.1-transformer dimensions every path cuts every dot product the same way (fc2's K = 8192 in four quarters): equal
     codes and bit-equal logits at every step (200 steps: 8-step graphs, the fused attention arithmetic, hand-offs replayed
-    26 x 6 x 200 times), for one chain launch per block (zn_debug_tune(15, 2)) and for the whole-step kernel (the default).  At
+    26 x 6 x 200 times), for one chain launch per block (zn_debug_tune(15, 2)), for the whole-step kernel (the default: block 0's in_proj
+    inside the launch, on the helper and communication waves) and for the whole-step kernel behind an in_proj launch (zn_debug_tune(18, 2)).  At
     d_model 512 the launches path keeps fc2's K = 2048 in one wave while the chain splits it in quarters - another summation
     order: equal codes, logits within one bf16 ulp of a hidden value."""
     cfg, seed, n = (synth.CHAIN_CFG, 55, 60) if which == "chain512" else (synth.FULL_CFG, 1234, 200)
@@ -76,6 +77,7 @@ def test_chain_is_bit_identical_to_the_launches_path(which):
     eng = model.engine(1)
     cond = synth.conditioning(seed, "cond", 2, 24, cfg["d_model"])
     eng.call("zn_debug_tune", 15, {"full-chain": 2}.get(which, 1))
+    eng.call("zn_debug_tune", 18, 2 if which == "full-step-nopre" else 1)
     try:
         a, la, pa = _run(model, cond, n, chain=True)
         b, lb, pb = _run(model, cond, n, chain=False)
@@ -96,6 +98,7 @@ def test_chain_is_bit_identical_to_the_launches_path(which):
         assert eng.counters()["handoff_timeouts"] == 0
     finally:
         eng.call("zn_debug_tune", 15, 1)
+        eng.call("zn_debug_tune", 18, 1)
 
 
 def test_whole_step_kernel_is_bit_identical_to_the_chain_path():
