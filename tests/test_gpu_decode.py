@@ -517,9 +517,9 @@ def test_config5_long_prefix_prefill_vs_reference(golden_dir, full):
 def test_config5_longform_generation_properties(full):
     """BASELINE config 5 at full size (P = 2584 prefix codes + 2584 new tokens, context 5.2 k, EOS suppressed), through
     size-independent properties: shape / range, run-to-run determinism, the prefix is returned unchanged, causality (a
-    run with fewer new tokens reproduces the long run's frames), and the two long-context attention launch shapes
-    (per-block split P.V pass vs one workgroup per value slice) give logits within the full-dims bar of each other
-    under one token stream."""
+    run with fewer new tokens reproduces the long run's frames), and the whole-step kernel (attention workgroups per key block,
+    6 blocks here) and the per-op launches (scores launch + per-block P.V launch) give the SAME logits under one token stream
+    (one attention arithmetic on every path since round 4)."""
     model, _ = full
     eng = model.engine(1)
     P, N = 2584, 2584
@@ -536,18 +536,18 @@ def test_config5_longform_generation_properties(full):
     assert torch.equal(a[..., :P], pre.to(torch.int64))
     assert torch.equal(a, b)
     assert tuple(short.shape) == (1, 9, P + 200) and torch.equal(a[..., :P + 192], short[..., :P + 192])
-    # split P.V pass (capacity > 1408, the default for this context) vs the unsplit two-pass shape, same token stream
+    # whole-step kernel vs the per-op launches, same token stream
     toks = synth.randint(5, "c5.stream", (80, 1, 9), 1024).astype(np.int32)      # covers all 1 + 64 + 8 sampling calls
     out1, l1 = _override_generate(model, cond.cpu(), toks, 64, 1, prefix=pre)
-    eng.call("zn_debug_tune", 9, 1 << 20)                      # never split
+    eng.call("zn_debug_tune", 8, 2)                            # per-op launches
     try:
         out2, l2 = _override_generate(model, cond.cpu(), toks, 64, 1, prefix=pre)
     finally:
-        eng.call("zn_debug_tune", 9, 1408)
+        eng.call("zn_debug_tune", 8, 1)
     assert torch.equal(out1, out2)
     d = max(float(np.abs(np.where(np.isfinite(x), x - y, 0.0)).max()) for x, y in zip(l1, l2))
-    print(f"\n[config 5] split vs unsplit P.V pass over 73 calls at context 2.6 k: max |dlogit| {d:.4g}")
-    assert d <= 0.1
+    print(f"\n[config 5] whole-step kernel vs per-op launches over 73 calls at context 2.6 k: max |dlogit| {d:.4g}")
+    assert d == 0.0
 
 
 def test_rope_table_limit_full_dims_properties(full):

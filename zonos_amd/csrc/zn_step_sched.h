@@ -1,4 +1,4 @@
-// Plain C++ (no HIP): shared by the kernels (zn_step_kernel.h, zn_step3_kernel.h) and by the host-side schedule check
+// Plain C++ (no HIP): shared by the kernel (zn_step_kernel.h) and by the host-side schedule check
 // (tests/test_step_schedule.py compiles tests/step_schedule_check.cpp with g++ and replays the schedule on the CPU).
 #pragma once
 
