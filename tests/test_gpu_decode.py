@@ -966,6 +966,41 @@ def test_small_m_projections_match_the_gemv_path(full):
         assert md <= 2.0 ** -5 * max(1.0, yb.float().abs().max().item())
 
 
+@pytest.mark.parametrize("R", [16, 10, 5])
+def test_fc1_layernorm_from_handed_over_statistics(full, R):
+    """Rows 5..16: fc1's nn.LayerNorm (_torch.py:325, `norm2`) is not a launch - the second out_proj's epilogue leaves {sum, centred second
+    moment} per row and 16-column tile, fc1 adds the tiles in a fixed order and normalises its activation chunks while staging them
+    (gemm16s_kernel<EPI_SILU, ., true>).  Against the same block with layernorm_kernel in between (zn_debug_tune(9, 2)): the statistics are
+    the same numbers summed in another order (tile-wise instead of lane-wise), so the normalised rows may differ by a bf16 ulp here and
+    there; block output bit-equal > 0.98 and within 2^-6 of its scale, new K/V (produced before the change) bit-equal; ragged row counts
+    (10, 5: clamped rows of the last group) included.  The batch-8 tests above hold the path against the oracle."""
+    model, _ = full
+    eng = model.engine(8)
+    st = _lib.stream_ptr()
+    L, max_len = 40, 64
+    x0 = synth.conditioning(98, "lnp.x", R, 1, 2048)[:, 0].contiguous()
+    x0 = (x0.float() * torch.linspace(0.5, 3.0, R)[:, None] + torch.linspace(-2.0, 2.0, R)[:, None]).to(torch.bfloat16)   # rows of different mean and scale
+    kv0 = torch.from_numpy(synth.normal(98, "lnp.kv", (R, max_len, 2, 4, 128))).to(torch.bfloat16)
+    lengths = torch.full((R,), L - 1, dtype=torch.int32, device="cuda:0")
+    outs = {}
+    try:
+        for mode in (1, 2):
+            eng.call("zn_debug_tune", 9, mode)
+            xa, kva = x0.clone().to("cuda:0"), kv0.clone().to("cuda:0")
+            for layer in (0, 11):
+                eng.call("zn_op_layer_decode", layer, xa.data_ptr(), kva.data_ptr(), max_len, lengths.data_ptr(), None, R, st)
+            torch.cuda.synchronize()
+            outs[mode] = (xa.cpu(), kva[:, L - 1].cpu())
+    finally:
+        eng.call("zn_debug_tune", 9, 1)
+    ya, yb = outs[1][0], outs[2][0]
+    assert torch.isfinite(ya.float()).all()
+    eq = float((ya.view(torch.int16) == yb.view(torch.int16)).float().mean())
+    md = (ya.float() - yb.float()).abs().max().item()
+    print(f"\n[fc1 LayerNorm from handed-over statistics vs the launch, {R} rows, two blocks] output bit-equal {eq:.5f}, max|diff| {md:.4g} (scale {yb.float().abs().max().item():.3g})")
+    assert eq > 0.98 and md <= 2.0 ** -6 * max(1.0, yb.float().abs().max().item())
+
+
 @pytest.mark.parametrize("rows", [5, 8, 13, 16])
 def test_small_m_linear_shapes_vs_fp32_reference(tiny, rows):
     """zn_op_linear at 5..16 activation rows (the LDS-staged MFMA kernel: 32/64-row workgroups, K split over workgroups

@@ -70,6 +70,7 @@ struct zn_handle_s {
   float* g16_part = nullptr;   // gemm16s_kernel: split-K partial tiles
   int* g16_tickets = nullptr;
   size_t g16_part_bytes = 0;
+  float* ln_part = nullptr;    // LayerNorm statistics per (row, 16-column tile) handed from out_proj's epilogue to fc1 (rows 5..16): [max_rows][ZN_G16_LNT][2]
   float *logits_raw = nullptr, *last_logits = nullptr;
   int* tok_raw = nullptr;
   float *scores = nullptr, *cmax = nullptr;
@@ -99,7 +100,7 @@ struct zn_handle_s {
   int force_eos_step = -1;
   float eos_bias = 0.f;
   unsigned dbg_pause = 0;           // ChainArgs::dbg_pause of this generation's whole-step launches
-  int tune[20] = {256, 512, 512, 1024, 512, 512, 2, 2, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // target workgroups: in_proj, out_proj, fc1, fc2, heads; [5] longest context of the fused attention launch (<= 512); [6] > 1: multi-step graphs; [7] > 1: LDS-staged small-M projections; [8] = 2: no persistent chain kernel (five launches per block instead); [9]: unused (was: KV capacity above which the P.V pass splits per block; it now always does beyond one block); [10] = 2: VALU prefill attention; [11] = 2: no in-workgroup-split small-M kernel
+  int tune[20] = {256, 512, 512, 1024, 512, 512, 2, 2, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // target workgroups: in_proj, out_proj, fc1, fc2, heads; [5] longest context of the fused attention launch (<= 512); [6] > 1: multi-step graphs; [7] > 1: LDS-staged small-M projections; [8] = 2: no persistent chain kernel (five launches per block instead); [9] = 2: fc1's LayerNorm as a launch of its own at 5..16 rows (default: statistics from out_proj's epilogue); [10] = 2: VALU prefill attention; [11] = 2: no in-workgroup-split small-M kernel
   const int* tok_override = nullptr;
   int tok_override_calls = 0;
   hipStream_t cap_stream = nullptr;
@@ -181,7 +182,7 @@ extern "C" int zn_destroy(zn_handle h) {
   if (!h) return ZN_OK;
   (void)zn_tenant_release(h->device, h);
   free_graph(h);
-  void* ptrs[] = {h->emb_tables_dev, h->x, h->q, h->o1, h->mbuf, h->nbuf, h->logits_raw, h->last_logits, h->tok_raw, h->scores, h->cmax, h->pv_part, h->pv_tickets, h->pf_x, h->pf_n, h->pf_qkv, h->pf_a, h->pf_u, h->pf_m, h->pf_res, h->pf_zx, h->pf_xbc, h->pf_y, h->pf_g, h->qkv_tmp, h->fw_lengths, h->st, h->remaining, h->stopping, h->res, h->hn, h->m_zx, h->m_xbc, h->m_y, h->m_g, h->m_vg, h->g16_part, h->g16_tickets, h->ch_gy1, h->ch_gx1, h->ch_gx2, h->ch_gm, h->ch_epoch, h->ch_x2, h->x_emb, h->tail_ticket, h->ch_gqkv, h->ch_ga, h->ch_gbmax, h->ch_gpart, h->stack_layers, h->ch_diag};
+  void* ptrs[] = {h->emb_tables_dev, h->x, h->q, h->o1, h->mbuf, h->nbuf, h->logits_raw, h->last_logits, h->tok_raw, h->scores, h->cmax, h->pv_part, h->pv_tickets, h->pf_x, h->pf_n, h->pf_qkv, h->pf_a, h->pf_u, h->pf_m, h->pf_res, h->pf_zx, h->pf_xbc, h->pf_y, h->pf_g, h->qkv_tmp, h->fw_lengths, h->st, h->remaining, h->stopping, h->res, h->hn, h->m_zx, h->m_xbc, h->m_y, h->m_g, h->m_vg, h->g16_part, h->g16_tickets, h->ln_part, h->ch_gy1, h->ch_gx1, h->ch_gx2, h->ch_gm, h->ch_epoch, h->ch_x2, h->x_emb, h->tail_ticket, h->ch_gqkv, h->ch_ga, h->ch_gbmax, h->ch_gpart, h->stack_layers, h->ch_diag};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (h->done_host) (void)hipHostFree(h->done_host);
   if (h->stop_event) (void)hipEventDestroy(h->stop_event);
@@ -304,6 +305,7 @@ extern "C" int zn_create(const zn_config* cfg, const zn_weights* w, int32_t max_
     ZC(hipMalloc(&h->g16_tickets, ZN_G16_MAX_GROUPS * sizeof(int)));
     ZC(hipMemset(h->g16_tickets, 0, ZN_G16_MAX_GROUPS * sizeof(int)));
     h->g16_part_bytes = ZN_G16_PART_BYTES;
+    ZC(hipMalloc(&h->ln_part, R * ZN_G16_LNT * 2 * sizeof(float)));
   }
   if (c.arch == 1) {
     ZC(hipMalloc(&h->res, R * c.d_model * 4));     // bf16, or fp32 with residual_in_fp32
@@ -355,10 +357,11 @@ static int launch_gemv_rows(const GemvArgs& a, int rgroup, int ks, int nch, int 
 // launch here (amortised over the batch).
 // rows in (4, 16], K a multiple of 256: the LDS-staged kernel (coalesced weight stream); K is split over workgroups until
 // the grid has >= 512 of them, the partial tiles meet in a scratch buffer (allocated by zn_create when max_rows > 4).
-template <int EPI>
+template <int EPI, bool LNP = false>
 static bool run_gemm16s(zn_handle h, GemvArgs g, hipStream_t s) {
   const int K = g.K;
   if (K % ZN_G16_KC || !h->g16_part) return false;
+  if (LNP && (K != 16 * ZN_G16_LNT || !g.ln_part_in)) return false;
   const int nrows_w = (EPI == EPI_SILU) ? g.N / 2 : g.N;          // weight rows that define the grid
   const int per64 = (EPI == EPI_SILU) ? 32 : 64;
   // 64-row workgroups when that already gives >= 512 of them, else 32-row ones, else split K as well
@@ -367,6 +370,7 @@ static bool run_gemm16s(zn_handle h, GemvArgs g, hipStream_t s) {
   if (groups > ZN_G16_MAX_GROUPS) return false;
   int ks = 1;
   while (groups * ks < 448 && ks < 16 && K % (2 * ks * ZN_G16_KC) == 0) ks *= 2;
+  // (fc2 at 16 rows, K = 8192 over 64 groups: 8 slices; 4: 1.690, 8: 1.681, 16: 1.746 ms per batch-8 step)
   if (ks > 1 && K / ks < 512) {
     // short slices: the combine costs more than the direct-fragment kernel's access pattern, unless a shallower split
     // still fills the chip (in_proj, N = 3072: 96 groups x 4 slices of 512)
@@ -375,8 +379,8 @@ static bool run_gemm16s(zn_handle h, GemvArgs g, hipStream_t s) {
   }
   if ((size_t)ks * 16 * groups * nwv * 16 * sizeof(float) > h->g16_part_bytes) return false;
   g.part = h->g16_part; g.tickets = h->g16_tickets; g.ksplit = ks;
-  if (nwv == 4) hipLaunchKernelGGL((gemm16s_kernel<EPI, 4>), dim3(groups, ks), dim3(256), 0, s, g);
-  else hipLaunchKernelGGL((gemm16s_kernel<EPI, 2>), dim3(groups, ks), dim3(128), 0, s, g);
+  if (nwv == 4) hipLaunchKernelGGL((gemm16s_kernel<EPI, 4, LNP>), dim3(groups, ks), dim3(256), 0, s, g);
+  else hipLaunchKernelGGL((gemm16s_kernel<EPI, 2, LNP>), dim3(groups, ks), dim3(128), 0, s, g);
   return true;
 }
 
@@ -419,6 +423,15 @@ static int run_gemm16(zn_handle h, GemvArgs a, int rows, hipStream_t s) {
     // that kernel normalises its rows itself when at most one workgroup per CU repeats the statistics (in_proj: 8.7 us vs
     // 4.8 + 6.2; the heads' 577 tiles: 21.8 vs 5.0 + 11.9)
     const bool k16_ln = k16 && PRO == PRO_LN && tiles <= 256 && K == 2 * ZN_G16K_NKW * ZN_G16K_KCH;
+    if constexpr (PRO == PRO_LN && EPI == EPI_SILU) {
+      // the producer of these rows left LayerNorm statistics per 16-column tile (layer_post_attention): fc1 normalises while it stages
+      if (a.ln_part_in && !k16 && h->tune[7] > 1) {
+        GemvArgs gl = a;
+        gl.nrows = nr; gl.x = a.x + (size_t)r0 * K; gl.ln_part_in = a.ln_part_in + (size_t)r0 * ZN_G16_LNT * 2;
+        if (gl.out) gl.out += (size_t)r0 * (a.N / 2);
+        if (run_gemm16s<EPI, true>(h, gl, s)) continue;
+      }
+    }
     if (PRO == PRO_LN && !k16_ln) {
       hipLaunchKernelGGL(layernorm_kernel, dim3(nr), dim3(64), 0, s, a.x + (size_t)r0 * K, a.ln_w, a.ln_b, h->nbuf, K, a.eps);
       g.x = h->nbuf;
@@ -430,6 +443,7 @@ static int run_gemm16(zn_handle h, GemvArgs a, int rows, hipStream_t s) {
     if (g.q_out) g.q_out += (size_t)r0 * a.n_heads * a.hd;
     if (g.kv) g.kv += (size_t)r0 * a.max_len * 2 * a.n_heads_kv * a.hd;
     if (g.conv_state) { g.conv_state += (size_t)r0 * a.conv_dim * 4; g.xbc += (size_t)r0 * a.conv_dim; }
+    if (g.ln_part_out) { if (k16 && EPI == EPI_RESID && a.N == 16 * ZN_G16_LNT) g.ln_part_out += (size_t)r0 * ZN_G16_LNT * 2; else g.ln_part_out = nullptr; }
     if (k16) {
       if (k16_ln) run_gemm16k<PRO, EPI>(g, s); else run_gemm16k<PRO_NONE, EPI>(g, s);
       continue;
@@ -568,6 +582,9 @@ static int layer_post_attention(zn_handle h, int li, bf16_t* x, int rows, hipStr
   const zn_layer_weights& lw = h->layers[li];
   const int d = c.d_model, nq = c.n_heads * h->hd;
   int rc;
+  // rows 5..16: the projection that completes the residual stream leaves LayerNorm statistics per 16-column tile and fc1 normalises its
+  // activation chunks from them - no LayerNorm launch in between (GemvArgs::ln_part_out).  tune[9] = 2: the launch.
+  const bool lnp = rows > 4 && h->tune[9] != 2 && h->ln_part && d == 16 * ZN_G16_LNT && gemm16k_fits(h, EPI_RESID, d, nq);
   {
     GemvArgs a{};
     a.W = (const bf16_t*)lw.out_proj; a.N = d; a.K = nq; a.x = h->o1;
@@ -576,9 +593,11 @@ static int layer_post_attention(zn_handle h, int li, bf16_t* x, int rows, hipStr
       if ((rc = run_gemv<PRO_NONE, EPI_STORE>(h, a, rows, h->tune[1], s))) return rc;
       GemvArgs b{};
       b.W = (const bf16_t*)lw.out_proj; b.N = d; b.K = nq; b.x = h->q; b.resid = x; b.out = x;
+      if (lnp) b.ln_part_out = h->ln_part;
       if ((rc = run_gemv<PRO_NONE, EPI_RESID>(h, b, rows, h->tune[1], s))) return rc;
     } else {
       a.resid = x; a.out = x;
+      if (lnp) a.ln_part_out = h->ln_part;
       if ((rc = run_gemv<PRO_NONE, EPI_RESID>(h, a, rows, h->tune[1], s))) return rc;
     }
   }
@@ -587,6 +606,7 @@ static int layer_post_attention(zn_handle h, int li, bf16_t* x, int rows, hipStr
     GemvArgs a{};
     a.W = (const bf16_t*)lw.fc1; a.N = 2 * c.d_ff; a.K = d; a.x = x;
     a.ln_w = (const bf16_t*)lw.norm2_w; a.ln_b = (const bf16_t*)lw.norm2_b; a.eps = c.norm_eps; a.out = h->mbuf;
+    if (lnp) a.ln_part_in = h->ln_part;
     if ((rc = run_gemv<PRO_LN, EPI_SILU>(h, a, rows, h->tune[2], s))) return rc;
   }
   {  // fc2 -> residual

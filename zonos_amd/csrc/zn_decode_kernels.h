@@ -47,6 +47,13 @@ struct GemvArgs {
   // gemm16k_kernel<EPI_ROPE_KV> over the rows of a short prefill (pf_S > 0): activation row m = r * pf_S + s is position pf_base + s of
   // cache row r (lengths unused); q goes to q_out [m][Hq * hd]
   int pf_S, pf_base;
+  // LayerNorm statistics handed from the producer of a residual stream to the consumer that normalises it (rows 5..16): gemm16k_kernel<EPI_RESID>
+  // leaves, per activation row and 16-column tile of its bf16 output, {sum, centred second moment about the tile's mean} (ln_part_out
+  // [rows][N / 16][2] fp32); gemm16s_kernel<EPI_SILU, ., true> (ln_part_in, ln_tiles = K / 16) adds the tiles in a fixed order - the row
+  // mean from the sums, then sum_t M2_t + 16 (mean_t - mean)^2, which is the centred second moment of the row exactly - and normalises
+  // its activation chunks while staging them, in place of a layernorm_kernel launch in between.
+  float* ln_part_out;
+  const float* ln_part_in;
 };
 
 // EPI_MAMBA operands of activation row r and the weight-row pair starting at rowA (both rows lie in the same segment:
@@ -549,7 +556,12 @@ __global__ __launch_bounds__(NW * 64) void gemm16_kernel(GemvArgs a) {
 ZN_DEVINL void st_wt(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }   // write-through
 ZN_DEVINL float ld_wt(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }   // L2-bypassing
 // NWV = waves (16-row tiles) per workgroup: 4 (64 rows) or 2 (32 rows; more, smaller workgroups for mid-size N).
-template <int EPI, int NWV>
+// LNP: the activations are a residual stream whose nn.LayerNorm has not been applied yet; its producer left per-tile statistics
+// (GemvArgs::ln_part_in, ZN_G16_LNT tiles of 16 columns per row).  The workgroup adds them in a fixed order while its first weight chunk
+// is on the way and normalises every activation chunk as it stages it (the arithmetic of layernorm_kernel on each value; the statistics
+// are summed tile-wise instead of lane-wise) - no LayerNorm launch, no normalised copy of the rows in memory.
+#define ZN_G16_LNT 128
+template <int EPI, int NWV, bool LNP = false>
 __global__ __launch_bounds__(NWV * 64) void gemm16s_kernel(GemvArgs a) {
   constexpr int KC = ZN_G16_KC, LDW = KC + 8, NT = NWV * 64, TN = NWV * 16, HALF = TN / 2;
   constexpr int XP = 512 / NT;                        // activation pieces per thread (16 rows x 32 pieces)
@@ -557,6 +569,10 @@ __global__ __launch_bounds__(NWV * 64) void gemm16s_kernel(GemvArgs a) {
   __shared__ __attribute__((aligned(16))) bf16_t Xs[16 * LDW];
   __shared__ float Ct[TN][17];
   __shared__ int s_last;
+  constexpr int LPT = LNP ? 16 * ZN_G16_LNT / NT : 1, LSEG = NT / 16, LTS = ZN_G16_LNT / LSEG;   // partials per thread; segments of a row; tiles per segment
+  __shared__ float2 s_lnp[LNP ? 16 : 1][LNP ? ZN_G16_LNT + 1 : 1];
+  __shared__ float s_lnseg[LNP ? 16 : 1][LNP ? LSEG : 1];
+  __shared__ float s_mr[LNP ? 16 : 1][2];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n = lane & 15, g = lane >> 4;
   const int grp = blockIdx.x, ys = blockIdx.y;
@@ -590,10 +606,61 @@ __global__ __launch_bounds__(NWV * 64) void gemm16s_kernel(GemvArgs a) {
     xp[j] = a.x + (size_t)(row < a.nrows ? row : a.nrows - 1) * K + kbeg + c16 * 8;
     xl[j] = row * LDW + c16 * 8;
   }
+  float2 lp[LPT];
+  u32x4 lnw = u32x4{0, 0, 0, 0}, lnb = u32x4{0, 0, 0, 0};
+  const int lnk = kbeg + (tid & 31) * 8;               // every piece of a thread sits in the same 16-byte column of the chunk (NT % 32 == 0)
+  if constexpr (LNP) {
+    // requests return in order: statistics first, then the first activation chunk and its affine parameters, then the weights
+#pragma unroll
+    for (int j = 0; j < LPT; ++j) {
+      const int idx = j * NT + tid, row = idx / ZN_G16_LNT, t = idx % ZN_G16_LNT;
+      lp[j] = *(const float2*)(a.ln_part_in + ((size_t)(row < a.nrows ? row : a.nrows - 1) * ZN_G16_LNT + t) * 2);
+    }
+  }
 #pragma unroll
   for (int j = 0; j < XP; ++j) xr[j] = ld16(xp[j]);
+  if constexpr (LNP) { lnw = ld16(a.ln_w + lnk); lnb = ld16(a.ln_b + lnk); __builtin_amdgcn_sched_barrier(0); }
 #pragma unroll
   for (int j = 0; j < 8; ++j) wr[j] = ld_nt16(wp[j]);
+  // (LNP: the statistics end later than the first weight chunk arrives - their inputs are as far away as the weights.  Requesting the second
+  // weight chunk here as well, for the loop's first iteration to take over: 1.765 vs 1.688 ms per batch-8 step - more in flight per thread is
+  // slower, as the note at the loop says.)
+  if constexpr (LNP) {
+    __builtin_amdgcn_sched_barrier(0);                 // the weight requests stay above the statistics' wait
+#pragma unroll
+    for (int j = 0; j < LPT; ++j) { const int idx = j * NT + tid; s_lnp[idx / ZN_G16_LNT][idx % ZN_G16_LNT] = lp[j]; }
+    __syncthreads();
+    const int lrow = tid & 15, lseg = tid >> 4;
+    float ssum = 0.f;
+#pragma unroll
+    for (int t = 0; t < LTS; ++t) ssum += s_lnp[lrow][lseg * LTS + t].x;
+    s_lnseg[lrow][lseg] = ssum;
+    __syncthreads();
+    float tot = 0.f;
+#pragma unroll
+    for (int q = 0; q < LSEG; ++q) tot += s_lnseg[lrow][q];
+    const float invK = 1.0f / (float)K, mean = tot * invK;
+    __syncthreads();
+    float sq = 0.f;
+#pragma unroll
+    for (int t = 0; t < LTS; ++t) {
+      const float2 pt = s_lnp[lrow][lseg * LTS + t];
+      const float dm = pt.x * 0.0625f - mean;
+      sq += pt.y + 16.0f * dm * dm;
+    }
+    s_lnseg[lrow][lseg] = sq;
+    __syncthreads();
+    if (tid < 16) {
+      float tq = 0.f;
+#pragma unroll
+      for (int q = 0; q < LSEG; ++q) tq += s_lnseg[tid][q];
+      s_mr[tid][0] = mean;
+      s_mr[tid][1] = ln_rstd(tq, invK, a.eps);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < XP; ++j) { const int row = (j * NT + tid) >> 5; xr[j] = ln_norm8(xr[j], s_mr[row][0], s_mr[row][1], lnw, lnb); }
+  }
   // the residual operands of this thread's two epilogue items are requested with the first chunk: with K split over workgroups only the
   // last arriver uses them, but there they would be one more dependent round trip behind the ticket and the read-back of the slices
   unsigned resid_pre[2] = {0u, 0u};
@@ -612,15 +679,20 @@ __global__ __launch_bounds__(NWV * 64) void gemm16s_kernel(GemvArgs a) {
   for (int c = 0; c < nchunks; ++c) {
     __syncthreads();                                   // the previous chunk's fragment reads are done
 #pragma unroll
-    for (int j = 0; j < XP; ++j) *(u32x4*)&Xs[xl[j]] = xr[j];
+    for (int j = 0; j < XP; ++j) *(u32x4*)&Xs[xl[j]] = xr[j];       // (LNP: normalised one iteration earlier, below)
 #pragma unroll
     for (int j = 0; j < 8; ++j) *(u32x4*)&Ws[wl[j]] = wr[j];
     __syncthreads();
     if (c + 1 < nchunks) {
 #pragma unroll
       for (int j = 0; j < XP; ++j) xr[j] = ld16(xp[j] + (size_t)(c + 1) * KC);
+      if constexpr (LNP) {
+        lnw = ld16(a.ln_w + lnk + (c + 1) * KC); lnb = ld16(a.ln_b + lnk + (c + 1) * KC);
+        __builtin_amdgcn_sched_barrier(0);             // requests return in order: the activations must not queue behind the weights (the scheduler interleaved them)
+      }
 #pragma unroll
       for (int j = 0; j < 8; ++j) wr[j] = ld_nt16(wp[j] + (size_t)(c + 1) * KC);
+      if constexpr (LNP) __builtin_amdgcn_sched_barrier(0);
     }
     const bf16_t* wf = &Ws[(wave * 16 + n) * LDW + 8 * g];
     const bf16_t* xf = &Xs[n * LDW + 8 * g];
@@ -629,6 +701,18 @@ __global__ __launch_bounds__(NWV * 64) void gemm16s_kernel(GemvArgs a) {
       const u32x4 bw = *(const u32x4*)(wf + 32 * st);
       const u32x4 ax = *(const u32x4*)(xf + 32 * st);
       acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(zn_bf16x8, ax), __builtin_bit_cast(zn_bf16x8, bw), acc, 0, 0, 0);
+    }
+    if constexpr (LNP) {
+      // the next chunk's activations (L2-resident, requested ahead of its weights) are normalised here, while those weights are still on
+      // their way from HBM (every workgroup repeats the normalisation of all 16 rows: 256 values per thread over the launch).  In front
+      // of the LDS writes, i.e. behind the wait for the weights: 16.3 vs 13.7 us per launch for the kernel without the normalisation, here
+      // 14.5; activations requested two chunks ahead and normalised right behind the weight requests: slower (their late requests end
+      // up in the loop head's wait).
+      if (c + 1 < nchunks) {
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < XP; ++j) { const int row = (j * NT + tid) >> 5; xr[j] = ln_norm8(xr[j], s_mr[row][0], s_mr[row][1], lnw, lnb); }
+      }
     }
   }
   // D layout: col (LDS row wave*16 + n) = lane & 15, row (activation row) = 4*(lane>>4) + reg
@@ -864,13 +948,35 @@ __global__ __launch_bounds__(ZN_G16K_NKW * 64) void gemm16k_kernel(GemvArgs a) {
 #pragma unroll
   for (int reg = 0; reg < 4; ++reg) Ct[wave][n][4 * g + reg] = acc[reg];
   __syncthreads();
-  if (!e_on) return;
   float vA = 0.f, vB = 0.f;
+  if (e_on) {
 #pragma unroll
-  for (int w = 0; w < NKW; ++w) { vA += Ct[w][2 * epj][em]; vB += Ct[w][2 * epj + 1][em]; }
-  int er = em;
-  if constexpr (EPI == EPI_ROPE_KV) { if (a.pf_S > 0) er = pf_r; }
-  gemv_epilogue<EPI>(a, er, erowA, erowB, eb_ok, erowA >> 1, vA, eb_ok ? vB : 0.f, resid, cs, sn, pos, cst, cw);
+    for (int w = 0; w < NKW; ++w) { vA += Ct[w][2 * epj][em]; vB += Ct[w][2 * epj + 1][em]; }
+    int er = em;
+    if constexpr (EPI == EPI_ROPE_KV) { if (a.pf_S > 0) er = pf_r; }
+    gemv_epilogue<EPI>(a, er, erowA, erowB, eb_ok, erowA >> 1, vA, eb_ok ? vB : 0.f, resid, cs, sn, pos, cst, cw);
+  }
+  if constexpr (EPI == EPI_RESID) {
+    // LayerNorm statistics of this tile's 16 output columns per activation row (GemvArgs::ln_part_out; the host asks for them only
+    // when N % 16 == 0): the eight column pairs of row em sit in lanes em + 16 q of waves 0 and 1.  Per wave: sum and centred second
+    // moment of its 8 values; the two halves meet in LDS (Chan's pairwise update, equal counts).
+    if (a.ln_part_out == nullptr) return;                 // uniform
+    const float oA = bfround(lo_f(resid) + bfround(vA)), oB = bfround(hi_f(resid) + bfround(vB));      // the values gemv_epilogue stored
+    float s8 = oA + oB;
+    s8 += __shfl_xor(s8, 16); s8 += __shfl_xor(s8, 32);
+    const float m8 = s8 * 0.125f;
+    float q8 = (oA - m8) * (oA - m8) + (oB - m8) * (oB - m8);
+    q8 += __shfl_xor(q8, 16); q8 += __shfl_xor(q8, 32);
+    if (wave == 1 && lane < 16) { s_red[0][0][lane] = s8; s_red[1][0][lane] = q8; }
+    __syncthreads();
+    if (wave == 0 && lane < 16 && lane < a.nrows) {
+      const float sb = s_red[0][0][lane], qb = s_red[1][0][lane], dm = (sb - s8) * 0.125f;
+      float2 o;
+      o.x = s8 + sb;
+      o.y = q8 + qb + 4.0f * dm * dm;
+      *(float2*)(a.ln_part_out + ((size_t)((int)blockIdx.y * 16 + lane) * gridDim.x + tile) * 2) = o;
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------ attention

@@ -51,8 +51,10 @@
                                                             // that sweep's first pass issued AHEAD of those requests, 1 us after the publish: 0.868 vs 0.829)
 #endif
 #ifndef ZN_SK_SWEEP_DELAY
-#define ZN_SK_SWEEP_DELAY 40                                // s_sleep units (64 cycles) between an op's publish and the first sweep pass for its output
-#endif                                                      // (two sweep passes in flight per wave, a new one every half round trip: 0.891 vs 0.869 ms per step - more polling loads the fabric)
+#define ZN_SK_SWEEP_DELAY 32                                // s_sleep units (64 cycles) between an op's publish and the first sweep pass for its output
+#endif                                                      // (two sweep passes in flight per wave, a new one every half round trip: 0.891 vs 0.869 ms per step - more polling loads the fabric).
+                                                            // With the key-block attention role, ms per step at contexts 300 / 600 / 1600 / 3800 (profiles/r04_sweep_delay.txt): 20: .852 .879
+                                                            // .902 .976; 24: .844 .866 .886 .973; 28: .834 .853 .868 .975; 32: .835 .852 .867 .980; 40: .834 .856 .875 .990; 48: .834 .862 .881 1.001
 #define ZN_SK_DYN_LDS (ZN_SK_CW * ZN_SK_PARK * 8192)        // parked tiles (streaming role) / StepKbLds (attention role)
 #ifndef ZN_SK_APOLL
 #define ZN_SK_APOLL 1                                       // sweep passes an attention workgroup keeps in flight while it waits for a hand-off.  Its CU streams nothing, and
