@@ -200,7 +200,11 @@ int zn_debug_prefill_mode(zn_handle h, int32_t mode);
  * whole-step kernel instead of inside it; 16: 2 = the ticketed sampler launch instead of the one-workgroup step tail at batch 1 (the default for greedy decoding), 3 = the one-workgroup tail also with a temperature.  Every path gives bit-identical
  * results.  14: one-shot test hooks for the next generation (7: hand-off tags about to wrap; 9: the timeout word found set; 11: every
  * whole-step launch stops all its waves for 30 ms in block 2, as a paused device would; 13: forget the wait statistics of zn_get_counters
- * [6], [7] now).  Keys 0 .. 19. */
+ * [6], [7] now).  Batches of 3 .. 8 utterances (5 .. 16 rows): 9: 2 = fc1's LayerNorm as a launch of its own (default: fc1 normalises its
+ * activation chunks from statistics the preceding out_proj's epilogue left per 16-column tile - the same nn.LayerNorm with its sums taken
+ * tile-wise, a bf16 ulp apart in about one value of a hundred); 19: value-column parts of the decode attention launches: 1 = never split,
+ * 2 = always, other = the default (5 rows and more: 4 workgroups per (row, kv head) in the one-launch shape, 2 per (row, kv head, block)
+ * beyond 512 keys; bit-identical either way).  Keys 0 .. 19. */
 int zn_debug_tune(zn_handle h, int32_t key, int32_t value);
 /* Diagnostic: workgroup 0 of every persistent chain launch records s_memrealtime (100 MHz) stamps of its phases into
  * stamps_dev [2 * n_layer][32] (NULL = off); rows n_layer.. hold the fused attention launch's (start, length known, scores

@@ -183,9 +183,9 @@ def _check_ticket_kernel(ins):
 
 
 def test_ticketed_combines_use_write_through_stores_and_sc1_loads(kernels_isa):
-    names = [n for n in kernels_isa if re.match(r"_Z14gemm16s_kernelILi\d+ELi\d+EE", n) or re.match(r"_Z17attn_block_kernelILi\d+ELi\d+ELb0EE", n)
+    names = [n for n in kernels_isa if re.match(r"_Z14gemm16s_kernelILi\d+ELi\d+ELb[01]EE", n) or re.match(r"_Z17attn_block_kernelILi\d+ELi\d+ELb0ELi\d+EE", n)
              or re.match(r"_Z14gemm64s_kernelILi\d+EE", n)]
-    assert len(names) >= 10
+    assert len(names) >= 25            # gemm16s: 5 epilogues x 2 sizes + the LayerNorm-statistics form; attn_block (split shape): head sizes x groups x column parts
     for n in names:
         _check_ticket_kernel(kernels_isa[n])
 

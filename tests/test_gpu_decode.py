@@ -261,6 +261,46 @@ def test_attention_long_context_split_pass_vs_cpu_sdpa(full):
         assert eq > 0.99, (L, eq)
 
 
+def test_attention_value_column_split_is_bit_identical(full):
+    """Batches of 3..8 utterances launch TWO workgroups per (row, kv head[, 512-key block]), each with all the scores / P of the pair and
+    half of the value columns (attn_block_kernel<..., DS = 2>; zn_debug_tune(19, 2) forces it, (19, 1) forbids it).  A column of P.V depends
+    on P and its own V column only, so the outputs must be the SAME BITS as the unsplit launches: 16 rows of ragged lengths (one block, the
+    512 / 513 boundary, several blocks, a row of one key), both launch shapes, twice each (the split shape's tickets return to zero); one
+    case against torch CPU SDPA as well, so that the common value is the right one."""
+    import torch.nn.functional as F
+    model, _ = full
+    eng = model.engine(8)
+    st = _lib.stream_ptr()
+    gen = torch.Generator().manual_seed(5)
+    R = 16
+    try:
+        for cap, lens in ((512, [1, 2, 15, 16, 17, 63, 64, 65, 100, 255, 256, 300, 449, 480, 511, 512]),
+                          (1536, [1, 30, 511, 512, 513, 514, 600, 1000, 1023, 1024, 1025, 1100, 1400, 1500, 1535, 1536])):
+            q = torch.randn(R, 16, 1, 128, generator=gen).to(torch.bfloat16)
+            kv = torch.randn(R, cap, 2, 4, 128, generator=gen).to(torch.bfloat16)
+            qd = q.transpose(1, 2).reshape(R, 2048).contiguous().to("cuda:0")
+            kvd = kv.to("cuda:0")
+            lengths = torch.tensor([l - 1 for l in lens], dtype=torch.int32, device="cuda:0")
+            outs = {}
+            for mode in (1, 2):
+                eng.call("zn_debug_tune", 19, mode)
+                out = torch.full((R, 2048), float("nan"), dtype=torch.bfloat16, device="cuda:0")
+                for rep in range(2):
+                    eng.call("zn_op_attn_decode", qd.data_ptr(), kvd.data_ptr(), cap, lengths.data_ptr(), None, out.data_ptr(), R, st)
+                torch.cuda.synchronize()
+                outs[mode] = out.cpu()
+            assert torch.isfinite(outs[2].float()).all()
+            assert torch.equal(outs[1].view(torch.int16), outs[2].view(torch.int16)), cap
+            r0 = 9
+            L = lens[r0]
+            ref = F.scaled_dot_product_attention(q[r0:r0 + 1], kv[r0:r0 + 1, :L, 0].transpose(1, 2), kv[r0:r0 + 1, :L, 1].transpose(1, 2), enable_gqa=True)[0, :, 0]
+            eq = float((outs[2][r0].view(16, 128).view(torch.int16) == ref.contiguous().view(torch.int16)).float().mean())
+            print(f"\n[attn value-column split, capacity {cap}] 16 rows bit-identical to the unsplit launches; row {r0} (L = {L}) vs CPU SDPA bit-equal {eq:.5f}")
+            assert eq > 0.99
+    finally:
+        eng.call("zn_debug_tune", 19, 3)
+
+
 @pytest.mark.parametrize("kernel", [1, 2], ids=["mfma", "valu"])
 def test_attention_prefill_vs_cpu_sdpa(full, kernel):
     """zn_op_attn_prefill vs torch CPU SDPA(is_causal=True) — the S > 1 call of _torch.py:415 — on random bf16 q/K/V at

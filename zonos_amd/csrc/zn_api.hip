@@ -511,13 +511,27 @@ static bool attn_fused_for(zn_handle h, int keys_upper_bound) {
   return keys_upper_bound <= lim;
 }
 
+#ifndef ZN_ATTN_DSF
+#define ZN_ATTN_DSF 4
+#endif
+#ifndef ZN_ATTN_DSS
+#define ZN_ATTN_DSS 2
+#endif
 template <int HD>
-static int launch_attn_g(const AttnArgs& a, int G, dim3 grid, bool fused, hipStream_t s) {
+static int launch_attn_g(const AttnArgs& a, int G, dim3 grid, bool fused, bool split_cols, hipStream_t s) {
+  constexpr int DS = HD == 128 ? ZN_ATTN_DSS : 1;       // value-column parts per (row, kv head[, block]) when split_cols (attn_block_kernel)
+  constexpr int DSF = HD == 128 ? ZN_ATTN_DSF : 1;      // ... of the one-launch shape
   switch (G) {
 #define ZN_ATTN_CASE(GG) case GG: \
-    if (fused) { hipLaunchKernelGGL((attn_block_kernel<HD, GG, true>), dim3(grid.y * grid.z), dim3(512), 0, s, a); return 0; } \
+    if (fused) { \
+      if (split_cols && DSF > 1) hipLaunchKernelGGL((attn_block_kernel<HD, GG, true, DSF>), dim3(grid.y * grid.z * DSF), dim3(512), 0, s, a); \
+      else hipLaunchKernelGGL((attn_block_kernel<HD, GG, true>), dim3(grid.y * grid.z), dim3(512), 0, s, a); \
+      return 0; \
+    } \
     hipLaunchKernelGGL((attn_scores_kernel<HD, GG>), grid, dim3(256), 0, s, a); \
-    hipLaunchKernelGGL((attn_block_kernel<HD, GG, false>), dim3(grid.y, grid.z * a.nbcap), dim3(512), 0, s, a); return 0;
+    if (split_cols && DS > 1) hipLaunchKernelGGL((attn_block_kernel<HD, GG, false, DS>), dim3(grid.y * DS, grid.z * a.nbcap), dim3(512), 0, s, a); \
+    else hipLaunchKernelGGL((attn_block_kernel<HD, GG, false>), dim3(grid.y, grid.z * a.nbcap), dim3(512), 0, s, a); \
+    return 0;
     ZN_ATTN_CASE(1) ZN_ATTN_CASE(2) ZN_ATTN_CASE(4) ZN_ATTN_CASE(8)
 #undef ZN_ATTN_CASE
   }
@@ -535,9 +549,9 @@ static int ensure_attn_ws(zn_handle h, int max_len) {
   HIPCHK(h, hipMalloc(&h->scores, RH * lcap * sizeof(float)));
   HIPCHK(h, hipMalloc(&h->cmax, RH * nc * sizeof(float)));
   { const size_t groups = (size_t)h->max_rows * h->cfg.n_heads_kv;
-    HIPCHK(h, hipMalloc(&h->pv_part, groups * (lcap / 512) * (size_t)(h->G * h->hd + h->G) * sizeof(float)));
-    HIPCHK(h, hipMalloc(&h->pv_tickets, groups * sizeof(int)));
-    HIPCHK(h, hipMemset(h->pv_tickets, 0, groups * sizeof(int))); }
+    HIPCHK(h, hipMalloc(&h->pv_part, groups * (lcap / 512) * (size_t)(h->G * h->hd + 4 * h->G) * sizeof(float)));     // (up to four column parts, each with its e sums)
+    HIPCHK(h, hipMalloc(&h->pv_tickets, 4 * groups * sizeof(int)));
+    HIPCHK(h, hipMemset(h->pv_tickets, 0, 4 * groups * sizeof(int))); }
   h->lcap = lcap;
   return ZN_OK;
 }
@@ -557,8 +571,10 @@ static int run_attention(zn_handle h, const bf16_t* q, const bf16_t* kv, int max
   const bool fused = h->attn_fused;
   a.part = h->pv_part; a.tickets = h->pv_tickets; a.nbcap = (max_len + 511) / 512;
   if (a.nbcap > 32) ZN_FAIL(h, ZN_ERR_ARG, "attention: %d keys of capacity exceed the 32 blocks the split pass combines", max_len);
-  int r2 = hd == 128 ? launch_attn_g<128>(a, h->G, grid, fused, s) : hd == 64 ? launch_attn_g<64>(a, h->G, grid, fused, s)
-                                                                             : launch_attn_g<32>(a, h->G, grid, fused, s);
+  // batches of 3..8 utterances: two workgroups per (row, kv head[, block]), each with half of the value columns (tune[19] = 1: never, 2: always)
+  const bool sc = h->tune[19] == 2 || (h->tune[19] != 1 && rows > 4);
+  int r2 = hd == 128 ? launch_attn_g<128>(a, h->G, grid, fused, sc, s) : hd == 64 ? launch_attn_g<64>(a, h->G, grid, fused, sc, s)
+                                                                                 : launch_attn_g<32>(a, h->G, grid, fused, sc, s);
   if (r2) ZN_FAIL(h, ZN_ERR_UNSUPPORTED, "attention: unsupported group %d", h->G);
   return ZN_OK;
 }

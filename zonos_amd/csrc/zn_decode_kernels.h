@@ -1182,12 +1182,24 @@ ZN_DEVINL void attn_block_mask_v(AttnV<HD>& V, int key0, int L, int lane) {
 // SPLIT (!FUSED): after attn_scores_kernel, one workgroup per (row, kv head, 512-key block): running maximum from the chunk maxima of all
 //   earlier chunks, the block's unnormalised P.V and e sums leave as write-through partials, and the last workgroup of a (row, kv head) to
 //   arrive (ticket, no waiting) replays the recurrence over the blocks in order and normalises.
-template <int HD, int G, bool FUSED>
+// DS > 1 (batches of 3..8 utterances): DS workgroups per (row, kv head[, block]), each with all the scores / P of the pair and HD / DS of the value
+//   columns - every output column keeps its arithmetic (a column of P.V depends on P and its own V column only), the K rows are read DS times
+//   (the second reader of a pair sits 8 workgroups later, i.e. on the same XCD's L2 as dispatch goes), the V read per CU halves: a CU sustains
+//   only a few tens of GB/s and 16 rows x 4 kv heads are 64 workgroups.
+template <int HD, int G, bool FUSED, int DS = 1>
 __global__ __launch_bounds__(512) void attn_block_kernel(AttnArgs a) {
-  constexpr int NW = 8, GL = (G + 3) / 4;
-  int kvh, r, jb;
-  if constexpr (FUSED) { kvh = blockIdx.x % a.n_heads_kv; r = blockIdx.x / a.n_heads_kv; jb = 0; }
-  else { kvh = blockIdx.x; r = blockIdx.y / a.nbcap; jb = blockIdx.y % a.nbcap; }
+  constexpr int NW = 8, GL = (G + 3) / 4, HDV = HD / DS;
+  static_assert(HD % DS == 0 && HDV % 32 == 0, "value-column split");
+  int kvh, r, jb, hv = 0;
+  if constexpr (FUSED) {
+    int pair = blockIdx.x;
+    if constexpr (DS > 1) {
+      const int q = blockIdx.x, npairs = gridDim.x / DS;
+      if (npairs % 8 == 0) { pair = (q / (8 * DS)) * 8 + (q % 8); hv = (q / 8) % DS; }
+      else { pair = q / DS; hv = q % DS; }
+    }
+    kvh = pair % a.n_heads_kv; r = pair / a.n_heads_kv; jb = 0;
+  } else { kvh = blockIdx.x % a.n_heads_kv; hv = blockIdx.x / a.n_heads_kv; r = blockIdx.y / a.nbcap; jb = blockIdx.y % a.nbcap; }
   int nst = 0;
   auto stamp = [&]() { if (FUSED && a.stamps && blockIdx.x == 0 && threadIdx.x == 0) a.stamps[nst] = __builtin_amdgcn_s_memrealtime(); ++nst; };
   stamp();
@@ -1201,11 +1213,11 @@ __global__ __launch_bounds__(512) void attn_block_kernel(AttnArgs a) {
   const int tb = jb * 512;
   __shared__ float s_sc[G][512];
   __shared__ __attribute__((aligned(16))) bf16_t s_p[G][512];
-  __shared__ __attribute__((aligned(16))) float s_accw[NW][G][HD];
+  __shared__ __attribute__((aligned(16))) float s_accw[NW][G][HDV];
   __shared__ float s_l[NW][G];
   __shared__ float s_bm[NW][G];
-  AttnV<HD> V;
-  attn_block_load_v<HD>(V, kvr + (size_t)(a.n_heads_kv + kvh) * HD, kvrow, tb + wave * 64, a.max_len - 1, lane);
+  AttnV<HDV> V;
+  attn_block_load_v<HDV>(V, kvr + (size_t)(a.n_heads_kv + kvh) * HD + hv * HDV, kvrow, tb + wave * 64, a.max_len - 1, lane);
   float mnew[GL];
   int L, nb;
   if constexpr (FUSED) {
@@ -1318,33 +1330,33 @@ __global__ __launch_bounds__(512) void attn_block_kernel(AttnArgs a) {
     }
     __syncthreads();                                      // the scores are in LDS
   }
-  attn_block_mask_v<HD>(V, tb + wave * 64, L, lane);
+  attn_block_mask_v<HDV>(V, tb + wave * 64, L, lane);
   int E = Eraw > 0 ? Eraw : L;
   if (E < L) E = L;
   const int nkeys = min(512, L - tb), nvec = min(512, E - tb) & ~15;
   attn_block_probs<G>(s_sc, mnew, nkeys, nvec, s_p, s_l, wave, lane);
   __syncthreads();
   stamp();
-  attn_block_pv<HD, G>(s_p, V, s_accw, wave, lane);
+  attn_block_pv<HDV, G>(s_p, V, s_accw, wave, lane);
   __syncthreads();
   stamp();
   if constexpr (FUSED) {
-    for (int o = tid; o < G * HD; o += 512) {
-      const int g = o / HD, d = o % HD;
+    for (int o = tid; o < G * HDV; o += 512) {
+      const int g = o / HDV, d = o % HDV;
       float v = 0.f, l = 0.f;
 #pragma unroll
       for (int w = 0; w < NW; ++w) v += s_accw[w][g][d];
 #pragma unroll
       for (int w = 0; w < NW; ++w) l += s_l[w][g];
-      a.out[((size_t)r * a.n_heads + kvh * G + g) * HD + d] = f2bf(__fmul_rn(v, 1.0f / l));
+      a.out[((size_t)r * a.n_heads + kvh * G + g) * HD + hv * HDV + d] = f2bf(__fmul_rn(v, 1.0f / l));
     }
     stamp();
   } else {
-    constexpr int PSZ = G * HD + G;
-    const int group = r * a.n_heads_kv + kvh;
+    constexpr int PSZ = G * HDV + G;                      // per (row, kv head, column part, block): its P.V columns and (a copy of) the e sums
+    const int group = (r * a.n_heads_kv + kvh) * DS + hv;
     float* pp = a.part + ((size_t)group * a.nbcap + jb) * PSZ;
-    for (int o = tid; o < G * HD; o += 512) {
-      const int g = o / HD, d = o % HD;
+    for (int o = tid; o < G * HDV; o += 512) {
+      const int g = o / HDV, d = o % HDV;
       float v = 0.f;
 #pragma unroll
       for (int w = 0; w < NW; ++w) v += s_accw[w][g][d];
@@ -1353,7 +1365,7 @@ __global__ __launch_bounds__(512) void attn_block_kernel(AttnArgs a) {
         float l = 0.f;
 #pragma unroll
         for (int w = 0; w < NW; ++w) l += s_l[w][g];
-        st_wt(pp + G * HD + g, l);
+        st_wt(pp + G * HDV + g, l);
       }
     }
     __builtin_amdgcn_s_waitcnt(0);                        // stores acknowledged before the ticket
@@ -1383,8 +1395,8 @@ __global__ __launch_bounds__(512) void attn_block_kernel(AttnArgs a) {
     }
     __syncthreads();
     const float* pb = a.part + (size_t)group * a.nbcap * PSZ;
-    for (int o = tid; o < G * HD; o += 512) {
-      const int g = o / HD;
+    for (int o = tid; o < G * HDV; o += 512) {
+      const int g = o / HDV;
       float tot = 0.f, lt = 0.f, mprev = -INFINITY;
       for (int j0 = 0; j0 < nb; j0 += 8) {
         // eight blocks' partials requested at once (one memory round trip per eight blocks, not per block)
@@ -1393,7 +1405,7 @@ __global__ __launch_bounds__(512) void attn_block_kernel(AttnArgs a) {
         for (int u = 0; u < 8; ++u) {
           const int j = min(j0 + u, nb - 1);
           pv[u] = ld_wt(pb + (size_t)j * PSZ + o);
-          pl[u] = ld_wt(pb + (size_t)j * PSZ + G * HD + g);
+          pl[u] = ld_wt(pb + (size_t)j * PSZ + G * HDV + g);
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
@@ -1407,7 +1419,7 @@ __global__ __launch_bounds__(512) void attn_block_kernel(AttnArgs a) {
           }
         }
       }
-      a.out[((size_t)r * a.n_heads + kvh * G + g) * HD + (o % HD)] = f2bf(__fmul_rn(tot, 1.0f / lt));
+      a.out[((size_t)r * a.n_heads + kvh * G + g) * HD + hv * HDV + (o % HDV)] = f2bf(__fmul_rn(tot, 1.0f / lt));
     }
   }
 }
