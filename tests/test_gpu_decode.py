@@ -263,7 +263,7 @@ def test_attention_long_context_split_pass_vs_cpu_sdpa(full):
 
 def test_attention_value_column_split_is_bit_identical(full):
     """Batches of 3..8 utterances launch TWO workgroups per (row, kv head[, 512-key block]), each with all the scores / P of the pair and
-    half of the value columns (attn_block_kernel<..., DS = 2>; zn_debug_tune(19, 2) forces it, (19, 1) forbids it).  A column of P.V depends
+    part of the value columns (attn_block_kernel<..., DS>; zn_debug_tune(19, 2) forces it, (19, 1) forbids it).  A column of P.V depends
     on P and its own V column only, so the outputs must be the SAME BITS as the unsplit launches: 16 rows of ragged lengths (one block, the
     512 / 513 boundary, several blocks, a row of one key), both launch shapes, twice each (the split shape's tickets return to zero); one
     case against torch CPU SDPA as well, so that the common value is the right one."""
@@ -275,6 +275,7 @@ def test_attention_value_column_split_is_bit_identical(full):
     R = 16
     try:
         for cap, lens in ((512, [1, 2, 15, 16, 17, 63, 64, 65, 100, 255, 256, 300, 449, 480, 511, 512]),
+                          (1024, [1, 30, 511, 512, 513, 514, 528, 529, 600, 767, 768, 769, 1000, 1022, 1023, 1024]),
                           (1536, [1, 30, 511, 512, 513, 514, 600, 1000, 1023, 1024, 1025, 1100, 1400, 1500, 1535, 1536])):
             q = torch.randn(R, 16, 1, 128, generator=gen).to(torch.bfloat16)
             kv = torch.randn(R, cap, 2, 4, 128, generator=gen).to(torch.bfloat16)

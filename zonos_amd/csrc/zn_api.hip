@@ -113,7 +113,7 @@ struct zn_handle_s {
   hipGraph_t graph[ZN_NGRAPHS] = {};
   bool graph_tried[ZN_NGRAPHS] = {};
   int len_hi = 0;            // host-side upper bound of the rows' KV lengths (keys already cached)
-  bool attn_fused = false;   // launch shape of the next run_attention
+  int attn_fused = 0;        // launch shape of the next run_attention (attn_fused_for)
   std::string err;
 };
 
@@ -506,9 +506,13 @@ static int run_gemv(zn_handle h, GemvArgs a, int rows, int target_blocks, hipStr
 // by the attention role of zn_step_kernel.h).  The fused launch (scores + pass 2 + normalisation in one launch) serves contexts of one block:
 // tune[5] may lower that limit (tests), never raise it.
 #define ZN_AFUSED_LIMIT 512
-static bool attn_fused_for(zn_handle h, int keys_upper_bound) {
+// Launch shape of the decode attention for contexts of at most keys_upper_bound keys: 1 = the one-launch shape (one block), 0 = scores launch +
+// block launch.
+static bool attn_split_cols(zn_handle h, int rows) { return h->tune[19] == 2 || (h->tune[19] != 1 && rows > 4); }
+static int attn_fused_for(zn_handle h, int keys_upper_bound, int rows) {
+  (void)rows;
   const int lim = h->tune[5] < ZN_AFUSED_LIMIT ? h->tune[5] : ZN_AFUSED_LIMIT;
-  return keys_upper_bound <= lim;
+  return keys_upper_bound <= lim ? 1 : 0;
 }
 
 #ifndef ZN_ATTN_DSF
@@ -518,7 +522,7 @@ static bool attn_fused_for(zn_handle h, int keys_upper_bound) {
 #define ZN_ATTN_DSS 2
 #endif
 template <int HD>
-static int launch_attn_g(const AttnArgs& a, int G, dim3 grid, bool fused, bool split_cols, hipStream_t s) {
+static int launch_attn_g(const AttnArgs& a, int G, dim3 grid, int fused, bool split_cols, hipStream_t s) {
   constexpr int DS = HD == 128 ? ZN_ATTN_DSS : 1;       // value-column parts per (row, kv head[, block]) when split_cols (attn_block_kernel)
   constexpr int DSF = HD == 128 ? ZN_ATTN_DSF : 1;      // ... of the one-launch shape
   switch (G) {
@@ -568,11 +572,11 @@ static int run_attention(zn_handle h, const bf16_t* q, const bf16_t* kv, int max
   dim3 grid((max_len + ZN_ACHUNK - 1) / ZN_ACHUNK, c.n_heads_kv, rows);
   // one fused launch for contexts of one 512-key block (the caller bounds the context: h->attn_fused); beyond: scores, then the P.V pass
   // with one workgroup per (slice, kv head, row, 512-key block) and the ticketed in-order combine
-  const bool fused = h->attn_fused;
+  const int fused = h->attn_fused;
   a.part = h->pv_part; a.tickets = h->pv_tickets; a.nbcap = (max_len + 511) / 512;
   if (a.nbcap > 32) ZN_FAIL(h, ZN_ERR_ARG, "attention: %d keys of capacity exceed the 32 blocks the split pass combines", max_len);
   // batches of 3..8 utterances: two workgroups per (row, kv head[, block]), each with half of the value columns (tune[19] = 1: never, 2: always)
-  const bool sc = h->tune[19] == 2 || (h->tune[19] != 1 && rows > 4);
+  const bool sc = attn_split_cols(h, rows);
   int r2 = hd == 128 ? launch_attn_g<128>(a, h->G, grid, fused, sc, s) : hd == 64 ? launch_attn_g<64>(a, h->G, grid, fused, sc, s)
                                                                                  : launch_attn_g<32>(a, h->G, grid, fused, sc, s);
   if (r2) ZN_FAIL(h, ZN_ERR_UNSUPPORTED, "attention: unsupported group %d", h->G);
@@ -1370,7 +1374,7 @@ extern "C" int zn_prefill(zn_handle h, const void* hidden_dev, int32_t S, zn_str
     for (int p = 0; p < S; ++p) {
       hipLaunchKernelGGL(gather_pos_kernel, dim3(h->rows), dim3(256), 0, s, (const bf16_t*)hidden_dev, h->x, S, p, c.d_model);
       int ext = (p / qb) * qb + qb; if (ext > S) ext = S;
-      h->attn_fused = attn_fused_for(h, ++h->len_hi);
+      h->attn_fused = attn_fused_for(h, ++h->len_hi, h->rows);
       if (c.arch == 1) {
         if ((rc = hybrid_token(h, p == S - 1, s))) return rc;
       } else {
@@ -1415,7 +1419,7 @@ extern "C" int zn_decode_steps(zn_handle h, int32_t n, zn_stream stream) {
   }
   for (int i = 0; i < n;) {
     // this step appends one key per row; a run of ZN_GRAPH_STEPS steps with one launch shape replays the long graph
-    const bool fused = attn_fused_for(h, h->len_hi + 1);
+    const int fused = attn_fused_for(h, h->len_hi + 1, h->rows);
     const bool want_run = n - i >= ZN_GRAPH_STEPS && h->tune[6] > 1;
     // the whole-step kernel serves every step whose context fits one of its instantiations (stack_mode_for); a run of steps takes the
     // attention role its LAST step needs (workgroups of key blocks past a step's context leave at once)
@@ -1424,8 +1428,8 @@ extern "C" int zn_decode_steps(zn_handle h, int32_t n, zn_stream stream) {
     const int mode_one = st_ok ? stack_mode_for(h, h->rows, h->len_hi + 1) : -1;
     const bool stack_run = mode_run >= 0, stack = stack_run || mode_one >= 0;
     const int mode = stack_run ? mode_run : mode_one;
-    const int run = stack ? (stack_run ? ZN_GRAPH_STEPS : 1) : ((want_run && attn_fused_for(h, h->len_hi + ZN_GRAPH_STEPS) == fused) ? ZN_GRAPH_STEPS : 1);
-    const int k = stack ? (8 + (run > 1 ? ZN_SK_KB_MAXNB + 1 : 0) + mode) : ((fused ? 1 : 0) | (run > 1 ? 2 : 0));
+    const int run = stack ? (stack_run ? ZN_GRAPH_STEPS : 1) : ((want_run && attn_fused_for(h, h->len_hi + ZN_GRAPH_STEPS, h->rows) == fused) ? ZN_GRAPH_STEPS : 1);
+    const int k = stack ? (8 + (run > 1 ? ZN_SK_KB_MAXNB + 1 : 0) + mode) : (fused + (run > 1 ? 4 : 0));      // launches path: slots 0..2 and 4..6
     h->attn_fused = fused; h->use_stack = stack;
     if (stack) h->stack_nbk = mode;
     if (!h->graph_exec[k] && !h->graph_tried[k] && n > 1) {
@@ -1772,7 +1776,7 @@ extern "C" int zn_op_layer_decode(zn_handle h, int32_t layer, void* x, void* kv,
     ZN_FAIL(h, ZN_ERR_ARG, "zn_op_layer_decode: bad argument");
   int rc = ensure_attn_ws(h, max_len);
   if (rc) return rc;
-  h->attn_fused = attn_fused_for(h, max_len);   // lengths live on the device: bound the context by the capacity
+  h->attn_fused = attn_fused_for(h, max_len, rows);   // lengths live on the device: bound the context by the capacity
   rc = layer_decode(h, layer, (bf16_t*)x, (bf16_t*)kv, max_len, lengths, ext, 0, rows, (hipStream_t)stream);
   if (rc) return rc;
   HIPCHK(h, hipGetLastError());
@@ -1813,7 +1817,7 @@ extern "C" int zn_op_backbone_forward(zn_handle h, const void* hidden_dev, void*
     hipLaunchKernelGGL(gather_pos_kernel, dim3(rows), dim3(256), 0, s, hid, h->x, S, p, d);
     hipLaunchKernelGGL(fill_int_kernel, dim3(1), dim3(64 > rows ? 64 : rows), 0, s, h->fw_lengths, rows, base + p);
     int ext = (p / qb) * qb + qb; if (ext > S) ext = S;
-    h->attn_fused = attn_fused_for(h, base + p + 1);
+    h->attn_fused = attn_fused_for(h, base + p + 1, rows);
     for (int li = 0; li < c.n_layer; ++li) {
       if (c.arch == 1) rc = hybrid_layer(h, li, (void*)caches_dev[li], max_len, h->fw_lengths, rows, s);
       else rc = layer_decode(h, li, h->x, (bf16_t*)caches_dev[li], max_len, h->fw_lengths, nullptr, S > 1 ? base + ext : 0, rows, s);
@@ -1857,7 +1861,7 @@ extern "C" int zn_op_attn_decode(zn_handle h, const void* q, const void* kv, int
   if (rows > h->max_rows) ZN_FAIL(h, ZN_ERR_ARG, "zn_op_attn_decode: rows > max_rows");
   int rc = ensure_attn_ws(h, max_len);
   if (rc) return rc;
-  h->attn_fused = attn_fused_for(h, max_len);
+  h->attn_fused = attn_fused_for(h, max_len, rows);
   rc = run_attention(h, (const bf16_t*)q, (const bf16_t*)kv, max_len, lengths, ext, 0, (bf16_t*)out, rows, (hipStream_t)stream);
   if (rc) return rc;
   HIPCHK(h, hipGetLastError());

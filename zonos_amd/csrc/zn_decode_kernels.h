@@ -1182,6 +1182,58 @@ ZN_DEVINL void attn_block_mask_v(AttnV<HD>& V, int key0, int L, int lane) {
 // SPLIT (!FUSED): after attn_scores_kernel, one workgroup per (row, kv head, 512-key block): running maximum from the chunk maxima of all
 //   earlier chunks, the block's unnormalised P.V and e sums leave as write-through partials, and the last workgroup of a (row, kv head) to
 //   arrive (ticket, no waiting) replays the recurrence over the blocks in order and normalises.
+// Pass 1 of a 512-key block inside a one-launch shape: this wave's 16-key tiles (K rows in kk, requested whole - 16 lanes x 16 B = one 256-byte
+// key row per 16-lane phase; a fragment-shaped request would touch 16 different rows per phase and bound the pass by the vector-memory pipe -
+// and staged per wave in padded LDS, where the MFMA B fragments are read back conflict-free) -> S[head][key] = Q K^T as 16x16x32 tiles
+// (attn_scores_kernel's operands and order) into sc, the wave's maxima into bm[wave].  nk: keys of the block inside the context.
+template <int HD> struct AttnFusedK { static constexpr int KLD = HD + 8, LPK = HD / 8, KPL = 64 / LPK, NLD = 16 / KPL, TPW = 512 / 16 / 8; };
+template <int HD>
+ZN_DEVINL void attn_fused_load_k(u32x4 (&kk)[AttnFusedK<HD>::TPW][AttnFusedK<HD>::NLD], const bf16_t* kcol0, size_t kvrow, int tb, int row_max, int wave, int lane) {
+  using C = AttnFusedK<HD>;
+  const int kq = lane / C::LPK, kd = lane % C::LPK;
+#pragma unroll
+  for (int tl = 0; tl < C::TPW; ++tl)
+#pragma unroll
+    for (int i = 0; i < C::NLD; ++i) kk[tl][i] = ld16(kcol0 + kd * 8 + (size_t)min(tb + (tl * 8 + wave) * 16 + C::KPL * i + kq, row_max) * kvrow);
+}
+template <int HD, int G>
+ZN_DEVINL void attn_fused_scores(const zn_bf16x8 (&qa)[HD / 32], const u32x4 (&kk)[AttnFusedK<HD>::TPW][AttnFusedK<HD>::NLD], bf16_t* kw, float (*sc)[512],
+                                 float (*bm)[G], int nk, float scale, int wave, int lane) {
+  using C = AttnFusedK<HD>;
+  constexpr int KST = HD / 32;
+  const int kn = lane & 15, kg = lane >> 4, kq = lane / C::LPK, kd = lane % C::LPK;
+  float mx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+  for (int tl = 0; tl < C::TPW; ++tl) {
+    const int tt = (tl * 8 + wave) * 16;
+    if (tt < nk) {                                            // wave-uniform
+#pragma unroll
+      for (int i = 0; i < C::NLD; ++i) *(u32x4*)(kw + (C::KPL * i + kq) * C::KLD + kd * 8) = kk[tl][i];
+      f32x4 c = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int st = 0; st < KST; ++st) {
+        const u32x4 bfrag = *(const u32x4*)(kw + kn * C::KLD + 32 * st + 8 * kg);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa[st], __builtin_bit_cast(zn_bf16x8, bfrag), c, 0, 0, 0);
+      }
+      const int t = tt + kn;
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int head = 4 * kg + reg;
+        if (head < G && t < nk) {
+          const float sv = __fmul_rn(c[reg], scale);
+          mx[reg] = fmaxf(mx[reg], sv);
+          sc[head][t] = sv;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    const float m = wave_max(kg == g / 4 ? mx[g % 4] : -INFINITY);
+    if (lane == 0) bm[wave][g] = m;
+  }
+}
+
 // DS > 1 (batches of 3..8 utterances): DS workgroups per (row, kv head[, block]), each with all the scores / P of the pair and HD / DS of the value
 //   columns - every output column keeps its arithmetic (a column of P.V depends on P and its own V column only), the K rows are read DS times
 //   (the second reader of a pair sits 8 workgroups later, i.e. on the same XCD's L2 as dispatch goes), the V read per CU halves: a CU sustains
@@ -1223,7 +1275,7 @@ __global__ __launch_bounds__(512) void attn_block_kernel(AttnArgs a) {
   if constexpr (FUSED) {
     // ---- pass 1 in LDS: S[head][key] = Q K^T as 16x16x32 tiles (attn_scores_kernel's operands and order)
     static_assert(HD % 32 == 0 && G <= 16, "fused attention tile shape");
-    constexpr int KST = HD / 32, TPW = 512 / 16 / NW;
+    constexpr int KST = HD / 32;
     const int kn = lane & 15, kg = lane >> 4;
     zn_bf16x8 qa[KST];
 #pragma unroll
@@ -1232,53 +1284,14 @@ __global__ __launch_bounds__(512) void attn_block_kernel(AttnArgs a) {
       if (kn < G) v = ld16(a.q + ((size_t)r * a.n_heads + kvh * G + kn) * HD + 32 * st + 8 * kg);
       qa[st] = __builtin_bit_cast(zn_bf16x8, v);
     }
-    // K rows are fetched whole (16 lanes x 16 B = one 256-byte key row per 16-lane phase; a fragment-shaped request would touch 16 different
-    // rows per phase and bound the pass by the vector-memory pipe) and staged per wave in padded LDS, where the MFMA B fragments are read back
-    // conflict-free.
-    constexpr int KLD = HD + 8, LPK = HD / 8, KPL = 64 / LPK, NLD = 16 / KPL;   // lanes per key row, keys per wave-load, loads per tile
-    __shared__ __attribute__((aligned(16))) bf16_t s_k[NW][16 * KLD];
-    const int kq = lane / LPK, kd = lane % LPK;
-    const bf16_t* kbase = kvr + (size_t)kvh * HD + kd * 8;
-    u32x4 kk[TPW][NLD];
-#pragma unroll
-    for (int tl = 0; tl < TPW; ++tl)
-#pragma unroll
-      for (int i = 0; i < NLD; ++i) kk[tl][i] = ld16(kbase + (size_t)min((tl * NW + wave) * 16 + KPL * i + kq, a.max_len - 1) * kvrow);
+    using KC = AttnFusedK<HD>;
+    __shared__ __attribute__((aligned(16))) bf16_t s_k[NW][16 * KC::KLD];
+    u32x4 kk[KC::TPW][KC::NLD];
+    attn_fused_load_k<HD>(kk, kvr + (size_t)kvh * HD, kvrow, 0, a.max_len - 1, wave, lane);
     __builtin_amdgcn_sched_barrier(0);
     L = Lraw + 1; nb = 1;
     stamp();
-    bf16_t* kw = &s_k[wave][0];
-    float mx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-    const int tend = min(L, 512);
-#pragma unroll
-    for (int tl = 0; tl < TPW; ++tl) {
-      const int tt = (tl * NW + wave) * 16;
-      if (tt < tend) {                                          // wave-uniform
-#pragma unroll
-        for (int i = 0; i < NLD; ++i) *(u32x4*)(kw + (KPL * i + kq) * KLD + kd * 8) = kk[tl][i];
-        f32x4 c = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int st = 0; st < KST; ++st) {
-          const u32x4 bfrag = *(const u32x4*)(kw + kn * KLD + 32 * st + 8 * kg);
-          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa[st], __builtin_bit_cast(zn_bf16x8, bfrag), c, 0, 0, 0);
-        }
-        const int t = tt + kn;
-#pragma unroll
-        for (int reg = 0; reg < 4; ++reg) {
-          const int head = 4 * kg + reg;
-          if (head < G && t < tend) {
-            const float sv = __fmul_rn(c[reg], a.scale);
-            mx[reg] = fmaxf(mx[reg], sv);
-            s_sc[head][t] = sv;
-          }
-        }
-      }
-    }
-#pragma unroll
-    for (int g = 0; g < G; ++g) {
-      const float m = wave_max(kg == g / 4 ? mx[g % 4] : -INFINITY);
-      if (lane == 0) s_bm[wave][g] = m;
-    }
+    attn_fused_scores<HD, G>(qa, kk, &s_k[wave][0], s_sc, s_bm, min(L, 512), a.scale, wave, lane);
     stamp();
     __syncthreads();
     stamp();
@@ -1423,6 +1436,10 @@ __global__ __launch_bounds__(512) void attn_block_kernel(AttnArgs a) {
     }
   }
 }
+
+// (Measured and dropped, round 4: a one-launch shape that walks TWO blocks per workgroup - scores, e / P, P.V per block, the recurrence in the
+// split shape's arithmetic; bit-identical - for 5..16 rows at 513..1024 keys: 1.699 vs 1.697 ms per batch-8 step.  One CU then pulls the K rows
+// of 1024 keys, which costs what the second launch and the ticket do.)
 
 // ------------------------------------------------------------------------------------------------ embedding
 struct EmbedArgs {
