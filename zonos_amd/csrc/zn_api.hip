@@ -371,6 +371,7 @@ static bool run_gemm16s(zn_handle h, GemvArgs g, hipStream_t s) {
   int ks = 1;
   while (groups * ks < 448 && ks < 16 && K % (2 * ks * ZN_G16_KC) == 0) ks *= 2;
   // (fc2 at 16 rows, K = 8192 over 64 groups: 8 slices; 4: 1.690, 8: 1.681, 16: 1.746 ms per batch-8 step)
+  // (the Mamba2 in_proj, N = 8512 over 266 groups: 1 / 2 (default) / 4 slices: 1.933 / 1.937 / 1.945 ms per batch-8 hybrid step)
   if (ks > 1 && K / ks < 512) {
     // short slices: the combine costs more than the direct-fragment kernel's access pattern, unless a shallower split
     // still fills the chip (in_proj, N = 3072: 96 groups x 4 slices of 512)
