@@ -1007,16 +1007,16 @@ def test_small_m_projections_match_the_gemv_path(full):
         assert md <= 2.0 ** -5 * max(1.0, yb.float().abs().max().item())
 
 
-@pytest.mark.parametrize("R", [16, 10, 5])
+@pytest.mark.parametrize("R", [16, 10, 5, 24])
 def test_fc1_layernorm_from_handed_over_statistics(full, R):
     """Rows 5..16: fc1's nn.LayerNorm (_torch.py:325, `norm2`) is not a launch - the second out_proj's epilogue leaves {sum, centred second
     moment} per row and 16-column tile, fc1 adds the tiles in a fixed order and normalises its activation chunks while staging them
     (gemm16s_kernel<EPI_SILU, ., true>).  Against the same block with layernorm_kernel in between (zn_debug_tune(9, 2)): the statistics are
     the same numbers summed in another order (tile-wise instead of lane-wise), so the normalised rows may differ by a bf16 ulp here and
     there; block output bit-equal > 0.98 and within 2^-6 of its scale, new K/V (produced before the change) bit-equal; ragged row counts
-    (10, 5: clamped rows of the last group) included.  The batch-8 tests above hold the path against the oracle."""
+    (10, 5: clamped rows of the last group; 24: two row groups per launch pair) included.  The batch-8 tests above hold the path against the oracle."""
     model, _ = full
-    eng = model.engine(8)
+    eng = model.engine(max(8, (R + 1) // 2))
     st = _lib.stream_ptr()
     L, max_len = 40, 64
     x0 = synth.conditioning(98, "lnp.x", R, 1, 2048)[:, 0].contiguous()
