@@ -290,7 +290,7 @@ def run_rank(args) -> int:
         kname = {6: "step_kernel<NCH=4,T_OUT=2,T_FC1=10,T_FC2=5,T_IN=6,NBV=6> (whole decode step in one persistent launch: per block attention, out_proj x2, LayerNorm+fc1+SiLU-gate, fc2, "
                     f"next block's LayerNorm+in_proj+RoPE+KV append; norm_f + heads; context {STEP_KERNEL_CTX} keys)",
                  5: "chain_kernel<NCH=4,T_OUT=1,T_FC1=8,T_FC2=4,T_IN=2> (out_proj x2 + LayerNorm+fc1+SiLU-gate + fc2 + next block's LayerNorm+in_proj+RoPE+KV append, one persistent launch)",
-                 0: "gemm16s/gemv LayerNorm+fc1+SiLU-gate"}[which]
+                 0: "gemm16s_kernel<EPI_SILU, ., LNP> (5..16 rows: LayerNorm from the statistics out_proj's epilogue left + fc1 + SiLU-gate in one launch) / gemv LayerNorm+fc1+SiLU-gate (2..4 rows)"}[which]
         result["roofline"] = {"bound": "hbm", "kernel": kname,
                               "achieved": round(ach / 1e9, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": round(ach / HBM_PEAK, 4),
                               "traffic": traffic, "traffic_note": traffic_note, "bytes_per_launch": by.value, "us_per_launch": round(ms.value * 1e3, 3)}

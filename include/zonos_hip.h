@@ -231,7 +231,8 @@ int zn_op_backbone_forward(zn_handle h, const void* hidden_dev, void* out_dev, c
 /* ---------------------------------------------------------------- measurement */
 /* Average duration (HIP events on `stream`) of one of the decode step's weight-streaming kernels over `iters`
  * launches that cycle through the layers' weights, and its algorithmic bytes per launch (the weight matrix).
- * which: 0 = LayerNorm+fc1+SiLU-gate, 1 = fc2+residual, 2 = out_proj+residual, 3 = LayerNorm+heads,
+ * which: 0 = LayerNorm+fc1+SiLU-gate (5..16 rows: the one launch a decode step makes there, fc1 normalising from the statistics its
+ * producer left - that producer runs once outside the timed loop; zn_debug_tune(9, 2): the LayerNorm launch + fc1), 1 = fc2+residual, 2 = out_proj+residual, 3 = LayerNorm+heads,
  * 4 = LayerNorm+in_proj+RoPE+KV-append (into a scratch cache), 5 = the persistent post-attention chain of one block
  * (out_proj twice, LayerNorm+fc1+SiLU-gate, fc2, next block's LayerNorm+in_proj+RoPE+KV-append in ONE launch: batch 1 only;
  * bytes = those four weight matrices, out_proj counted once), 6 = the whole-step kernel (every block of a decode step and the heads in
