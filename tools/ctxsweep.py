@@ -29,6 +29,7 @@ def main():
     model, _ = build_model(synth.FULL_CFG, 1234, dev)
     eng = model.engine(1)
     eng.call("zn_debug_eos_bias", float("-inf"))
+    extra = [tuple(int(v) for v in kv.split("=")) for kv in filter(None, os.environ.get("ZN_TUNE", "").split(","))]      # e.g. ZN_TUNE=17=4
     st = _lib.stream_ptr()
     sp = _sampling_struct({"temperature": 0.0}, 1)
     W = 3_200_290_816
@@ -40,7 +41,7 @@ def main():
             ip.key_value_memory_dict[i][0].normal_()
         cells = []
         for m in modes:
-            for k, v in MODES[m].items():
+            for k, v in list(MODES[m].items()) + extra:
                 eng.call("zn_debug_tune", k, v)
             codes = torch.randint(0, 1024, (1, 9, max_new), dtype=torch.int32, device=dev)
             codes[..., L0:] = -1
